@@ -1,0 +1,103 @@
+"""Deterministic synthetic factor chains for tests and bench.py.
+
+Pure numpy/scipy input generation -- no oracle, no device code.  A chain is T states of size n with
+block-tridiagonal precision; factors come in homogeneous *sets* (same kind, d, GH degree), the unit
+the C-ABI works on.  psi parameter blocks use the C-ABI layouts of include/gvi_hip.h:
+
+  QUAD_PRIOR  [Phi (n x n, row-major) | Qinv (n x n)]          d = 2n   (gp/minimum_acc_prior.h, gp/LTV_prior.h)
+  FIXED_PRIOR [mu0 (d) | Kinv (d x d)]                         d = n    (gp/fixed_prior.h)
+  RANGE_1D    [y, mu_p, f*b, sig_r_sq, sig_p_sq]               d = 1    (src/1d_example.cpp:25-35)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK = 0, 1, 2, 3
+
+CONFIGS = {
+    # name: (cfg#, T, n, p, prior kind)
+    "tiny": (0, 5, 2, 3, "minacc"),
+    "c2": (2, 65, 2, 3, "minacc"),          # BASELINE.json configs[1]
+    "c3mini": (31, 9, 6, 5, "ltv"),
+    "c3small": (32, 33, 6, 5, "ltv"),
+    "c3": (3, 1025, 6, 5, "ltv"),           # BASELINE.json configs[2] (headline)
+}
+
+
+def _minacc(nd, qc, dt):
+    I = np.eye(nd)
+    Phi = np.block([[I, dt * I], [np.zeros((nd, nd)), I]])
+    iQc = np.eye(nd) / qc
+    Qinv = np.block([[12 * iQc / dt ** 3, -6 * iQc / dt ** 2], [-6 * iQc / dt ** 2, 4 * iQc / dt]])
+    return Phi, Qinv
+
+
+def _ltv(rng, nd, dt):
+    """Exact discretisation over 4 piece-wise-constant sub-intervals of a seeded stable second-order
+    system x'' = -Kp x - Kd x' + B2 u (state [x, x']): the maths of gp/LTV_prior.h:123-197."""
+    from scipy.linalg import expm
+    n = 2 * nd
+    Phi, Q = np.eye(n), np.zeros((n, n))
+    h = dt / 4
+    for _ in range(4):
+        Kp = np.diag(rng.uniform(0.5, 2.0, nd)) + 0.1 * rng.normal(size=(nd, nd))
+        Kd = np.diag(rng.uniform(0.5, 1.5, nd)) + 0.1 * rng.normal(size=(nd, nd))
+        A = np.block([[np.zeros((nd, nd)), np.eye(nd)], [-Kp, -Kd]])
+        B = np.vstack([np.zeros((nd, nd)), np.eye(nd) + 0.1 * rng.normal(size=(nd, nd))])
+        M = np.zeros((2 * n, 2 * n))
+        M[:n, :n], M[:n, n:], M[n:, n:] = -A, B @ B.T, A.T
+        E = expm(M * h)
+        Ad = E[n:, n:].T
+        Qd = Ad @ E[:n, n:]
+        Phi = Ad @ Phi
+        Q = Ad @ Q @ Ad.T + (Qd + Qd.T) / 2
+    return Phi, np.linalg.inv(Q)
+
+
+def make_chain(name: str):
+    cfg, T, n, p, kind = CONFIGS[name]
+    rng = np.random.default_rng(0x5EED + cfg)
+    nd, K = n // 2, T - 1
+    dt = 0.1 if kind == "minacc" else 0.05
+    Phi = np.zeros((K, n, n))
+    Qinv = np.zeros((K, n, n))
+    for k in range(K):
+        Phi[k], Qinv[k] = _minacc(nd, 0.8, dt) if kind == "minacc" else _ltv(rng, nd, dt)
+    # start state: straight line with constant velocity + jitter
+    goal = rng.uniform(1.0, 2.0, nd)
+    t = np.arange(T)[:, None] * dt
+    horizon = (T - 1) * dt
+    mu0 = np.hstack([goal[None, :] * t / horizon, np.tile(goal / horizon, (T, 1))])
+    mu0 = mu0 + 0.05 * rng.normal(size=mu0.shape)
+    # anchors: fixed Gaussian priors on the first and the last state, K0 = 1e-2 I
+    anchor_mu = np.stack([np.hstack([np.zeros(nd), goal / horizon]), np.hstack([goal, goal / horizon])])
+    Kinv = np.stack([np.eye(n) / 1e-2] * 2)
+    # initial precision: 0.7 x (sum of factor Hessians) -- PD block-tridiagonal
+    D0 = np.zeros((T, n, n))
+    U0 = np.zeros((T - 1, n, n))
+    for k in range(K):
+        Lam = np.hstack([-Phi[k], np.eye(n)])
+        M = Lam.T @ Qinv[k] @ Lam
+        D0[k] += M[:n, :n]
+        D0[k + 1] += M[n:, n:]
+        U0[k] += M[:n, n:]
+    D0[0] += 2 * Kinv[0]
+    D0[T - 1] += 2 * Kinv[1]
+    D0, U0 = 0.7 * D0, 0.7 * U0
+    specs = [
+        dict(kind=PSI_QUAD_PRIOR, d=2 * n, p=p, start=np.arange(K, dtype=np.int32),
+             params=np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1),
+             temperature=np.ones(K), Phi=Phi, Qinv=Qinv),
+        dict(kind=PSI_FIXED_PRIOR, d=n, p=p, start=np.array([0, T - 1], dtype=np.int32),
+             params=np.concatenate([anchor_mu, Kinv.reshape(2, -1)], axis=1),
+             temperature=np.ones(2), mu0=anchor_mu, Kinv=Kinv),
+    ]
+    return dict(name=name, T=T, n=n, specs=specs, mu0=mu0, D0=D0, U0=U0)
+
+
+def random_marginals(rng, K, d, scale=1.0):
+    """Seeded (mu_k, Sigma_k) with SPD Sigma_k, for operator-level parity tests."""
+    mu = rng.normal(size=(K, d))
+    B = rng.normal(size=(K, d, d))
+    Sigma = scale * (B @ np.transpose(B, (0, 2, 1)) / d + 0.2 * np.eye(d))
+    return mu, Sigma

@@ -1,0 +1,43 @@
+"""Test-side glue: synthetic chains (gaussianvi_amd.synthetic) + the oracle's psi closures."""
+import numpy as np
+
+import gvi_oracle as o
+from gaussianvi_amd import synthetic as syn
+
+
+def oracle_psi_batch(spec):
+    if spec["kind"] == syn.PSI_QUAD_PRIOR:
+        return o.psi_batch_quad_prior(spec["Phi"], spec["Qinv"])
+    if spec["kind"] == syn.PSI_FIXED_PRIOR:
+        return o.psi_batch_fixed_prior(spec["mu0"], spec["Kinv"])
+    if spec["kind"] == syn.PSI_RANGE_1D:
+        y, mu_p, fb, srs, sps = spec["params"][0]
+        return o.psi_batch_range_1d(y, mu_p, fb, srs, sps)
+    raise ValueError(spec["kind"])
+
+
+def oracle_psi_point(spec):
+    def make(k):
+        if spec["kind"] == syn.PSI_QUAD_PRIOR:
+            return lambda x: o.psi_quad_prior(x, spec["Phi"][k], spec["Qinv"][k])
+        if spec["kind"] == syn.PSI_FIXED_PRIOR:
+            return lambda x: o.psi_fixed_prior(x, spec["mu0"][k], spec["Kinv"][k])
+        raise ValueError(spec["kind"])
+    return make
+
+
+def make_chain(name):
+    ch = syn.make_chain(name)
+    for spec in ch["specs"]:
+        spec["psi_batch"] = oracle_psi_batch(spec)
+        spec["psi_point"] = oracle_psi_point(spec)
+
+    def oracle_sets():
+        out = []
+        for spec in ch["specs"]:
+            fs = o.FactorSet(spec["start"], spec["d"], spec["p"], spec["psi_batch"])
+            fs.temperature = np.asarray(spec["temperature"], dtype=np.float64)
+            out.append(fs)
+        return out
+    ch["oracle_sets"] = oracle_sets
+    return ch
