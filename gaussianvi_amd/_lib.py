@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI library (include/gvi_hip.h).  No fallback: if the HIP extension is
+missing or does not load, importing the compute API raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgvi_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int8_p = C.POINTER(C.c_int8)
+c_void_pp = C.POINTER(C.c_void_p)
+
+# name -> argtypes; every function returns int status except the two string getters.
+# This table is also what tests/test_abi.py checks against include/gvi_hip.h.
+SIGNATURES = {
+    "gvi_ctx_create": [C.c_int, C.c_int, c_void_pp],
+    "gvi_ctx_destroy": [C.c_void_p],
+    "gvi_ctx_set_stream": [C.c_void_p, C.c_void_p],
+    "gvi_ctx_sync": [C.c_void_p],
+    "gvi_spgh_count": [C.c_int, C.c_int, C.POINTER(C.c_int64)],
+    "gvi_spgh_nodes": [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p],
+    "gvi_chain_set": [C.c_void_p, C.c_int, C.c_int],
+    "gvi_factors_add": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
+                        C.c_void_p, C.POINTER(C.c_int)],
+    "gvi_factors_set_table": [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p],
+    "gvi_factors_set_temperature": [C.c_void_p, C.c_int, C.c_void_p],
+    "gvi_factors_info": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                         C.POINTER(C.c_int64)],
+    "gvi_moments": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
+    "gvi_moments_dev": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
+    "gvi_raw_moments": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
+    "gvi_costs": [C.c_void_p, C.c_int] + [C.c_void_p] * 3,
+    "gvi_costs_dev": [C.c_void_p, C.c_int] + [C.c_void_p] * 3,
+    "gvi_expand": [C.c_void_p, C.c_int] + [C.c_void_p] * 3,
+    "gvi_moments_from_psi": [C.c_void_p, C.c_int] + [C.c_void_p] * 6,
+    "gvi_bt_assemble": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "gvi_bt_solve": [C.c_void_p] + [C.c_void_p] * 4,
+    "gvi_bt_logdet": [C.c_void_p] + [C.c_void_p] * 3,
+    "gvi_bt_marginals": [C.c_void_p] + [C.c_void_p] * 4,
+    "gvi_gather_marginals": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
+    "gvi_ngd_init": [C.c_void_p] + [C.c_void_p] * 3,
+    "gvi_ngd_cost": [C.c_void_p, c_double_p],
+    "gvi_ngd_factor_costs": [C.c_void_p, C.c_int, C.c_void_p],
+    "gvi_ngd_gradients": [C.c_void_p],
+    "gvi_ngd_trial": [C.c_void_p, C.c_double, c_double_p],
+    "gvi_ngd_accept": [C.c_void_p],
+    "gvi_ngd_step": [C.c_void_p, C.c_double, C.c_int, c_double_p, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int)],
+    "gvi_ngd_gradients_local": [C.c_void_p],
+    "gvi_ngd_gradients_finish": [C.c_void_p],
+    "gvi_ngd_trial_local": [C.c_void_p, C.c_double],
+    "gvi_ngd_trial_finish": [C.c_void_p, c_double_p],
+    "gvi_ngd_exchange": [C.c_void_p, C.c_int, c_void_pp, C.POINTER(C.c_int64)],
+    "gvi_ngd_get_state": [C.c_void_p] + [C.c_void_p] * 5,
+    "gvi_ngd_get_gradients": [C.c_void_p] + [C.c_void_p] * 6,
+    "gvi_profile_enable": [C.c_void_p, C.c_int],
+    "gvi_profile_last": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
+    "gvi_profile_geometry": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "gvi_set_variant": [C.c_void_p, C.c_int],
+}
+STRING_GETTERS = {"gvi_version": [], "gvi_last_error": [C.c_void_p]}
+
+_lib = None
+
+
+def load():
+    """Load gaussianvi_amd/libgvi_hip.so (built by gaussianvi_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m gaussianvi_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, args in STRING_GETTERS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_char_p
+    _lib = lib
+    return lib

@@ -1,0 +1,276 @@
+"""Thin numpy-facing wrapper over the C ABI (include/gvi_hip.h).  One method per entry point, same
+names and argument meaning; arrays are float64 C-contiguous.  All compute happens in the HIP
+library -- nothing here computes on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK = 0, 1, 2, 3
+GVI_F64, GVI_F32 = 0, 1
+
+
+class GviError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"gvi status {status}: {msg}")
+        self.status = status
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def spgh_count(d: int, p: int) -> int:
+    lib = _lib.load()
+    n = C.c_int64()
+    st = lib.gvi_spgh_count(d, p, C.byref(n))
+    if st:
+        raise GviError(st, lib.gvi_last_error(None).decode())
+    return n.value
+
+
+def spgh_nodes(d: int, p: int):
+    """(Z [N,d], w [N], idx [N,d,3] int8) from the product's host generator."""
+    lib = _lib.load()
+    N = spgh_count(d, p)
+    Z = np.empty((N, d)); w = np.empty(N); idx = np.empty((N, d, 3), dtype=np.int8)
+    st = lib.gvi_spgh_nodes(d, p, N, _p(Z), _p(w), _p(idx))
+    if st:
+        raise GviError(st, lib.gvi_last_error(None).decode())
+    return Z, w, idx
+
+
+class Context:
+    def __init__(self, device: int = 0, dtype: int = GVI_F64):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        st = self.lib.gvi_ctx_create(device, dtype, C.byref(h))
+        if st:
+            raise GviError(st, self.lib.gvi_last_error(None).decode())
+        self.h = h
+        self.T = self.n = 0
+        self.sets = []          # (K, d, p, N)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gvi_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        if st:
+            raise GviError(st, self.lib.gvi_last_error(self.h).decode())
+
+    # ---- setup ----
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.gvi_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def sync(self):
+        self._ck(self.lib.gvi_ctx_sync(self.h))
+
+    def chain_set(self, T, n):
+        self._ck(self.lib.gvi_chain_set(self.h, T, n))
+        self.T, self.n, self.sets = T, n, []
+
+    def factors_add(self, d, p, start, kind, params=None, temperature=None):
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        K = len(start)
+        params = None if params is None else _f64(params).reshape(K, -1)
+        temperature = None if temperature is None else _f64(temperature)
+        sid = C.c_int()
+        self._ck(self.lib.gvi_factors_add(self.h, K, d, p, _p(start), kind, _p(params),
+                                          0 if params is None else params.shape[1], _p(temperature), C.byref(sid)))
+        k_, d_, p_, N = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        self._ck(self.lib.gvi_factors_info(self.h, sid.value, C.byref(k_), C.byref(d_), C.byref(p_), C.byref(N)))
+        self.sets.append((K, d, p, N.value))
+        return sid.value
+
+    def factors_set_table(self, sid, Z, w):
+        Z, w = _f64(Z), _f64(w)
+        self._ck(self.lib.gvi_factors_set_table(self.h, sid, len(w), _p(Z), _p(w)))
+        K, d, p, _ = self.sets[sid]
+        self.sets[sid] = (K, d, p, len(w))
+
+    def factors_set_temperature(self, sid, temperature):
+        self._ck(self.lib.gvi_factors_set_temperature(self.h, sid, _p(_f64(temperature))))
+
+    # ---- per-pass factor operators (host buffers) ----
+    def moments(self, sid, mu, Sigma):
+        K, d, _, _ = self.sets[sid]
+        mu, Sigma = _f64(mu), _f64(Sigma)
+        Ephi, Vdmu, Vddmu = np.empty(K), np.empty((K, d)), np.empty((K, d, d))
+        self._ck(self.lib.gvi_moments(self.h, sid, _p(mu), _p(Sigma), _p(Ephi), _p(Vdmu), _p(Vddmu)))
+        return Ephi, Vdmu, Vddmu
+
+    def raw_moments(self, sid, mu, Sigma):
+        K, d, _, _ = self.sets[sid]
+        mu, Sigma = _f64(mu), _f64(Sigma)
+        E0, E1, E2 = np.empty(K), np.empty((K, d)), np.empty((K, d, d))
+        self._ck(self.lib.gvi_raw_moments(self.h, sid, _p(mu), _p(Sigma), _p(E0), _p(E1), _p(E2)))
+        return E0, E1, E2
+
+    def costs(self, sid, mu, Sigma):
+        K = self.sets[sid][0]
+        mu, Sigma = _f64(mu), _f64(Sigma)
+        cost = np.empty(K)
+        self._ck(self.lib.gvi_costs(self.h, sid, _p(mu), _p(Sigma), _p(cost)))
+        return cost
+
+    def expand(self, sid, mu, Sigma):
+        K, d, _, N = self.sets[sid]
+        mu, Sigma = _f64(mu), _f64(Sigma)
+        X = np.empty((K, d, N))
+        self._ck(self.lib.gvi_expand(self.h, sid, _p(mu), _p(Sigma), _p(X)))
+        return X
+
+    def moments_from_psi(self, sid, mu, Sigma, psi):
+        K, d, _, _ = self.sets[sid]
+        mu, Sigma, psi = _f64(mu), _f64(Sigma), _f64(psi)
+        Ephi, Vdmu, Vddmu = np.empty(K), np.empty((K, d)), np.empty((K, d, d))
+        self._ck(self.lib.gvi_moments_from_psi(self.h, sid, _p(mu), _p(Sigma), _p(psi), _p(Ephi), _p(Vdmu), _p(Vddmu)))
+        return Ephi, Vdmu, Vddmu
+
+    # ---- joint operators ----
+    def bt_assemble(self, sids, Vdmus, Vddmus):
+        T, n = self.T, self.n
+        ids = (C.c_int * len(sids))(*sids)
+        Vd = [_f64(v) for v in Vdmus]
+        Vdd = [_f64(v) for v in Vddmus]
+        pv = (C.c_void_p * len(sids))(*[v.ctypes.data for v in Vd])
+        pvv = (C.c_void_p * len(sids))(*[v.ctypes.data for v in Vdd])
+        g, D, U = np.empty((T, n)), np.empty((T, n, n)), np.empty((max(T - 1, 0), n, n))
+        self._ck(self.lib.gvi_bt_assemble(self.h, len(sids), ids, pv, pvv, _p(g), _p(D), _p(U)))
+        return g, D, U
+
+    def bt_solve(self, D, U, rhs):
+        D, U, rhs = _f64(D), _f64(U), _f64(rhs)
+        x = np.empty(self.T * self.n)
+        self._ck(self.lib.gvi_bt_solve(self.h, _p(D), _p(U), _p(rhs), _p(x)))
+        return x.reshape(self.T, self.n)
+
+    def bt_logdet(self, D, U):
+        D, U = _f64(D), _f64(U)
+        out = np.empty(1)
+        self._ck(self.lib.gvi_bt_logdet(self.h, _p(D), _p(U), _p(out)))
+        return float(out[0])
+
+    def bt_marginals(self, D, U):
+        D, U = _f64(D), _f64(U)
+        T, n = self.T, self.n
+        SD, SU = np.empty((T, n, n)), np.empty((max(T - 1, 0), n, n))
+        self._ck(self.lib.gvi_bt_marginals(self.h, _p(D), _p(U), _p(SD), _p(SU)))
+        return SD, SU
+
+    def gather_marginals(self, sid, mu, SigD, SigU):
+        K, d, _, _ = self.sets[sid]
+        mu, SigD, SigU = _f64(mu), _f64(SigD), _f64(SigU)
+        mk, Sk = np.empty((K, d)), np.empty((K, d, d))
+        self._ck(self.lib.gvi_gather_marginals(self.h, sid, _p(mu), _p(SigD), _p(SigU), _p(mk), _p(Sk)))
+        return mk, Sk
+
+    # ---- resident NGD iteration ----
+    def ngd_init(self, mu, D, U):
+        mu, D, U = _f64(mu), _f64(D), _f64(U)
+        self._ck(self.lib.gvi_ngd_init(self.h, _p(mu), _p(D), _p(U)))
+
+    def ngd_cost(self):
+        v = C.c_double()
+        self._ck(self.lib.gvi_ngd_cost(self.h, C.byref(v)))
+        return v.value
+
+    def ngd_factor_costs(self, sid):
+        out = np.empty(self.sets[sid][0])
+        self._ck(self.lib.gvi_ngd_factor_costs(self.h, sid, _p(out)))
+        return out
+
+    def ngd_gradients(self):
+        self._ck(self.lib.gvi_ngd_gradients(self.h))
+
+    def ngd_gradients_local(self):
+        self._ck(self.lib.gvi_ngd_gradients_local(self.h))
+
+    def ngd_gradients_finish(self):
+        self._ck(self.lib.gvi_ngd_gradients_finish(self.h))
+
+    def ngd_trial(self, step):
+        v = C.c_double()
+        self._ck(self.lib.gvi_ngd_trial(self.h, step, C.byref(v)))
+        return v.value
+
+    def ngd_trial_local(self, step):
+        self._ck(self.lib.gvi_ngd_trial_local(self.h, step))
+
+    def ngd_trial_finish(self):
+        v = C.c_double()
+        self._ck(self.lib.gvi_ngd_trial_finish(self.h, C.byref(v)))
+        return v.value
+
+    def ngd_accept(self):
+        self._ck(self.lib.gvi_ngd_accept(self.h))
+
+    def ngd_step(self, step_size_base=0.55, max_backtrack=10):
+        c0, c1 = C.c_double(), C.c_double()
+        ok, ntr = C.c_int(), C.c_int()
+        self._ck(self.lib.gvi_ngd_step(self.h, step_size_base, max_backtrack, C.byref(c0), C.byref(ok),
+                                       C.byref(c1), C.byref(ntr)))
+        return dict(cost_iter=c0.value, accepted=bool(ok.value), new_cost=c1.value, ntrials=ntr.value)
+
+    def ngd_exchange(self, which):
+        ptr, cnt = C.c_void_p(), C.c_int64()
+        self._ck(self.lib.gvi_ngd_exchange(self.h, which, C.byref(ptr), C.byref(cnt)))
+        return ptr.value, cnt.value
+
+    def ngd_get_state(self):
+        T, n = self.T, self.n
+        mu, D, U = np.empty((T, n)), np.empty((T, n, n)), np.empty((max(T - 1, 0), n, n))
+        SD, SU = np.empty((T, n, n)), np.empty((max(T - 1, 0), n, n))
+        self._ck(self.lib.gvi_ngd_get_state(self.h, _p(mu), _p(D), _p(U), _p(SD), _p(SU)))
+        return dict(mu=mu, D=D, U=U, SigD=SD, SigU=SU)
+
+    def ngd_get_gradients(self):
+        T, n = self.T, self.n
+        m1 = max(T - 1, 0)
+        out = dict(dmu=np.empty((T, n)), dD=np.empty((T, n, n)), dU=np.empty((m1, n, n)),
+                   g=np.empty((T, n)), VD=np.empty((T, n, n)), VU=np.empty((m1, n, n)))
+        self._ck(self.lib.gvi_ngd_get_gradients(self.h, *[_p(out[k]) for k in ("dmu", "dD", "dU", "g", "VD", "VU")]))
+        return out
+
+    # ---- measurement ----
+    def profile_enable(self, on=True):
+        self._ck(self.lib.gvi_profile_enable(self.h, int(on)))
+
+    def profile_last(self, sid, what=0):
+        ms = C.c_float()
+        self._ck(self.lib.gvi_profile_last(self.h, sid, what, C.byref(ms)))
+        return ms.value
+
+    def profile_geometry(self, sid):
+        v, nch, ch = C.c_int(), C.c_int(), C.c_int64()
+        self._ck(self.lib.gvi_profile_geometry(self.h, sid, C.byref(v), C.byref(nch), C.byref(ch)))
+        return dict(variant=v.value, nchunk=nch.value, chunk=ch.value)
+
+    def set_variant(self, v):
+        self._ck(self.lib.gvi_set_variant(self.h, v))
+
+
+def context_for_chain(chain, device=0, specs=None):
+    """Context with the chain of gaussianvi_amd.synthetic.make_chain loaded; returns (ctx, set ids)."""
+    ctx = Context(device)
+    ctx.chain_set(chain["T"], chain["n"])
+    ids = []
+    for spec in (chain["specs"] if specs is None else specs):
+        ids.append(ctx.factors_add(spec["d"], spec["p"], spec["start"], spec["kind"], spec["params"],
+                                   spec["temperature"]))
+    return ctx, ids

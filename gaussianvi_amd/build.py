@@ -1,0 +1,60 @@
+"""Build the in-tree native libraries.
+
+  gaussianvi_amd/libgvi_hip.so   HIP kernels + C-ABI (include/gvi_hip.h), hipcc --offload-arch=gfx950
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  Rebuilds only when a source is newer than the library.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgvi_hip.so")
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build gaussianvi_amd/libgvi_hip.so")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def lib_sources():
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    srcs.append(os.path.join(ROOT, "include", "gvi_hip.h"))
+    return srcs
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale(LIB, lib_sources()):
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function",
+           "-I", os.path.join(ROOT, "include"),
+           os.path.join(CSRC, "gvi_hip.hip"), "-x", "hip", os.path.join(CSRC, "spgh.cpp"),
+           "-o", LIB]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose:
+        sys.stderr.write(r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stderr[-8000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,1053 @@
+// C-ABI implementation (include/gvi_hip.h): context, factor sets, kernel dispatch, resident NGD state.
+#include "../../include/gvi_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "host_linalg.hpp"
+#include "kernels_bt.hpp"
+#include "kernels_factor.hpp"
+#include "spgh.hpp"
+
+using namespace gvi;
+
+namespace {
+
+struct DevMem {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem&) = delete;
+  DevMem& operator=(const DevMem&) = delete;
+  ~DevMem() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  hipError_t ensure(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    release();
+    hipError_t e = hipMalloc(&p, n ? n : 8);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  double* d() const { return (double*)p; }
+  int32_t* i() const { return (int32_t*)p; }
+};
+
+struct Table {
+  int d = 0, p = 0;
+  int64_t N = 0, Np = 0;
+  DevMem Zt, w;
+};
+
+struct FactorSet {
+  int K = 0, d = 0, p = 0, m = 0, kind = 0, raw_stride = 0;
+  std::vector<int32_t> start;
+  std::shared_ptr<Table> table;
+  DevMem dstart, dptr, didx, A, b, sgn, raw, temperature;
+  DevMem S, Sinv, Lam, H, u0;         // per-pass products
+  DevMem partial;
+  int nchunk = 1;
+  int64_t chunk = 0;
+  bool use_reg = false;
+  // operator outputs / NGD per-set state
+  DevMem mu_k[2], Sigma_k[2], Ephi, cost, Vdmu, Vddmu, raw1, raw2, X, psi_ext;
+  hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [moments|cost][start|stop]
+  bool ev_set[2] = {false, false};
+  ~FactorSet() { for (auto& a : ev) for (auto& e : a) if (e) (void)hipEventDestroy(e); }
+  FactorDev dev() const {
+    FactorDev f;
+    f.K = K; f.d = d; f.m = m; f.kind = kind;
+    f.N = table->N; f.Np = table->Np;
+    f.Zt = table->Zt.d(); f.w = table->w.d();
+    f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
+    f.temperature = temperature.d();
+    f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.u0 = u0.d();
+    return f;
+  }
+};
+
+struct NgdState {
+  bool ready = false;
+  int cur = 0;
+  DevMem mu[2], Lam[2], Sig[2], hld[2];   // Lam = [D | U], Sig = [SigD | SigU]
+  DevMem exch0, exch1;                    // [g | VD | VU], [cost partial sum]
+  DevMem dmu, dLam, total;
+  bool cost_valid[2] = {false, false};
+  double cost[2] = {0, 0};
+  bool have_trial = false;
+};
+
+}  // namespace
+
+struct gvi_ctx {
+  int device = 0, dtype = GVI_F64;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  int T = 0, n = 0;
+  std::vector<std::unique_ptr<FactorSet>> sets;
+  std::vector<std::shared_ptr<Table>> tables;
+  NgdState ngd;
+  DevMem Wbuf, Ibuf, vbuf, scratch, hldtmp;
+  std::string err;
+  int variant = 0;
+  bool profile = false;
+  int target_waves = 2048;
+};
+
+namespace {
+
+thread_local std::string g_noctx_err;
+
+gvi_status fail(gvi_ctx* c, gvi_status s, const std::string& msg) {
+  if (c) c->err = msg; else g_noctx_err = msg;
+  return s;
+}
+
+#define HIPCK(ctx, expr)                                                                       \
+  do {                                                                                         \
+    hipError_t e__ = (expr);                                                                   \
+    if (e__ != hipSuccess)                                                                     \
+      return fail(ctx, GVI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));       \
+  } while (0)
+#define GVICK(expr)                          \
+  do {                                       \
+    gvi_status s__ = (expr);                 \
+    if (s__ != GVI_OK) return s__;           \
+  } while (0)
+
+size_t bt_count(const gvi_ctx* c) { return (size_t)(2 * c->T - 1) * c->n * c->n; }   // [D | U]
+size_t nn_(const gvi_ctx* c) { return (size_t)c->n * c->n; }
+
+gvi_status h2d(gvi_ctx* c, void* dst, const void* src, size_t bytes) {
+  HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return GVI_OK;
+}
+gvi_status d2h(gvi_ctx* c, void* dst, const void* src, size_t bytes) {
+  HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return GVI_OK;
+}
+gvi_status sync(gvi_ctx* c) {
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  return GVI_OK;
+}
+
+gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const double* Z, const double* w) {
+  t.d = d; t.p = p; t.N = N; t.Np = (N + 63) / 64 * 64;
+  std::vector<double> zt((size_t)d * t.Np, 0.0), wp(t.Np, 0.0);
+  for (int64_t i = 0; i < N; ++i) {
+    wp[i] = w[i];
+    for (int a = 0; a < d; ++a) zt[(size_t)a * t.Np + i] = Z[(size_t)i * d + a];
+  }
+  HIPCK(c, t.Zt.ensure(zt.size() * 8));
+  HIPCK(c, t.w.ensure(wp.size() * 8));
+  HIPCK(c, hipMemcpy(t.Zt.p, zt.data(), zt.size() * 8, hipMemcpyHostToDevice));
+  HIPCK(c, hipMemcpy(t.w.p, wp.data(), wp.size() * 8, hipMemcpyHostToDevice));
+  return GVI_OK;
+}
+
+FactorSet* get_set(gvi_ctx* c, int id) {
+  if (!c || id < 0 || id >= (int)c->sets.size()) return nullptr;
+  return c->sets[id].get();
+}
+
+// which (d, m) pairs have a register-kernel instantiation
+bool reg_supported(int kind, int d, int m) {
+  if (kind == KIND_RANGE_1D) return d == 1;
+  if (kind == KIND_QUAD_PRIOR) return (d == 2 && m == 1) || (d == 4 && m == 2) || (d == 6 && m == 3) ||
+                                      (d == 8 && m == 4) || (d == 12 && m == 6);
+  if (kind == KIND_FIXED_PRIOR) return d == m && (d == 1 || d == 2 || d == 3 || d == 4 || d == 6 || d == 8);
+  return false;
+}
+
+void plan_chunks(gvi_ctx* c, FactorSet& s, bool reg) {
+  const int64_t Np = s.table->Np;
+  if (reg) {
+    const int64_t iters = Np / 64;
+    int64_t nch = std::max<int64_t>(1, (c->target_waves + s.K - 1) / s.K);
+    nch = std::min<int64_t>(nch, std::max<int64_t>(1, iters / 4));
+    const int64_t per = (iters + nch - 1) / nch;
+    s.chunk = per * 64;
+    s.nchunk = (int)((Np + s.chunk - 1) / s.chunk);
+  } else {
+    const int64_t blocks = (Np + 255) / 256;
+    int64_t nch = std::max<int64_t>(1, (1024 + s.K - 1) / s.K);
+    nch = std::min<int64_t>(nch, blocks);
+    const int64_t per = (blocks + nch - 1) / nch;
+    s.chunk = per * 256;
+    s.nchunk = (int)((Np + s.chunk - 1) / s.chunk);
+  }
+}
+
+template <int D, typename Psi>
+void launch_reg(const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (a.full) hipLaunchKernelGGL((moments_reg_kernel<D, Psi, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((moments_reg_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
+}
+
+bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
+  const int d = s.d;
+  if (s.kind == KIND_RANGE_1D && d == 1) { launch_reg<1, PsiRange1D>(a, grid, st); return true; }
+  if (s.kind == KIND_QUAD_PRIOR) {
+    switch (d) {
+      case 2: launch_reg<2, PsiQuad<2, 1>>(a, grid, st); return true;
+      case 4: launch_reg<4, PsiQuad<4, 2>>(a, grid, st); return true;
+      case 6: launch_reg<6, PsiQuad<6, 3>>(a, grid, st); return true;
+      case 8: launch_reg<8, PsiQuad<8, 4>>(a, grid, st); return true;
+      case 12: launch_reg<12, PsiQuad<12, 6>>(a, grid, st); return true;
+    }
+  }
+  if (s.kind == KIND_FIXED_PRIOR) {
+    switch (d) {
+      case 1: launch_reg<1, PsiQuad<1, 1>>(a, grid, st); return true;
+      case 2: launch_reg<2, PsiQuad<2, 2>>(a, grid, st); return true;
+      case 3: launch_reg<3, PsiQuad<3, 3>>(a, grid, st); return true;
+      case 4: launch_reg<4, PsiQuad<4, 4>>(a, grid, st); return true;
+      case 6: launch_reg<6, PsiQuad<6, 6>>(a, grid, st); return true;
+      case 8: launch_reg<8, PsiQuad<8, 8>>(a, grid, st); return true;
+    }
+  }
+  return false;
+}
+
+// prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
+gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma) {
+  const int d = s.d, dp = d + (d & 1);
+  const size_t lds = (size_t)(4 * d * d + 2 * dp + 3 * d) * 8 + (size_t)dp * 4 + 16;
+  hipLaunchKernelGGL(prep_kernel, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+// moments (full=1) or cost (full=0) pass for one set; prep must have run for (mu, Sigma).
+gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full) {
+  bool reg = reg_supported(s.kind, s.d, s.m) && !psi_ext && c->variant != 1;
+  if (c->variant == 2 && !reg && !psi_ext)
+    return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
+  plan_chunks(c, s, reg);
+  s.use_reg = reg;
+  const size_t need = (size_t)s.K * s.nchunk * npairs(s.d) * 8;
+  HIPCK(c, s.partial.ensure(need));
+  MomArgs a;
+  a.f = s.dev(); a.mu = mu; a.psi_ext = psi_ext; a.partial = s.partial.d();
+  a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full;
+  const int which = full ? 0 : 1;
+  if (c->profile) {
+    for (int e = 0; e < 2; ++e)
+      if (!s.ev[which][e]) HIPCK(c, hipEventCreate(&s.ev[which][e]));
+    HIPCK(c, hipEventRecord(s.ev[which][0], c->stream));
+  }
+  if (reg) {
+    dim3 grid((s.K + 3) / 4, s.nchunk);
+    if (!dispatch_reg(s, a, grid, c->stream)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
+  } else {
+    if (s.d > 32) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel supports d <= 32");
+    const int d = s.d, m = s.m;
+    const size_t lds = (size_t)(2 * GEN_BS * (d + 1) + GEN_BS + d * d + d + m * d + 2 * m) * 8;
+    if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCK(c, hipFuncSetAttribute((const void*)moments_generic_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(moments_generic_kernel, dim3(s.K, s.nchunk), dim3(GEN_BS), lds, c->stream, a);
+  }
+  HIPCK(c, hipGetLastError());
+  if (c->profile) {
+    HIPCK(c, hipEventRecord(s.ev[which][1], c->stream));
+    s.ev_set[which] = true;
+  }
+  return GVI_OK;
+}
+
+gvi_status run_epilogue(gvi_ctx* c, FactorSet& s, int full, double* Ephi, double* cost, double* Vdmu,
+                        double* Vddmu, double* Ex, double* Exx) {
+  EpiArgs e;
+  e.f = s.dev(); e.partial = s.partial.d(); e.nchunk = s.nchunk; e.full = full;
+  e.Ephi = Ephi; e.cost = cost; e.Vdmu = Vdmu; e.Vddmu = Vddmu; e.E_xmuphi = Ex; e.E_xxphi = Exx;
+  const size_t lds = (size_t)(npairs(s.d) + 2 * s.d * s.d) * 8;
+  hipLaunchKernelGGL(epilogue_kernel, dim3(s.K), dim3(64), lds, c->stream, e);
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+gvi_status ensure_set_buffers(gvi_ctx* c, FactorSet& s) {
+  const size_t K = s.K, d = s.d;
+  for (int i = 0; i < 2; ++i) {
+    HIPCK(c, s.mu_k[i].ensure(K * d * 8));
+    HIPCK(c, s.Sigma_k[i].ensure(K * d * d * 8));
+  }
+  HIPCK(c, s.Ephi.ensure(K * 8));
+  HIPCK(c, s.cost.ensure(K * 8));
+  HIPCK(c, s.Vdmu.ensure(K * d * 8));
+  HIPCK(c, s.Vddmu.ensure(K * d * d * 8));
+  return GVI_OK;
+}
+
+gvi_status ensure_chain_ws(gvi_ctx* c) {
+  const size_t T = c->T, nn = nn_(c);
+  HIPCK(c, c->Wbuf.ensure(T * nn * 8));
+  HIPCK(c, c->Ibuf.ensure(T * nn * 8));
+  HIPCK(c, c->vbuf.ensure(T * c->n * 8));
+  HIPCK(c, c->hldtmp.ensure(8));
+  return GVI_OK;
+}
+
+// log-det (+ optionally marginals) of the chain (D, U) device arrays
+gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* SigD, double* SigU, double* hld) {
+  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
+  GVICK(ensure_chain_ws(c));
+  FactorArgs a;
+  a.T = c->T; a.n = c->n; a.D = D; a.U = U; a.Wbuf = c->Wbuf.d(); a.Ibuf = c->Ibuf.d();
+  a.SigD = SigD; a.SigU = SigU; a.half_logdet = hld;
+  const size_t n = c->n, lds = (n * 3 * n + 4 * n * n) * 8;
+  hipLaunchKernelGGL(bt_factor_kernel, dim3(1), dim3(64), lds, c->stream, a);
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+gvi_status run_bt_solve(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, double* x) {
+  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
+  GVICK(ensure_chain_ws(c));
+  SolveArgs a;
+  a.T = c->T; a.n = c->n; a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale;
+  a.Wbuf = c->Wbuf.d(); a.vbuf = c->vbuf.d(); a.x = x;
+  const size_t n = c->n, lds = (n * (2 * n + 1) + 2 * n * n + 2 * n) * 8;
+  hipLaunchKernelGGL(bt_solve_kernel, dim3(1), dim3(64), lds, c->stream, a);
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+gvi_status run_scatter(gvi_ctx* c, FactorSet& s, const double* Vdmu, const double* Vddmu, double* g, double* D, double* U) {
+  ScatterArgs a;
+  a.T = c->T; a.n = c->n; a.d = s.d; a.K = s.K;
+  a.start = s.dstart.i(); a.ptr = s.dptr.i(); a.idx = s.didx.i();
+  a.Vdmu = Vdmu; a.Vddmu = Vddmu; a.g = g; a.D = D; a.U = U;
+  const int64_t total = (int64_t)c->T * (c->n + 2 * c->n * c->n);
+  hipLaunchKernelGGL(bt_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, a);
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+gvi_status run_gather(gvi_ctx* c, FactorSet& s, const double* mu, const double* SigD, const double* SigU,
+                      double* mu_k, double* Sigma_k) {
+  const int64_t total = (int64_t)s.K * (s.d + s.d * s.d);
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, s.K, s.d, c->n,
+                     s.dstart.i(), mu, SigD, SigU, mu_k, Sigma_k);
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+gvi_status check_pass_args(gvi_ctx* c, FactorSet* s, const void* mu, const void* Sigma) {
+  if (!c) return GVI_ERR_ARG;
+  if (!s) return fail(c, GVI_ERR_ARG, "bad set id");
+  if (!mu || !Sigma) return fail(c, GVI_ERR_ARG, "mu / Sigma is NULL");
+  return GVI_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* gvi_version(void) { return "gvi_hip 0.1 (gfx950, fp64)"; }
+
+const char* gvi_last_error(const gvi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_noctx_err.c_str(); }
+
+gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
+  if (!out) return fail(nullptr, GVI_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (dtype == GVI_F32) return fail(nullptr, GVI_ERR_UNSUPPORTED, "GVI_F32 (config 5) is not implemented yet");
+  if (dtype != GVI_F64) return fail(nullptr, GVI_ERR_ARG, "unknown dtype");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, GVI_ERR_HIP, "no HIP device: this library has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, GVI_ERR_ARG, "device index out of range");
+  if (hipSetDevice(device) != hipSuccess) return fail(nullptr, GVI_ERR_HIP, "hipSetDevice failed");
+  std::unique_ptr<gvi_ctx> c(new gvi_ctx);
+  c->device = device; c->dtype = dtype;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+    return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
+  if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
+  *out = c.release();
+  return GVI_OK;
+}
+
+gvi_status gvi_ctx_destroy(gvi_ctx* ctx) {
+  if (!ctx) return GVI_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->sets.clear();
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return GVI_OK;
+}
+
+gvi_status gvi_ctx_set_stream(gvi_ctx* ctx, void* hip_stream) {
+  if (!ctx) return GVI_ERR_ARG;
+  HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+  if (hip_stream) {
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+  } else if (!ctx->own_stream) {
+    HIPCK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+  }
+  return GVI_OK;
+}
+
+gvi_status gvi_ctx_sync(gvi_ctx* ctx) { return ctx ? sync(ctx) : GVI_ERR_ARG; }
+
+gvi_status gvi_spgh_count(int d, int p, int64_t* N) {
+  if (!N) return fail(nullptr, GVI_ERR_ARG, "N is NULL");
+  const int64_t n = spgh_count(d, p);
+  if (n < 0) return fail(nullptr, GVI_ERR_NOTABLE, "(d, p) outside the tabulated rules (1 <= p <= 25, d <= 64)");
+  *N = n;
+  return GVI_OK;
+}
+
+gvi_status gvi_spgh_nodes(int d, int p, int64_t N, double* Z, double* w, int8_t* idx) {
+  SparseGrid g;
+  if (spgh_generate(d, p, g)) return fail(nullptr, GVI_ERR_NOTABLE, "(d, p) outside the tabulated rules");
+  if (N != g.N) return fail(nullptr, GVI_ERR_ARG, "N does not match gvi_spgh_count(d, p)");
+  if (Z) memcpy(Z, g.Z.data(), g.Z.size() * 8);
+  if (w) memcpy(w, g.w.data(), g.w.size() * 8);
+  if (idx) memcpy(idx, g.idx.data(), g.idx.size());
+  return GVI_OK;
+}
+
+gvi_status gvi_chain_set(gvi_ctx* ctx, int T, int n) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (T < 1 || n < 1) return fail(ctx, GVI_ERR_ARG, "T and n must be >= 1");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  ctx->T = T; ctx->n = n;
+  ctx->sets.clear();
+  ctx->ngd.ready = false;
+  ctx->ngd.have_trial = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
+                           const double* psi_params, int64_t params_per_factor, const double* temperature,
+                           int* set_id) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (ctx->T < 1) return fail(ctx, GVI_ERR_STATE, "call gvi_chain_set first");
+  if (K < 1 || !start) return fail(ctx, GVI_ERR_ARG, "K < 1 or start is NULL");
+  const int n = ctx->n;
+  if (d != n && d != 2 * n) return fail(ctx, GVI_ERR_ARG, "factor dimension must be n or 2n");
+  for (int k = 0; k < K; ++k)
+    if (start[k] < 0 || (int64_t)start[k] * n + d > (int64_t)ctx->T * n)
+      return fail(ctx, GVI_ERR_ARG, "start index out of range");
+  int m = 0;
+  int64_t need = 0;
+  switch (psi_kind) {
+    case GVI_PSI_RANGE_1D: if (d != 1) return fail(ctx, GVI_ERR_ARG, "RANGE_1D needs d == 1"); need = 5; break;
+    case GVI_PSI_QUAD_PRIOR: if (d % 2) return fail(ctx, GVI_ERR_ARG, "QUAD_PRIOR needs even d"); m = d / 2; need = 2 * (int64_t)m * m; break;
+    case GVI_PSI_FIXED_PRIOR: m = d; need = d + (int64_t)d * d; break;
+    case GVI_PSI_HOST_CALLBACK: need = 0; break;
+    default: return fail(ctx, GVI_ERR_ARG, "unknown psi kind");
+  }
+  if (need > 0 && (!psi_params || params_per_factor < need))
+    return fail(ctx, GVI_ERR_ARG, "psi_params missing or params_per_factor too small for this kind");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+
+  std::unique_ptr<FactorSet> s(new FactorSet);
+  s->K = K; s->d = d; s->p = p; s->m = m; s->kind = psi_kind;
+  s->start.assign(start, start + K);
+  // quadrature table: shared between sets with the same (d, p)
+  for (auto& t : ctx->tables) if (t->d == d && t->p == p) s->table = t;
+  if (!s->table) {
+    SparseGrid g;
+    if (spgh_generate(d, p, g)) return fail(ctx, GVI_ERR_NOTABLE, "(d, p) outside the tabulated rules");
+    auto t = std::make_shared<Table>();
+    GVICK(upload_table(ctx, *t, d, p, g.N, g.Z.data(), g.w.data()));
+    ctx->tables.push_back(t);
+    s->table = t;
+  }
+  // psi operands
+  std::vector<double> A((size_t)K * m * d, 0.0), b((size_t)K * m, 0.0), sg((size_t)K * m, 1.0);
+  if (psi_kind == GVI_PSI_QUAD_PRIOR || psi_kind == GVI_PSI_FIXED_PRIOR) {
+    std::vector<double> Q, lam, W;
+    for (int k = 0; k < K; ++k) {
+      const double* P = psi_params + (size_t)k * params_per_factor;
+      const double* Qin = psi_kind == GVI_PSI_QUAD_PRIOR ? P + (size_t)m * m : P + d;
+      Q.assign((size_t)m * m, 0.0);
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) Q[(size_t)i * m + j] = 0.5 * (Qin[i * m + j] + Qin[j * m + i]);
+      jacobi_eigh(m, Q, lam, W);
+      // psi = c * r^T Qinv r = sum_r sign(e_r) (sqrt(c |e_r|) w_r^T r)^2 ,  c = 1/2 (QUAD) or 1 (FIXED)
+      const double cfac = psi_kind == GVI_PSI_QUAD_PRIOR ? 0.5 : 1.0;
+      for (int r = 0; r < m; ++r) {
+        const double sc = std::sqrt(cfac * std::fabs(lam[r]));
+        sg[(size_t)k * m + r] = lam[r] < 0 ? -1.0 : 1.0;
+        double* Arow = &A[((size_t)k * m + r) * d];
+        if (psi_kind == GVI_PSI_QUAD_PRIOR) {      // r = Phi x1 - x2 = [Phi, -I] x
+          for (int a = 0; a < m; ++a) {
+            double acc = 0.0;
+            for (int j = 0; j < m; ++j) acc += W[(size_t)j * m + r] * P[j * m + a];
+            Arow[a] = sc * acc;
+            Arow[m + a] = -sc * W[(size_t)a * m + r];
+          }
+        } else {                                   // r = x - mu0
+          double off = 0.0;
+          for (int a = 0; a < d; ++a) { Arow[a] = sc * W[(size_t)a * m + r]; off += Arow[a] * P[a]; }
+          b[(size_t)k * m + r] = -off;
+        }
+      }
+    }
+  }
+  auto up = [&](DevMem& dm, const void* src, size_t bytes) -> gvi_status {
+    HIPCK(ctx, dm.ensure(bytes ? bytes : 8));
+    if (bytes) HIPCK(ctx, hipMemcpy(dm.p, src, bytes, hipMemcpyHostToDevice));
+    return GVI_OK;
+  };
+  GVICK(up(s->A, A.data(), A.size() * 8));
+  GVICK(up(s->b, b.data(), b.size() * 8));
+  GVICK(up(s->sgn, sg.data(), sg.size() * 8));
+  if (psi_kind == GVI_PSI_RANGE_1D) {
+    std::vector<double> raw((size_t)K * 5);
+    for (int k = 0; k < K; ++k) memcpy(&raw[(size_t)k * 5], psi_params + (size_t)k * params_per_factor, 40);
+    s->raw_stride = 5;
+    GVICK(up(s->raw, raw.data(), raw.size() * 8));
+  } else {
+    GVICK(up(s->raw, nullptr, 0));
+  }
+  std::vector<double> temp(K, 1.0);
+  if (temperature) temp.assign(temperature, temperature + K);
+  GVICK(up(s->temperature, temp.data(), temp.size() * 8));
+  // CSR over states for the ordered assemble
+  std::vector<int32_t> ptr(ctx->T + 1, 0), idx(K);
+  for (int k = 0; k < K; ++k) ptr[start[k] + 1]++;
+  for (int t = 0; t < ctx->T; ++t) ptr[t + 1] += ptr[t];
+  {
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int k = 0; k < K; ++k) idx[fill[start[k]]++] = k;
+  }
+  GVICK(up(s->dstart, s->start.data(), (size_t)K * 4));
+  GVICK(up(s->dptr, ptr.data(), ptr.size() * 4));
+  GVICK(up(s->didx, idx.data(), idx.size() * 4));
+  HIPCK(ctx, s->S.ensure((size_t)K * d * d * 8));
+  HIPCK(ctx, s->Sinv.ensure((size_t)K * d * d * 8));
+  HIPCK(ctx, s->Lam.ensure((size_t)K * d * d * 8));
+  HIPCK(ctx, s->H.ensure((size_t)K * std::max(m, 1) * d * 8));
+  HIPCK(ctx, s->u0.ensure((size_t)K * std::max(m, 1) * 8));
+  GVICK(ensure_set_buffers(ctx, *s));
+  ctx->sets.push_back(std::move(s));
+  ctx->ngd.ready = false;
+  if (set_id) *set_id = (int)ctx->sets.size() - 1;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const double* Z, const double* w) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
+  if (N < 1 || !Z || !w) return fail(ctx, GVI_ERR_ARG, "bad table");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  auto t = std::make_shared<Table>();
+  GVICK(upload_table(ctx, *t, s->d, -1, N, Z, w));
+  s->table = t;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_set_temperature(gvi_ctx* ctx, int set_id, const double* temperature) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s || !temperature) return fail(ctx, GVI_ERR_ARG, "bad set id / NULL temperature");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  HIPCK(ctx, hipMemcpy(s->temperature.p, temperature, (size_t)s->K * 8, hipMemcpyHostToDevice));
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_info(const gvi_ctx* ctx, int set_id, int* K, int* d, int* p, int64_t* N) {
+  FactorSet* s = get_set(const_cast<gvi_ctx*>(ctx), set_id);
+  if (!s) return GVI_ERR_ARG;
+  if (K) *K = s->K;
+  if (d) *d = s->d;
+  if (p) *p = s->p;
+  if (N) *N = s->table->N;
+  return GVI_OK;
+}
+
+// ---- per-pass factor operators ----
+gvi_status gvi_moments_dev(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* Ephi,
+                           double* Vdmu, double* Vddmu) {
+  FactorSet* s = get_set(ctx, set_id);
+  GVICK(check_pass_args(ctx, s, mu, Sigma));
+  if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_ARG, "HOST_CALLBACK set: use gvi_expand + gvi_moments_from_psi");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(run_prep(ctx, *s, mu, Sigma));
+  GVICK(run_moments(ctx, *s, mu, nullptr, 1));
+  return run_epilogue(ctx, *s, 1, Ephi, nullptr, Vdmu, Vddmu, nullptr, nullptr);
+}
+
+gvi_status gvi_costs_dev(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* cost) {
+  FactorSet* s = get_set(ctx, set_id);
+  GVICK(check_pass_args(ctx, s, mu, Sigma));
+  if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_ARG, "HOST_CALLBACK set has no device psi");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(run_prep(ctx, *s, mu, Sigma));
+  GVICK(run_moments(ctx, *s, mu, nullptr, 0));
+  return run_epilogue(ctx, *s, 0, nullptr, cost, nullptr, nullptr, nullptr, nullptr);
+}
+
+static gvi_status upload_pass_inputs(gvi_ctx* ctx, FactorSet* s, const double* mu, const double* Sigma) {
+  GVICK(h2d(ctx, s->mu_k[0].p, mu, (size_t)s->K * s->d * 8));
+  return h2d(ctx, s->Sigma_k[0].p, Sigma, (size_t)s->K * s->d * s->d * 8);
+}
+
+gvi_status gvi_moments(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* Ephi,
+                       double* Vdmu, double* Vddmu) {
+  FactorSet* s = get_set(ctx, set_id);
+  GVICK(check_pass_args(ctx, s, mu, Sigma));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
+  GVICK(gvi_moments_dev(ctx, set_id, s->mu_k[0].d(), s->Sigma_k[0].d(), s->Ephi.d(), s->Vdmu.d(), s->Vddmu.d()));
+  if (Ephi) GVICK(d2h(ctx, Ephi, s->Ephi.p, (size_t)s->K * 8));
+  if (Vdmu) GVICK(d2h(ctx, Vdmu, s->Vdmu.p, (size_t)s->K * s->d * 8));
+  if (Vddmu) GVICK(d2h(ctx, Vddmu, s->Vddmu.p, (size_t)s->K * s->d * s->d * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_raw_moments(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* E_phi,
+                           double* E_xmuphi, double* E_xxphi) {
+  FactorSet* s = get_set(ctx, set_id);
+  GVICK(check_pass_args(ctx, s, mu, Sigma));
+  if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_ARG, "HOST_CALLBACK set has no device psi");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
+  HIPCK(ctx, s->raw1.ensure((size_t)s->K * s->d * 8));
+  HIPCK(ctx, s->raw2.ensure((size_t)s->K * s->d * s->d * 8));
+  GVICK(run_prep(ctx, *s, s->mu_k[0].d(), s->Sigma_k[0].d()));
+  GVICK(run_moments(ctx, *s, s->mu_k[0].d(), nullptr, 1));
+  GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), nullptr, nullptr, nullptr, s->raw1.d(), s->raw2.d()));
+  if (E_phi) GVICK(d2h(ctx, E_phi, s->Ephi.p, (size_t)s->K * 8));
+  if (E_xmuphi) GVICK(d2h(ctx, E_xmuphi, s->raw1.p, (size_t)s->K * s->d * 8));
+  if (E_xxphi) GVICK(d2h(ctx, E_xxphi, s->raw2.p, (size_t)s->K * s->d * s->d * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_costs(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* cost) {
+  FactorSet* s = get_set(ctx, set_id);
+  GVICK(check_pass_args(ctx, s, mu, Sigma));
+  if (!cost) return fail(ctx, GVI_ERR_ARG, "cost is NULL");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
+  GVICK(gvi_costs_dev(ctx, set_id, s->mu_k[0].d(), s->Sigma_k[0].d(), s->cost.d()));
+  GVICK(d2h(ctx, cost, s->cost.p, (size_t)s->K * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_expand(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* X) {
+  FactorSet* s = get_set(ctx, set_id);
+  GVICK(check_pass_args(ctx, s, mu, Sigma));
+  if (!X) return fail(ctx, GVI_ERR_ARG, "X is NULL");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
+  const size_t bytes = (size_t)s->K * s->d * s->table->N * 8;
+  HIPCK(ctx, s->X.ensure(bytes));
+  GVICK(run_prep(ctx, *s, s->mu_k[0].d(), s->Sigma_k[0].d()));
+  hipLaunchKernelGGL(expand_kernel, dim3((unsigned)((s->table->N + 255) / 256), s->K), dim3(256), 0, ctx->stream,
+                     s->dev(), s->mu_k[0].d(), s->X.d());
+  HIPCK(ctx, hipGetLastError());
+  GVICK(d2h(ctx, X, s->X.p, bytes));
+  return sync(ctx);
+}
+
+gvi_status gvi_moments_from_psi(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, const double* psi,
+                                double* Ephi, double* Vdmu, double* Vddmu) {
+  FactorSet* s = get_set(ctx, set_id);
+  GVICK(check_pass_args(ctx, s, mu, Sigma));
+  if (!psi) return fail(ctx, GVI_ERR_ARG, "psi is NULL");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
+  const size_t bytes = (size_t)s->K * s->table->N * 8;
+  HIPCK(ctx, s->psi_ext.ensure(bytes));
+  GVICK(h2d(ctx, s->psi_ext.p, psi, bytes));
+  GVICK(run_prep(ctx, *s, s->mu_k[0].d(), s->Sigma_k[0].d()));
+  GVICK(run_moments(ctx, *s, s->mu_k[0].d(), s->psi_ext.d(), 1));
+  GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), nullptr, s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr));
+  if (Ephi) GVICK(d2h(ctx, Ephi, s->Ephi.p, (size_t)s->K * 8));
+  if (Vdmu) GVICK(d2h(ctx, Vdmu, s->Vdmu.p, (size_t)s->K * s->d * 8));
+  if (Vddmu) GVICK(d2h(ctx, Vddmu, s->Vddmu.p, (size_t)s->K * s->d * s->d * 8));
+  return sync(ctx);
+}
+
+// ---- joint operators (host-pointer forms stage through the scratch buffer) ----
+gvi_status gvi_bt_assemble(gvi_ctx* ctx, int nsets, const int* set_ids, const double* const* Vdmu,
+                           const double* const* Vddmu, double* g, double* D, double* U) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (nsets < 1 || !set_ids || !Vdmu || !Vddmu || !g || !D || !U) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t T = ctx->T, n = ctx->n, nn = n * n, tot = T * n + bt_count(ctx);
+  HIPCK(ctx, ctx->scratch.ensure(tot * 8));
+  double* dg = ctx->scratch.d();
+  double* dD = dg + T * n;
+  double* dU = dD + T * nn;
+  HIPCK(ctx, hipMemsetAsync(dg, 0, tot * 8, ctx->stream));
+  for (int i = 0; i < nsets; ++i) {
+    FactorSet* s = get_set(ctx, set_ids[i]);
+    if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
+    GVICK(h2d(ctx, s->Vdmu.p, Vdmu[i], (size_t)s->K * s->d * 8));
+    GVICK(h2d(ctx, s->Vddmu.p, Vddmu[i], (size_t)s->K * s->d * s->d * 8));
+    GVICK(run_scatter(ctx, *s, s->Vdmu.d(), s->Vddmu.d(), dg, dD, dU));
+  }
+  GVICK(d2h(ctx, g, dg, T * n * 8));
+  GVICK(d2h(ctx, D, dD, T * nn * 8));
+  if (T > 1) GVICK(d2h(ctx, U, dU, (T - 1) * nn * 8));
+  return sync(ctx);
+}
+
+static gvi_status stage_chain(gvi_ctx* ctx, const double* D, const double* U, size_t extra, double** dD, double** dU,
+                              double** dextra) {
+  const size_t T = ctx->T, nn = nn_(ctx);
+  HIPCK(ctx, ctx->scratch.ensure((bt_count(ctx) + extra) * 8));
+  *dD = ctx->scratch.d();
+  *dU = *dD + T * nn;
+  *dextra = *dU + (T - 1) * nn;
+  GVICK(h2d(ctx, *dD, D, T * nn * 8));
+  if (T > 1) GVICK(h2d(ctx, *dU, U, (T - 1) * nn * 8));
+  return GVI_OK;
+}
+
+gvi_status gvi_bt_solve(gvi_ctx* ctx, const double* D, const double* U, const double* rhs, double* x) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (!D || (!U && ctx->T > 1) || !rhs || !x) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t Tn = (size_t)ctx->T * ctx->n;
+  double *dD, *dU, *ex;
+  GVICK(stage_chain(ctx, D, U, 2 * Tn, &dD, &dU, &ex));
+  GVICK(h2d(ctx, ex, rhs, Tn * 8));
+  GVICK(run_bt_solve(ctx, dD, dU, ex, 1.0, ex + Tn));
+  GVICK(d2h(ctx, x, ex + Tn, Tn * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_bt_logdet(gvi_ctx* ctx, const double* D, const double* U, double* half_logdet) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (!D || (!U && ctx->T > 1) || !half_logdet) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  double *dD, *dU, *ex;
+  GVICK(stage_chain(ctx, D, U, 1, &dD, &dU, &ex));
+  GVICK(run_bt_factor(ctx, dD, dU, nullptr, nullptr, ex));
+  GVICK(d2h(ctx, half_logdet, ex, 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_bt_marginals(gvi_ctx* ctx, const double* D, const double* U, double* SigD, double* SigU) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (!D || (!U && ctx->T > 1) || !SigD || (!SigU && ctx->T > 1)) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t T = ctx->T, nn = nn_(ctx);
+  double *dD, *dU, *ex;
+  GVICK(stage_chain(ctx, D, U, bt_count(ctx) + 1, &dD, &dU, &ex));
+  double* sD = ex;
+  double* sU = sD + T * nn;
+  GVICK(run_bt_factor(ctx, dD, dU, sD, sU, sU + (T - 1) * nn));
+  GVICK(d2h(ctx, SigD, sD, T * nn * 8));
+  if (T > 1) GVICK(d2h(ctx, SigU, sU, (T - 1) * nn * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_gather_marginals(gvi_ctx* ctx, int set_id, const double* mu, const double* SigD, const double* SigU,
+                                double* mu_k, double* Sigma_k) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
+  if (!mu || !SigD || (!SigU && ctx->T > 1) || !mu_k || !Sigma_k) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t T = ctx->T, n = ctx->n, nn = n * n;
+  HIPCK(ctx, ctx->scratch.ensure((T * n + bt_count(ctx)) * 8));
+  double* dmu = ctx->scratch.d();
+  double* sD = dmu + T * n;
+  double* sU = sD + T * nn;
+  GVICK(h2d(ctx, dmu, mu, T * n * 8));
+  GVICK(h2d(ctx, sD, SigD, T * nn * 8));
+  if (T > 1) GVICK(h2d(ctx, sU, SigU, (T - 1) * nn * 8));
+  GVICK(run_gather(ctx, *s, dmu, sD, sU, s->mu_k[0].d(), s->Sigma_k[0].d()));
+  GVICK(d2h(ctx, mu_k, s->mu_k[0].p, (size_t)s->K * s->d * 8));
+  GVICK(d2h(ctx, Sigma_k, s->Sigma_k[0].p, (size_t)s->K * s->d * s->d * 8));
+  return sync(ctx);
+}
+
+// ---- device-resident NGD iteration ----
+static gvi_status ngd_check(gvi_ctx* ctx) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (!ctx->ngd.ready) return fail(ctx, GVI_ERR_STATE, "call gvi_ngd_init first");
+  return GVI_OK;
+}
+
+// marginals + log-det of Lam[i], then gather every set's (mu_k, Sigma_k) into slot i
+static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, nn = nn_(ctx);
+  double* D = g.Lam[i].d();
+  double* U = D + T * nn;
+  double* sD = g.Sig[i].d();
+  double* sU = sD + T * nn;
+  GVICK(run_bt_factor(ctx, D, U, sD, sU, g.hld[i].d()));
+  for (auto& s : ctx->sets) GVICK(run_gather(ctx, *s, g.mu[i].d(), sD, sU, s->mu_k[i].d(), s->Sigma_k[i].d()));
+  return GVI_OK;
+}
+
+// sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0]
+static gvi_status ngd_cost_local(gvi_ctx* ctx, int i) {
+  NgdState& g = ctx->ngd;
+  int first = 1;
+  if (ctx->sets.empty()) HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
+  for (auto& s : ctx->sets) {
+    if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
+    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d()));
+    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0));
+    GVICK(run_epilogue(ctx, *s, 0, nullptr, s->cost.d(), nullptr, nullptr, nullptr, nullptr));
+    hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, s->K, s->cost.d(), g.exch1.d(), first);
+    HIPCK(ctx, hipGetLastError());
+    first = 0;
+  }
+  return GVI_OK;
+}
+
+static gvi_status ngd_cost_finish(gvi_ctx* ctx, int i, double* out) {
+  NgdState& g = ctx->ngd;
+  hipLaunchKernelGGL(cost_total_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), g.total.d());
+  HIPCK(ctx, hipGetLastError());
+  double v = 0.0;
+  GVICK(d2h(ctx, &v, g.total.p, 8));
+  GVICK(sync(ctx));
+  g.cost[i] = v;
+  g.cost_valid[i] = true;
+  if (out) *out = v;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const double* U) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (ctx->T < 1) return fail(ctx, GVI_ERR_STATE, "call gvi_chain_set first");
+  if (!mu || !D || (!U && ctx->T > 1)) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n, bt = bt_count(ctx);
+  for (int i = 0; i < 2; ++i) {
+    HIPCK(ctx, g.mu[i].ensure(T * n * 8));
+    HIPCK(ctx, g.Lam[i].ensure(bt * 8));
+    HIPCK(ctx, g.Sig[i].ensure(bt * 8));
+    HIPCK(ctx, g.hld[i].ensure(8));
+  }
+  HIPCK(ctx, g.exch0.ensure((T * n + bt) * 8));
+  HIPCK(ctx, g.exch1.ensure(8));
+  HIPCK(ctx, g.dmu.ensure(T * n * 8));
+  HIPCK(ctx, g.dLam.ensure(bt * 8));
+  HIPCK(ctx, g.total.ensure(8));
+  for (auto& s : ctx->sets) GVICK(ensure_set_buffers(ctx, *s));
+  g.cur = 0; g.have_trial = false;
+  g.cost_valid[0] = g.cost_valid[1] = false;
+  GVICK(h2d(ctx, g.mu[0].p, mu, T * n * 8));
+  GVICK(h2d(ctx, g.Lam[0].p, D, T * nn * 8));
+  if (T > 1) GVICK(h2d(ctx, g.Lam[0].d() + T * nn, U, (T - 1) * nn * 8));
+  GVICK(ngd_refresh(ctx, 0));
+  GVICK(sync(ctx));
+  g.ready = true;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_cost(gvi_ctx* ctx, double* cost) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  if (!g.cost_valid[g.cur]) {
+    GVICK(ngd_cost_local(ctx, g.cur));
+    GVICK(ngd_cost_finish(ctx, g.cur, nullptr));
+  }
+  if (cost) *cost = g.cost[g.cur];
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs) {
+  GVICK(ngd_check(ctx));
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s || !costs) return fail(ctx, GVI_ERR_ARG, "bad set id / NULL");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const int i = ctx->ngd.cur;
+  GVICK(gvi_costs_dev(ctx, set_id, s->mu_k[i].d(), s->Sigma_k[i].d(), s->cost.d()));
+  GVICK(d2h(ctx, costs, s->cost.p, (size_t)s->K * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n;
+  const int i = g.cur;
+  double* eg = g.exch0.d();
+  double* eD = eg + T * n;
+  double* eU = eD + T * nn;
+  HIPCK(ctx, hipMemsetAsync(eg, 0, (T * n + bt_count(ctx)) * 8, ctx->stream));
+  for (auto& s : ctx->sets) {
+    if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
+    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d()));
+    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 1));
+    GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), s->cost.d(), s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr));
+    GVICK(run_scatter(ctx, *s, s->Vdmu.d(), s->Vddmu.d(), eg, eD, eU));
+  }
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_gradients_finish(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n, bt = bt_count(ctx);
+  double* eg = g.exch0.d();
+  double* eD = eg + T * n;
+  double* eU = eD + T * nn;
+  hipLaunchKernelGGL(sub_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)bt, eD,
+                     g.Lam[g.cur].d(), g.dLam.d());
+  HIPCK(ctx, hipGetLastError());
+  return run_bt_solve(ctx, eD, eU, eg, -1.0, g.dmu.d());
+}
+
+gvi_status gvi_ngd_gradients(gvi_ctx* ctx) {
+  GVICK(gvi_ngd_gradients_local(ctx));
+  return gvi_ngd_gradients_finish(ctx);
+}
+
+gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  const size_t Tn = (size_t)ctx->T * ctx->n, bt = bt_count(ctx);
+  const int c = g.cur, t = 1 - c;
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((Tn + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn, step,
+                     g.mu[c].d(), g.dmu.d(), g.mu[t].d());
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)bt, step,
+                     g.Lam[c].d(), g.dLam.d(), g.Lam[t].d());
+  HIPCK(ctx, hipGetLastError());
+  g.cost_valid[t] = false;
+  GVICK(ngd_refresh(ctx, t));
+  GVICK(ngd_cost_local(ctx, t));
+  g.have_trial = true;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost) {
+  GVICK(ngd_check(ctx));
+  if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  return ngd_cost_finish(ctx, 1 - ctx->ngd.cur, new_cost);
+}
+
+gvi_status gvi_ngd_trial(gvi_ctx* ctx, double step, double* new_cost) {
+  GVICK(gvi_ngd_trial_local(ctx, step));
+  return gvi_ngd_trial_finish(ctx, new_cost);
+}
+
+gvi_status gvi_ngd_accept(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
+  ctx->ngd.cur = 1 - ctx->ngd.cur;
+  ctx->ngd.have_trial = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter, int* accepted,
+                        double* new_cost, int* ntrials) {
+  GVICK(ngd_check(ctx));
+  double c0 = 0.0;
+  GVICK(gvi_ngd_cost(ctx, &c0));
+  if (cost_iter) *cost_iter = c0;
+  GVICK(gvi_ngd_gradients(ctx));
+  double step = step_size_base, c1 = c0;
+  int cnt = 0, ok = 0;
+  while (true) {
+    step *= 0.75;                                  // gvibase/GVI-GH-impl.h:83
+    GVICK(gvi_ngd_trial(ctx, step, &c1));
+    if (c1 < c0) { GVICK(gvi_ngd_accept(ctx)); ok = 1; ++cnt; break; }   // NaN compares false -> rejected
+    ++cnt;
+    if (cnt > max_backtrack) break;
+  }
+  if (accepted) *accepted = ok;
+  if (new_cost) *new_cost = ok ? c1 : c0;
+  if (ntrials) *ntrials = cnt;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_exchange(gvi_ctx* ctx, int which, void** dev_ptr, int64_t* count) {
+  GVICK(ngd_check(ctx));
+  if (!dev_ptr || !count) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  if (which == 0) { *dev_ptr = ctx->ngd.exch0.p; *count = (int64_t)((size_t)ctx->T * ctx->n + bt_count(ctx)); }
+  else if (which == 1) { *dev_ptr = ctx->ngd.exch1.p; *count = 1; }
+  else return fail(ctx, GVI_ERR_ARG, "which must be 0 or 1");
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_get_state(gvi_ctx* ctx, double* mu, double* D, double* U, double* SigD, double* SigU) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n;
+  const int i = g.cur;
+  if (mu) GVICK(d2h(ctx, mu, g.mu[i].p, T * n * 8));
+  if (D) GVICK(d2h(ctx, D, g.Lam[i].p, T * nn * 8));
+  if (U && T > 1) GVICK(d2h(ctx, U, g.Lam[i].d() + T * nn, (T - 1) * nn * 8));
+  if (SigD) GVICK(d2h(ctx, SigD, g.Sig[i].p, T * nn * 8));
+  if (SigU && T > 1) GVICK(d2h(ctx, SigU, g.Sig[i].d() + T * nn, (T - 1) * nn * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* dU, double* gq, double* VD, double* VU) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n;
+  if (dmu) GVICK(d2h(ctx, dmu, g.dmu.p, T * n * 8));
+  if (dD) GVICK(d2h(ctx, dD, g.dLam.p, T * nn * 8));
+  if (dU && T > 1) GVICK(d2h(ctx, dU, g.dLam.d() + T * nn, (T - 1) * nn * 8));
+  if (gq) GVICK(d2h(ctx, gq, g.exch0.p, T * n * 8));
+  if (VD) GVICK(d2h(ctx, VD, g.exch0.d() + T * n, T * nn * 8));
+  if (VU && T > 1) GVICK(d2h(ctx, VU, g.exch0.d() + T * n + T * nn, (T - 1) * nn * 8));
+  return sync(ctx);
+}
+
+gvi_status gvi_profile_enable(gvi_ctx* ctx, int on) {
+  if (!ctx) return GVI_ERR_ARG;
+  ctx->profile = on != 0;
+  for (auto& s : ctx->sets) s->ev_set[0] = s->ev_set[1] = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what, float* ms) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s || !ms || what < 0 || what > 1) return GVI_ERR_ARG;
+  if (!s->ev_set[what]) return fail(ctx, GVI_ERR_STATE, "no profiled launch recorded");
+  HIPCK(ctx, hipEventSynchronize(s->ev[what][1]));
+  HIPCK(ctx, hipEventElapsedTime(ms, s->ev[what][0], s->ev[what][1]));
+  return GVI_OK;
+}
+
+gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s) return GVI_ERR_ARG;
+  if (variant) *variant = s->use_reg ? 2 : 1;
+  if (nchunk) *nchunk = s->nchunk;
+  if (chunk) *chunk = s->chunk;
+  return GVI_OK;
+}
+
+gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
+  if (!ctx || variant < 0 || variant > 2) return GVI_ERR_ARG;
+  ctx->variant = variant;
+  return GVI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,511 @@
+// Per-factor device kernels of the NGD Gauss-Hermite hot path (gfx950, wave64, fp64).
+//
+//   prep_kernel      Sigma_k -> S_k = Sigma_k^{1/2}, S_k^{-1}, Lam_k = Sigma_k^{-1} (parallel Jacobi,
+//                    one wave per factor) and the per-pass psi operands H_k = A_k S_k, u0_k
+//                    [SparseGaussHermite::update_sigmapoints, quadrature/SparseGaussHermite.h:231-243;
+//                     update_precision_from_joint, gvibase/GVIFactorizedBase.h:111-114]
+//   moments_*        c_i = w_i psi(mu + S z_i) and the z-space moments  sum_i c_i [1, z_i, z_i z_i^T]
+//                    [SparseGaussHermite::Integrate x3, quadrature/SparseGaussHermite.h:197-221;
+//                     closures ngd/NGDFactorizedBaseGH.h:46-48]
+//   epilogue_kernel  ordered sum of the chunk partials, back-transform to x-space, Vdmu_k / Vddmu_k
+//                    [calculate_partial_V, ngd/NGDFactorizedBaseGH.h:53-74]
+//   expand_kernel    X = mu + S z for the host-callback psi route.
+//
+// Formulation.  With x = mu + S z:  E[(x-mu) psi] = S m1,  E[(x-mu)(x-mu)^T psi] = S M2 S  where
+// m1 = sum c_i z_i, M2 = sum c_i z_i z_i^T are accumulated in z-space, so the N x d x d expand GEMM of
+// the reference disappears from the per-point work.  Because Lam S = S^{-1}:
+//   Vdmu = S^{-1} m1 / T,   Vddmu = (S^{-1} M2 S^{-1} - Lam m0) / T.
+// Sum-of-squares psi kinds (quadratic priors) are evaluated as psi = sum_r s_r (u0 + H z)_r^2 with
+// H = A S folded per pass, A = diag(sqrt|e|) W^T [Phi, -I] from the eigen-decomposition of Qinv done
+// once on the host at gvi_factors_add.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gvi {
+
+enum { KIND_RANGE_1D = 0, KIND_QUAD_PRIOR = 1, KIND_FIXED_PRIOR = 2, KIND_HOST_CALLBACK = 3 };
+
+__host__ __device__ inline int npairs(int d) { return (d + 1) * (d + 2) / 2; }
+
+// packed z-space moment layout: [0] m0 | [1..d] m1 | then upper triangle of M2 row by row
+__host__ __device__ inline int pair_index(int d, int a, int b) {  // a <= b < d
+  return 1 + d + a * d - a * (a - 1) / 2 + (b - a);
+}
+
+struct FactorDev {
+  int K, d, m, kind;
+  int64_t N, Np;            // points, padded to a multiple of 64 (pad: z = 0, w = 0)
+  const double* Zt;         // [d][Np] dimension-major: lane-over-points loads are coalesced
+  const double* w;          // [Np]
+  const double* A;          // [K][m][d]   sum-of-squares kinds
+  const double* b;          // [K][m]
+  const double* sgn;        // [K][m]
+  const double* raw;        // [K][raw_stride] raw parameter block (RANGE_1D)
+  int raw_stride;
+  const double* temperature;  // [K]
+  // per-pass products of prep_kernel
+  double* S;                // [K][d][d]
+  double* Sinv;             // [K][d][d]
+  double* Lam;              // [K][d][d]
+  double* H;                // [K][m][d]
+  double* u0;               // [K][m]
+};
+
+// ---------------------------------------------------------------------------------------------
+// prep_kernel: one wave (block of 64) per factor.  Parallel-ordered (round-robin) cyclic Jacobi on
+// the symmetric d x d block held in LDS; every round applies d/2 disjoint plane rotations at once:
+//   A'_ij = al_i al_j A_ij + al_i be_j A_i,pj + be_i al_j A_pi,j + be_i be_j A_pi,pj ,
+//   V'_ij = al_j V_ij + be_j V_i,pj           (p. = rotation partner, (al, be) = (c, -/+s)).
+// ---------------------------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __restrict__ mu,
+                                                  const double* __restrict__ Sigma) {
+  extern __shared__ double sm[];
+  const int d = f.d, dd = d * d, k = blockIdx.x, lane = threadIdx.x;
+  const int dp = d + (d & 1);
+  double* A0 = sm;
+  double* A1 = A0 + dd;
+  double* V0 = A1 + dd;
+  double* V1 = V0 + dd;
+  double* al = V1 + dd;          // [dp]
+  double* be = al + dp;          // [dp]
+  double* lam = be + dp;         // [d] (3 functions of lambda: sqrt, 1/sqrt, 1/x)
+  int* pa = (int*)(lam + 3 * d); // [dp]
+
+  const double* Sg = Sigma + (size_t)k * dd;
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    A0[e] = i >= j ? Sg[i * d + j] : Sg[j * d + i];   // lower triangle, like SelfAdjointEigenSolver
+    V0[e] = i == j ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double* A = A0; double* An = A1; double* V = V0; double* Vn = V1;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0, dg = 0.0;
+    for (int e = lane; e < dd; e += 64) {
+      const int i = e / d, j = e % d;
+      const double v = A[e];
+      if (i == j) dg += v * v; else if (i < j) off += v * v;
+    }
+    off = wave_sum(off);
+    dg = wave_sum(dg);
+    if (off <= 1e-34 * dg) break;      // false for NaN input: runs the (bounded) 40 sweeps
+    for (int r = 0; r < dp - 1; ++r) {
+      if (lane < dp / 2) {
+        int p, q;
+        if (lane == 0) { p = dp - 1; q = r; }
+        else { p = (r + lane) % (dp - 1); q = (r - lane + dp - 1) % (dp - 1); }
+        if (p > q) { const int t = p; p = q; q = t; }
+        double c = 1.0, s = 0.0;
+        const bool valid = q < d;
+        if (valid) {
+          const double apq = A[p * d + q];
+          if (apq != 0.0) {
+            const double theta = (A[q * d + q] - A[p * d + p]) / (2.0 * apq);
+            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            c = 1.0 / sqrt(t * t + 1.0);
+            s = t * c;
+          }
+        }
+        al[p] = c; be[p] = -s; pa[p] = valid ? q : p;
+        al[q] = c; be[q] = s;  pa[q] = valid ? p : q;
+      }
+      __syncthreads();
+      for (int e = lane; e < dd; e += 64) {
+        const int i = e / d, j = e % d;
+        const int pi = pa[i], pj = pa[j];
+        const double ai = al[i], bi = be[i], aj = al[j], bj = be[j];
+        An[e] = ai * (aj * A[i * d + j] + bj * A[i * d + pj]) + bi * (aj * A[pi * d + j] + bj * A[pi * d + pj]);
+        Vn[e] = aj * V[i * d + j] + bj * V[i * d + pj];
+      }
+      __syncthreads();
+      double* t = A; A = An; An = t;
+      t = V; V = Vn; Vn = t;
+    }
+  }
+  if (lane < d) {
+    const double l = A[lane * d + lane];
+    lam[lane] = sqrt(l);               // negative eigenvalue -> NaN, as the reference's operatorSqrt
+    lam[d + lane] = 1.0 / sqrt(l);
+    lam[2 * d + lane] = 1.0 / l;
+  }
+  __syncthreads();
+  // S, S^-1, Lam = V f(lambda) V^T; S is also kept in LDS (An) for H = A_k S
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < d; ++c) {
+      const double vv = V[i * d + c] * V[j * d + c];
+      s0 += vv * lam[c]; s1 += vv * lam[d + c]; s2 += vv * lam[2 * d + c];
+    }
+    An[e] = s0;
+    f.S[(size_t)k * dd + e] = s0;
+    f.Sinv[(size_t)k * dd + e] = s1;
+    f.Lam[(size_t)k * dd + e] = s2;
+  }
+  __syncthreads();
+  if (f.m > 0) {
+    const int m = f.m;
+    const double* Ak = f.A + (size_t)k * m * d;
+    for (int e = lane; e < m * d; e += 64) {
+      const int r = e / d, a = e % d;
+      double h = 0.0;
+      for (int c = 0; c < d; ++c) h += Ak[r * d + c] * An[c * d + a];
+      f.H[(size_t)k * m * d + e] = h;
+    }
+    if (lane < m) {
+      double u = f.b[(size_t)k * m + lane];
+      for (int c = 0; c < d; ++c) u += Ak[lane * d + c] * mu[(size_t)k * d + c];
+      f.u0[(size_t)k * m + lane] = u;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// psi evaluation at an x-space point (generic kernel, expand-based).
+// ---------------------------------------------------------------------------------------------
+__device__ inline double psi_range_1d(const double* p, double x) {
+  // p = [y, mu_p, f*b, sig_r_sq, sig_p_sq]            (src/1d_example.cpp:25-35)
+  const double e = x - p[1], r = p[0] - p[2] / x;
+  return e * e / p[4] / 2 + r * r / p[3] / 2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// moments_generic_kernel: any d (<= 32), any psi kind.  Block = 256 threads handles one factor and a
+// range of points in sub-chunks of 256: stage 1 (thread = point) expands x = mu + S z, evaluates
+// psi and parks [z, 1] and c = w psi in LDS; stage 2 (thread = output pair (a,b)) accumulates
+// sum_i c_i zh_i[a] zh_i[b].  LDS-bound; it is the reference-shaped fallback and the parity
+// cross-check for the register kernel.
+// ---------------------------------------------------------------------------------------------
+struct MomArgs {
+  FactorDev f;
+  const double* mu;        // [K][d]
+  const double* psi_ext;   // [K][N] host-evaluated psi (HOST_CALLBACK) or nullptr
+  double* partial;         // [K][nchunk][npo]
+  int64_t chunk;           // points per block (multiple of 256 for generic, 64 for register kernel)
+  int nchunk;
+  int full;                // 1: all moments, 0: m0 only (cost pass)
+};
+
+constexpr int GEN_BS = 256;
+constexpr int GEN_MAX_OUT = 3;   // outputs per thread: npairs(d) <= 768 -> d <= 37
+
+__global__ __launch_bounds__(GEN_BS) void moments_generic_kernel(MomArgs a) {
+  extern __shared__ double sm[];
+  const FactorDev& f = a.f;
+  const int d = f.d, m = f.m, k = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+  const int dz = d + 1;
+  double* zs = sm;                         // [256][dz]   z and the constant 1
+  double* xs = zs + GEN_BS * dz;           // [256][dz]   x = mu + S z
+  double* cs = xs + GEN_BS * dz;           // [256]
+  double* Ssh = cs + GEN_BS;               // [d][d]
+  double* mush = Ssh + d * d;              // [d]
+  double* Ash = mush + d;                  // [m][d]
+  double* bsh = Ash + m * d;               // [m]
+  double* gsh = bsh + m;                   // [m]
+  for (int e = tid; e < d * d; e += GEN_BS) Ssh[e] = f.S[(size_t)k * d * d + e];
+  for (int e = tid; e < d; e += GEN_BS) mush[e] = a.mu[(size_t)k * d + e];
+  for (int e = tid; e < m * d; e += GEN_BS) Ash[e] = f.A[(size_t)k * m * d + e];
+  for (int e = tid; e < m; e += GEN_BS) { bsh[e] = f.b[(size_t)k * m + e]; gsh[e] = f.sgn[(size_t)k * m + e]; }
+  const int npo = a.full ? npairs(d) : 1;
+  int oa[GEN_MAX_OUT], ob[GEN_MAX_OUT];
+  double acc[GEN_MAX_OUT];
+#pragma unroll
+  for (int o = 0; o < GEN_MAX_OUT; ++o) {
+    acc[o] = 0.0;
+    const int j = tid + o * GEN_BS;
+    int pa_ = d, pb_ = d;                   // j == 0 -> (1,1)
+    if (j >= 1 && j <= d) { pa_ = j - 1; pb_ = d; }
+    else if (j > d) {
+      int rem = j - 1 - d, row = 0;
+      while (row < d && rem >= d - row) { rem -= d - row; ++row; }
+      pa_ = row; pb_ = row + rem;
+    }
+    oa[o] = pa_; ob[o] = pb_;
+  }
+  double csum = 0.0;
+  const int64_t i0 = (int64_t)chunk * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < f.Np) ? i0 + a.chunk : f.Np;
+  __syncthreads();
+  for (int64_t base = i0; base < i1; base += GEN_BS) {
+    const int64_t i = base + tid;
+    double* zr = zs + tid * dz;
+    double* xr = xs + tid * dz;
+    double wi = 0.0;
+    if (i < i1) {
+      wi = f.w[i];
+      for (int c = 0; c < d; ++c) zr[c] = f.Zt[(size_t)c * f.Np + i];
+    } else {
+      for (int c = 0; c < d; ++c) zr[c] = 0.0;
+    }
+    zr[d] = 1.0;
+    double psi = 0.0;
+    if (i < f.N) {
+      for (int r = 0; r < d; ++r) {
+        double x = mush[r];
+        for (int c = 0; c < d; ++c) x += Ssh[r * d + c] * zr[c];
+        xr[r] = x;
+      }
+      if (a.psi_ext) psi = a.psi_ext[(size_t)k * f.N + i];
+      else if (f.kind == KIND_RANGE_1D) psi = psi_range_1d(f.raw + (size_t)k * f.raw_stride, xr[0]);
+      else {
+        for (int r = 0; r < m; ++r) {
+          double u = bsh[r];
+          for (int c = 0; c < d; ++c) u += Ash[r * d + c] * xr[c];
+          psi += gsh[r] * u * u;
+        }
+      }
+    }
+    const double c = wi * psi;
+    cs[tid] = c;
+    csum += c;
+    __syncthreads();
+    if (a.full) {
+#pragma unroll
+      for (int o = 0; o < GEN_MAX_OUT; ++o) {
+        if (tid + o * GEN_BS < npo) {
+          double s = acc[o];
+          const int pa_ = oa[o], pb_ = ob[o];
+          for (int t = 0; t < GEN_BS; ++t) s += cs[t] * zs[t * dz + pa_] * zs[t * dz + pb_];
+          acc[o] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  double* out = a.partial + ((size_t)k * a.nchunk + chunk) * npo;
+  if (a.full) {
+#pragma unroll
+    for (int o = 0; o < GEN_MAX_OUT; ++o)
+      if (tid + o * GEN_BS < npo) out[tid + o * GEN_BS] = acc[o];
+  } else {
+    cs[tid] = csum;
+    __syncthreads();
+    for (int s = GEN_BS / 2; s > 0; s >>= 1) {
+      if (tid < s) cs[tid] += cs[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) out[0] = cs[0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// moments_reg_kernel<D, Psi, FULL>: the hot kernel.  Block = 4 waves = 4 consecutive factors over
+// the same range of points (so a Z chunk is fetched once per block into L1/L2 and reused by the
+// four waves).  Lane owns points i = base + lane: d coalesced 8-byte loads from the dimension-major
+// table, psi through the factor's LDS-resident H (wave-uniform broadcast reads), and all
+// (d+1)(d+2)/2 z-space accumulators in registers.  Cross-lane reduction once per wave: 16 accumulators
+// at a time through a padded LDS tile, then two xor-shuffles.  No atomics: partials are written per
+// (factor, chunk) and summed in fixed order by epilogue_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int D, int M>
+struct PsiQuad {
+  static constexpr int LDS = M * D + 2 * M;
+  __device__ static void load(const MomArgs& a, int k, double* hs, int lane) {
+    for (int e = lane; e < M * D; e += 64) hs[e] = a.f.H[(size_t)k * M * D + e];
+    if (lane < M) {
+      hs[M * D + lane] = a.f.u0[(size_t)k * M + lane];
+      hs[M * D + M + lane] = a.f.sgn[(size_t)k * M + lane];
+    }
+  }
+  __device__ static double eval(const double (&z)[D], const double* hs) {
+    double u[M];                      // M independent FMA chains (column-outer order)
+#pragma unroll
+    for (int r = 0; r < M; ++r) u[r] = hs[M * D + r];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+#pragma unroll
+      for (int r = 0; r < M; ++r) u[r] = fma(hs[r * D + c], z[c], u[r]);
+    }
+    double psi = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) psi = fma(hs[M * D + M + r] * u[r], u[r], psi);
+    return psi;
+  }
+};
+
+struct PsiRange1D {
+  static constexpr int LDS = 8;
+  __device__ static void load(const MomArgs& a, int k, double* hs, int lane) {
+    if (lane == 0) { hs[0] = a.mu[k]; hs[1] = a.f.S[k]; }
+    if (lane < 5) hs[2 + lane] = a.f.raw[(size_t)k * a.f.raw_stride + lane];
+  }
+  __device__ static double eval(const double (&z)[1], const double* hs) {
+    return psi_range_1d(hs + 2, fma(hs[1], z[0], hs[0]));
+  }
+};
+
+template <int D, typename Psi, bool FULL>
+__global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
+  constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
+  constexpr int NB = (NP + 15) / 16;
+  __shared__ double hs[4][Psi::LDS];
+  __shared__ double red[4][16][65];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + wave;
+  const bool active = k < a.f.K;
+  if (active) Psi::load(a, k, hs[wave], lane);
+  __syncthreads();
+  double acc[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const double* __restrict__ Zt = a.f.Zt;
+  const double* __restrict__ w = a.f.w;
+  if (active) {
+    for (int64_t i = i0 + lane; i < i1; i += 64) {
+      double z[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) z[c] = Zt[(size_t)c * Np + i];
+      // padded tail (i >= N) carries w = 0, z = 0; the select keeps a non-finite psi(mu) out
+      const double cw = i < a.f.N ? w[i] * Psi::eval(z, hs[wave]) : 0.0;
+      acc[0] += cw;
+      if (FULL) {
+        int q = 1 + D;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          const double t = cw * z[c];
+          acc[1 + c] += t;
+#pragma unroll
+          for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
+        }
+      }
+    }
+  }
+  double* out = a.partial + ((size_t)(active ? k : 0) * a.nchunk + blockIdx.y) * NP;
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (bb * 16 + j < NP) red[wave][j][lane] = acc[bb * 16 + j];
+    __syncthreads();
+    const int j = lane & 15, part = lane >> 4;
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += red[wave][j][part * 16 + t];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// epilogue_kernel: one wave per factor.
+// ---------------------------------------------------------------------------------------------
+struct EpiArgs {
+  FactorDev f;
+  const double* partial;   // [K][nchunk][npo]
+  int nchunk, full;
+  double* Ephi;            // [K] or null
+  double* cost;            // [K] or null   (E[psi] / T_k)
+  double* Vdmu;            // [K][d] or null
+  double* Vddmu;           // [K][d][d] or null
+  double* E_xmuphi;        // [K][d] or null       raw integrals
+  double* E_xxphi;         // [K][d][d] or null
+};
+
+__global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
+  extern __shared__ double sm[];
+  const FactorDev& f = a.f;
+  const int d = f.d, dd = d * d, k = blockIdx.x, lane = threadIdx.x;
+  const int npo = a.full ? npairs(d) : 1;
+  double* Ms = sm;              // [npo]
+  double* M2 = Ms + npairs(d);  // [d][d]
+  double* Tm = M2 + dd;         // [d][d]
+  const double* P = a.partial + (size_t)k * a.nchunk * npo;
+  for (int j = lane; j < npo; j += 64) {
+    double s = 0.0;
+    for (int c = 0; c < a.nchunk; ++c) s += P[(size_t)c * npo + j];   // fixed order: deterministic
+    Ms[j] = s;
+  }
+  __syncthreads();
+  const double m0 = Ms[0];
+  const double Tk = f.temperature[k];
+  if (lane == 0) {
+    if (a.Ephi) a.Ephi[k] = m0;
+    if (a.cost) a.cost[k] = m0 / Tk;
+  }
+  if (!a.full) return;
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    M2[e] = i <= j ? Ms[pair_index(d, i, j)] : Ms[pair_index(d, j, i)];
+  }
+  __syncthreads();
+  const double* Sinv = f.Sinv + (size_t)k * dd;
+  const double* Lam = f.Lam + (size_t)k * dd;
+  const double* S = f.S + (size_t)k * dd;
+  if (a.Vdmu) {
+    for (int i = lane; i < d; i += 64) {
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += Sinv[i * d + c] * Ms[1 + c];
+      a.Vdmu[(size_t)k * d + i] = s / Tk;
+    }
+  }
+  if (a.Vddmu) {
+    for (int e = lane; e < dd; e += 64) {
+      const int i = e / d, j = e % d;
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += Sinv[i * d + c] * M2[c * d + j];
+      Tm[e] = s;
+    }
+    __syncthreads();
+    for (int e = lane; e < dd; e += 64) {
+      const int i = e / d, j = e % d;
+      if (i <= j) {           // upper triangle, mirrored (ngd/NGDFactorizedBaseGH.h:71-72)
+        double s = 0.0;
+        for (int c = 0; c < d; ++c) s += Tm[i * d + c] * Sinv[c * d + j];
+        const double v = (s - Lam[i * d + j] * m0) / Tk;
+        a.Vddmu[(size_t)k * dd + i * d + j] = v;
+        a.Vddmu[(size_t)k * dd + j * d + i] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (a.E_xmuphi) {
+    for (int i = lane; i < d; i += 64) {
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += S[i * d + c] * Ms[1 + c];
+      a.E_xmuphi[(size_t)k * d + i] = s;
+    }
+  }
+  if (a.E_xxphi) {
+    for (int e = lane; e < dd; e += 64) {
+      const int i = e / d, j = e % d;
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += S[i * d + c] * M2[c * d + j];
+      Tm[e] = s;
+    }
+    __syncthreads();
+    for (int e = lane; e < dd; e += 64) {
+      const int i = e / d, j = e % d;
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += Tm[i * d + c] * S[j * d + c];
+      a.E_xxphi[(size_t)k * dd + e] = s;
+    }
+  }
+}
+
+// X[k][a][i] = mu_a + sum_b S_ab z_b[i]  (reference CUDA-path layout [factor][dim][point])
+__global__ __launch_bounds__(256) void expand_kernel(FactorDev f, const double* __restrict__ mu,
+                                                     double* __restrict__ X) {
+  const int k = blockIdx.y, d = f.d;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= f.N) return;
+  const double* S = f.S + (size_t)k * d * d;
+  for (int r = 0; r < d; ++r) {
+    double x = mu[(size_t)k * d + r];
+    for (int c = 0; c < d; ++c) x += S[r * d + c] * f.Zt[(size_t)c * f.Np + i];
+    X[((size_t)k * d + r) * f.N + i] = x;
+  }
+}
+
+}  // namespace gvi

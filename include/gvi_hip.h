@@ -1,0 +1,183 @@
+/*
+ * gvi_hip.h -- C ABI of the MI355X (gfx950) natural-gradient Gauss-Hermite hot path.
+ *
+ * Drop-in boundary for hzyu17/GaussianVI's NGD-GH path.  The reference has no FFI: its boundary is
+ * two C++ contracts -- the per-factor operator surface of
+ * gvibase/GVIFactorizedBase.h:128-168 / ngd/NGDFactorizedBaseGH.h:37-129 and the joint surface of
+ * gvibase/GVI-GH.h:41-46,106-144 / ngd/NGD-GH.h:25-95.  Its own CUDA variant calls the device ONCE
+ * PER PASS WITH ALL FACTORS (gvibase/GVI-GH-Cuda-impl.h:177-192 -> helpers/CudaOperation.h:424-436);
+ * this ABI keeps that batched shape.  Every entry point cites what it replaces.
+ *
+ * Conventions
+ *   - plain C, opaque context, int status (0 = GVI_OK), no global state, one HIP stream per context;
+ *   - fp64 (GVI_F64).  GVI_F32 is declared for BASELINE config 5 and currently returns
+ *     GVI_ERR_UNSUPPORTED;
+ *   - all matrices ROW-MAJOR, factor-major batches: mu[K][d], Sigma[K][d][d], Vddmu[K][d][d];
+ *     chain blocks D[T][n][n] (diagonal), U[T-1][n][n] (block (t, t+1)), vectors g[T][n];
+ *   - functions without suffix take caller-owned HOST buffers (copy in, run, copy out, sync);
+ *     the `_dev` twins take DEVICE pointers and are asynchronous on the context stream;
+ *   - there is NO CPU fallback: every compute entry point needs a gfx950 device and reports
+ *     GVI_ERR_HIP otherwise.
+ */
+#ifndef GVI_HIP_H
+#define GVI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gvi_ctx gvi_ctx;
+typedef int gvi_status;
+
+enum {
+  GVI_OK = 0,
+  GVI_ERR_ARG = 1,         /* bad argument / shape */
+  GVI_ERR_HIP = 2,         /* HIP runtime error or no device */
+  GVI_ERR_UNSUPPORTED = 3, /* valid request this build does not implement */
+  GVI_ERR_NOTABLE = 4,     /* (d, p) outside the tabulated 1-D rules (p <= 25) */
+  GVI_ERR_STATE = 5        /* call order (e.g. ngd_* before ngd_init) */
+};
+enum { GVI_F64 = 0, GVI_F32 = 1 };
+
+/* psi kinds with device implementations.  Parameter block per factor:
+ *   GVI_PSI_RANGE_1D      [y, mu_p, f*b, sig_r_sq, sig_p_sq]                d = 1
+ *       psi(x) = (x-mu_p)^2/(2 sig_p_sq) + (y - f b / x)^2/(2 sig_r_sq)     src/1d_example.cpp:25-35
+ *   GVI_PSI_QUAD_PRIOR    [Phi (n x n) | Qinv (n x n)]                      d = 2n
+ *       psi(x) = 1/2 (Phi x1 - x2)^T Qinv (Phi x1 - x2)   gp/minimum_acc_prior.h:103-106, gp/LTV_prior.h:223-226
+ *   GVI_PSI_FIXED_PRIOR   [mu0 (d) | Kinv (d x d)]                          d = n
+ *       psi(x) = (x-mu0)^T Kinv (x-mu0)                                     gp/fixed_prior.h:28-30
+ *   GVI_PSI_HOST_CALLBACK no parameters: psi is an opaque host function (the reference's
+ *       std::function, ngd/NGDFactorizedBaseGH.h:30,46-48); use gvi_expand + gvi_moments_from_psi. */
+enum { GVI_PSI_RANGE_1D = 0, GVI_PSI_QUAD_PRIOR = 1, GVI_PSI_FIXED_PRIOR = 2, GVI_PSI_HOST_CALLBACK = 3 };
+
+const char* gvi_version(void);
+/* Message of the last failing call on this context (never NULL). */
+const char* gvi_last_error(const gvi_ctx* ctx);
+
+/* ---- context: replaces CudaOperation Cuda_init / Cuda_free (helpers/CudaOperation.h:424-436) ---- */
+gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out);
+gvi_status gvi_ctx_destroy(gvi_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. the framework's current stream); NULL = own stream. */
+gvi_status gvi_ctx_set_stream(gvi_ctx* ctx, void* hip_stream);
+gvi_status gvi_ctx_sync(gvi_ctx* ctx);
+
+/* ---- quadrature table, host side: replaces nwspgr('GQN', d, p, 1) + the cereal table lookup
+ *      (quadrature/GH/SparseGH/nwspgr.m:32-134; quadrature/SparseGaussHermite.h:138-166) ----
+ * Z [N][d] rows ascending lexicographic, w [N], idx [N][d][3] = (level, node index, sign) of every
+ * coordinate (0 is canonicalised to (1,0,0)) -- the bit-exact "sigma-point index".  Any of Z/w/idx
+ * may be NULL.  Needs no GPU. */
+gvi_status gvi_spgh_count(int d, int p, int64_t* N);
+gvi_status gvi_spgh_nodes(int d, int p, int64_t N, double* Z, double* w, int8_t* idx);
+
+/* ---- problem definition ---- */
+/* Chain of T states of size n (joint dimension T n): GVIGH(vec_factors, dim_state, num_states, ...)
+ * gvibase/GVI-GH.h:41-64.  Drops previously added factor sets. */
+gvi_status gvi_chain_set(gvi_ctx* ctx, int T, int n);
+/* Add a homogeneous set of K factors (same d, GH degree p, psi kind): the batched counterpart of
+ * constructing K NGDFactorizedBaseGH objects (ngd/NGDFactorizedBaseGH.h:37-44).  start[k] is the
+ * reference's start_index (first state of factor k); d must be n or 2n.  temperature may be NULL
+ * (= 1).  Generates the (d,p) table and uploads it unless a table for (d,p) is already resident. */
+gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
+                           const double* psi_params, int64_t params_per_factor,
+                           const double* temperature, int* set_id);
+/* Replace the set's quadrature table by a caller-supplied one (e.g. read from the reference's
+ * cereal file quadrature/SparseGHQuadratureWeights_cereal.bin): Z [N][d], w [N], host. */
+gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const double* Z, const double* w);
+/* factor_switch_to_high_temperature (gvibase/GVIFactorizedBase.h:212-214), batched. */
+gvi_status gvi_factors_set_temperature(gvi_ctx* ctx, int set_id, const double* temperature);
+gvi_status gvi_factors_info(const gvi_ctx* ctx, int set_id, int* K, int* d, int* p, int64_t* N);
+
+/* ---- per-pass factor operators (one call = all K factors of the set) ---- */
+/* calculate_partial_V for every factor (ngd/NGDFactorizedBaseGH.h:53-74): symmetric sqrt of Sigma_k,
+ * sigma-point expand, psi, the three GH integrals, Vdmu_k = Lam_k E[(x-mu)psi]/T_k and
+ * Vddmu_k = sym(Lam_k E[(x-mu)(x-mu)^T psi] Lam_k - Lam_k E[psi])/T_k with Lam_k = Sigma_k^-1.
+ * Ephi[K] receives E[psi] (untempered).  Any output may be NULL. */
+gvi_status gvi_moments(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma,
+                       double* Ephi, double* Vdmu, double* Vddmu);
+gvi_status gvi_moments_dev(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma,
+                           double* Ephi, double* Vdmu, double* Vddmu);
+/* The raw integrals E_Phi / E_xMuPhi / E_xMuxMuTPhi (gvibase/GVIFactorizedBaseGH.h:54-64). */
+gvi_status gvi_raw_moments(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma,
+                           double* E_phi, double* E_xmuphi, double* E_xxphi);
+/* fact_cost_value for every factor (ngd/NGDFactorizedBaseGH.h:122-129): cost[k] = E[psi]/T_k. */
+gvi_status gvi_costs(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* cost);
+gvi_status gvi_costs_dev(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* cost);
+/* Generic-psi route (any kind): sigma points X [K][d][N] in the reference CUDA path's layout
+ * (gvibase/GVI-GH-Cuda-impl.h:177-189: [factor][dim][point]); the host evaluates psi [K][N];
+ * the device reduces.  SparseGaussHermite::update_sigmapoints / Integrate
+ * (quadrature/SparseGaussHermite.h:197-243). */
+gvi_status gvi_expand(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* X);
+gvi_status gvi_moments_from_psi(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma,
+                                const double* psi, double* Ephi, double* Vdmu, double* Vddmu);
+
+/* ---- joint (block-tridiagonal) operators ---- */
+/* local2joint_dmu_insertion / local2joint_dprecision_insertion + the sum of
+ * NGDGH::compute_gradients (ngd/NGDFactorizedBaseGH.h:91-106; ngd/NGD-GH-impl.h:39-55):
+ * g, D, U are overwritten with the ordered (set after set, factor index ascending) sum.
+ * Vdmu[s] / Vddmu[s] belong to set_ids[s]. */
+gvi_status gvi_bt_assemble(gvi_ctx* ctx, int nsets, const int* set_ids, const double* const* Vdmu,
+                           const double* const* Vddmu, double* g, double* D, double* U);
+/* x = A^-1 rhs for the symmetric block-tridiagonal A = (D, U): replaces the ConjugateGradient of
+ * ngd/NGD-GH-impl.h:59-60 by a direct block elimination (partial pivoting inside blocks). */
+gvi_status gvi_bt_solve(gvi_ctx* ctx, const double* D, const double* U, const double* rhs, double* x);
+/* sum(log pivots)/2 of the natural-order LDL^T (gvibase/GVI-GH-impl.h:192-196).  NaN when a pivot is
+ * not positive, so the reference's "NaN < cost is false -> reject the step" rule survives. */
+gvi_status gvi_bt_logdet(gvi_ctx* ctx, const double* D, const double* U, double* half_logdet);
+/* Tridiagonal blocks of A^-1: inverse_GBP / EigenWrapper::inv_sparse
+ * (gvibase/GVI-GH-GBP-impl.h:246-305; helpers/EigenWrapper.h:282-381). */
+gvi_status gvi_bt_marginals(gvi_ctx* ctx, const double* D, const double* U, double* SigD, double* SigU);
+/* update_mu_from_joint / extract_cov_from_joint for every factor of the set
+ * (gvibase/GVIFactorizedBase.h:104-122): mu_k [K][d], Sigma_k [K][d][d]. */
+gvi_status gvi_gather_marginals(gvi_ctx* ctx, int set_id, const double* mu, const double* SigD,
+                                const double* SigU, double* mu_k, double* Sigma_k);
+
+/* ---- device-resident NGD iteration: GVIGH::optimize body (gvibase/GVI-GH-impl.h:39-118) with
+ *      NGDGH::compute_gradients / onestep_linesearch / update_proposal (ngd/NGD-GH-impl.h:21-63,
+ *      130-156).  State (mu, Lambda, marginals, per-factor (mu_k, Sigma_k)) never leaves HBM. ---- */
+gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const double* U); /* host */
+/* cost_value() at the current proposal (gvibase/GVI-GH-impl.h:176-197). */
+gvi_status gvi_ngd_cost(gvi_ctx* ctx, double* cost);
+/* factor_cost_vector() for one set (gvibase/GVI-GH-impl.h:147-170), host buffer [K]. */
+gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs);
+/* compute_gradients(): moments of every set, assemble, dprecision = Vddmu - Lambda, solve dmu. */
+gvi_status gvi_ngd_gradients(gvi_ctx* ctx);
+/* onestep_linesearch(step): trial = current + step * (dmu, dprecision); returns its cost. */
+gvi_status gvi_ngd_trial(gvi_ctx* ctx, double step, double* new_cost);
+/* update_proposal: the last trial becomes the current proposal (marginals are reused). */
+gvi_status gvi_ngd_accept(gvi_ctx* ctx);
+/* One iteration with the reference's backtracking rule: step = base; repeat step *= 0.75, accept the
+ * first trial with cost < current cost, give up after max_backtrack + 1 trials.  cost_iter is the
+ * cost at entry; accepted/new_cost/ntrials report the outcome. */
+gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter,
+                        int* accepted, double* new_cost, int* ntrials);
+/* Split forms for sharded factors (one process per GPU): *_local does the rank's factors and leaves
+ * the partial sums in the exchange buffer; the caller all-reduces gvi_ngd_exchange() over the ranks
+ * (RCCL); *_finish does the replicated chain work.  Single GPU: local; finish. */
+gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx);
+gvi_status gvi_ngd_gradients_finish(gvi_ctx* ctx);
+gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step);
+gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost);
+/* which = 0: packed [g | D | U] partial sums (count = T n + (2T-1) n^2) written by gradients_local;
+ * which = 1: the trial's partial sum of factor costs (count = 1) written by trial_local. */
+gvi_status gvi_ngd_exchange(gvi_ctx* ctx, int which, void** dev_ptr, int64_t* count);
+/* Copy state to host; any pointer may be NULL.  mu[T][n], D, U, SigD[T][n][n], SigU[T-1][n][n]. */
+gvi_status gvi_ngd_get_state(gvi_ctx* ctx, double* mu, double* D, double* U, double* SigD, double* SigU);
+/* Last gradients: dmu[T][n], dD, dU (dprecision) and the assembled Vdmu g / Vddmu (VD, VU). */
+gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* dU, double* g,
+                                 double* VD, double* VU);
+
+/* ---- measurement hooks (bench.py): HIP-event time of the last moments / cost kernel launch of a
+ *      set, in milliseconds, measured on the context stream; enable before the launches. ---- */
+gvi_status gvi_profile_enable(gvi_ctx* ctx, int on);
+gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kernel, 1 cost kernel*/, float* ms);
+/* Launch geometry of the set's last moments/cost launch: variant (1 generic, 2 register), chunks. */
+gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk);
+/* Kernel variant override for A/B runs: 0 = auto, 1 = generic LDS kernel, 2 = register kernel. */
+gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GVI_HIP_H */

@@ -356,9 +356,21 @@ def linear_factor_closed_form(mu, Sigma, Lam_k, Lambda, Kinv, Psi_mu_t, constant
 # one expand + one psi evaluation per point (the reference evaluates psi three times); used as
 # the checker at sizes where the per-point python loops above are too slow.
 # --------------------------------------------------------------------------------------------
-def batched_moments(Z, w, mu, Sigma, psi_batch, temperature):
+def batched_moments(Z, w, mu, Sigma, psi_batch, temperature, block=None):
     """mu [K,d], Sigma [K,d,d], psi_batch(X[K,N,d]) -> [K,N].  Returns dict with E_phi, E_xmuphi,
-    E_xxphi (raw GH integrals) and Vdmu, Vddmu (ngd/NGDFactorizedBaseGH.h:53-74)."""
+    E_xxphi (raw GH integrals) and Vdmu, Vddmu (ngd/NGDFactorizedBaseGH.h:53-74).
+    Large batches are processed in blocks of factors to bound memory (psi_batch must then accept a
+    `sel` keyword selecting the factors of the block)."""
+    K = mu.shape[0]
+    if block is None:
+        block = max(1, int(2e8 // max(1, Z.shape[0] * Z.shape[1] * 8)))
+    if K > block:
+        T = np.broadcast_to(np.asarray(temperature, dtype=np.float64).reshape(-1), (K,))
+        parts = []
+        for a in range(0, K, block):
+            sel = slice(a, min(K, a + block))
+            parts.append(batched_moments(Z, w, mu[sel], Sigma[sel], lambda X, s=sel: psi_batch(X, sel=s), T[sel], block=K))
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
     lam, V = np.linalg.eigh(Sigma)
     with np.errstate(invalid="ignore", divide="ignore"):
         S = np.einsum("kij,kj,klj->kil", V, np.sqrt(lam), V)
@@ -369,7 +381,7 @@ def batched_moments(Z, w, mu, Sigma, psi_batch, temperature):
     c = psi * w[None, :]
     E_phi = c.sum(axis=1)
     E_xmuphi = np.einsum("kn,kna->ka", c, Y)
-    E_xxphi = np.einsum("kn,kna,knb->kab", c, Y, Y)
+    E_xxphi = np.einsum("kna,knb->kab", c[:, :, None] * Y, Y)
     T = np.asarray(temperature, dtype=np.float64).reshape(-1)
     Vdmu = np.einsum("kab,kb->ka", Lam, E_xmuphi) / T[:, None]
     Vddmu = (Lam @ E_xxphi @ Lam - Lam * E_phi[:, None, None]) / T[:, None, None]
@@ -380,9 +392,9 @@ def batched_moments(Z, w, mu, Sigma, psi_batch, temperature):
 
 def psi_batch_quad(A, b, sgn=None, half=True):
     """psi(x) = (1/2) sum_r sgn_r (A x + b)_r^2 for a batch: A [K,m,d], b [K,m]."""
-    def f(X):
-        U = np.einsum("kmd,knd->knm", A, X) + b[:, None, :]
-        s = np.ones(A.shape[:2]) if sgn is None else sgn
+    def f(X, sel=slice(None)):
+        U = np.einsum("kmd,knd->knm", A[sel], X) + b[sel][:, None, :]
+        s = np.ones(A.shape[:2])[sel] if sgn is None else sgn[sel]
         val = np.einsum("knm,km->kn", U * U, s)
         return val / 2 if half else val
     return f
@@ -392,21 +404,21 @@ def psi_batch_quad_prior(Phi, Qinv):
     """Batched psi_quad_prior: Phi [K,n,n], Qinv [K,n,n]."""
     n = Phi.shape[1]
 
-    def f(X):
-        R = np.einsum("kij,knj->kni", Phi, X[:, :, :n]) - X[:, :, n:2 * n]
-        return np.einsum("kni,kij,knj->kn", R, Qinv, R) / 2
+    def f(X, sel=slice(None)):
+        R = np.einsum("kij,knj->kni", Phi[sel], X[:, :, :n]) - X[:, :, n:2 * n]
+        return np.einsum("kni,kni->kn", np.einsum("kni,kij->knj", R, Qinv[sel]), R) / 2
     return f
 
 
 def psi_batch_fixed_prior(mu0, Kinv):
-    def f(X):
-        E = X - mu0[:, None, :]
-        return np.einsum("kni,kij,knj->kn", E, Kinv, E)
+    def f(X, sel=slice(None)):
+        E = X - mu0[sel][:, None, :]
+        return np.einsum("kni,kni->kn", np.einsum("kni,kij->knj", E, Kinv[sel]), E)
     return f
 
 
 def psi_batch_range_1d(y=1.2, mu_p=20.0, fb=40.0, sig_r_sq=0.09, sig_p_sq=9.0):
-    def f(X):
+    def f(X, sel=slice(None)):
         x = X[:, :, 0]
         return (x - mu_p) ** 2 / sig_p_sq / 2 + (y - fb / x) ** 2 / sig_r_sq / 2
     return f

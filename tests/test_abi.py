@@ -1,0 +1,93 @@
+"""CPU-only checks of the boundary: the C-ABI library builds/loads, exports every symbol declared in
+include/gvi_hip.h, fails loudly without a GPU, and its HOST-side sparse-grid generator reproduces the
+oracle / golden tables bit-exactly (sigma-point indices)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import gvi_oracle as o
+from gaussianvi_amd import _lib, api, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_lib()
+    return _lib.load()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gvi_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gvi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = _declared()
+    assert len(names) >= 40
+    bound = set(_lib.SIGNATURES) | set(_lib.STRING_GETTERS)
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in gvi_hip.h but not exported"
+        assert name in bound, f"{name} has no ctypes signature"
+    assert bound <= set(names)
+
+
+def test_no_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(api.GviError) as e:
+        api.Context(0)
+    assert e.value.status == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_fp32_reports_unsupported(lib):
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.gvi_ctx_create(0, api.GVI_F32, C.byref(h)) == 3
+
+
+@pytest.mark.parametrize("d,p", [(1, 10), (5, 2), (4, 3), (2, 10), (6, 5)])
+def test_generator_matches_golden_tables_bit_exact(lib, golden_dir, d, p):
+    g = np.load(os.path.join(golden_dir, "spgh_tables.npz"))
+    Z, w, idx = api.spgh_nodes(d, p)
+    assert np.array_equal(Z, g[f"Z_{d}_{p}"])                # bit-exact nodes
+    assert np.array_equal(idx, g[f"idx_{d}_{p}"])            # bit-exact (level, node, sign) indices
+    assert np.allclose(w, g[f"w_{d}_{p}"], rtol=1e-12, atol=1e-15)
+
+
+def test_generator_12_5_headline_table(lib, golden_dir):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_golden import idx_checksum
+    g = np.load(os.path.join(golden_dir, "spgh_tables.npz"))
+    Z, w, idx = api.spgh_nodes(12, 5)
+    assert Z.shape[0] == int(g["N_12_5"]) == api.spgh_count(12, 5) == 17217
+    assert np.array_equal(Z[:8], g["Zhead_12_5"]) and np.array_equal(Z[-8:], g["Ztail_12_5"])
+    assert idx_checksum(idx) == int(g["idxsum_12_5"])
+    assert np.allclose(w[:8], g["whead_12_5"], rtol=1e-11) and np.allclose(w[-8:], g["wtail_12_5"], rtol=1e-11)
+    assert np.isclose(np.abs(w).sum(), float(g["wabs_12_5"]), rtol=1e-12)
+    assert (w < 0).sum() == int(g["wneg_12_5"])
+    assert np.array_equal(np.abs(Z).sum(axis=0), g["Zcolabs_12_5"])
+    # rows ascending lexicographic, no duplicates
+    order = np.lexsort(Z.T[::-1])
+    assert np.array_equal(order, np.arange(len(Z)))
+    assert len(np.unique(Z, axis=0)) == len(Z)
+
+
+@pytest.mark.parametrize("d,p", [(1, 1), (1, 25), (2, 7), (3, 4), (7, 3), (20, 2), (13, 3)])
+def test_generator_matches_oracle_more_shapes(lib, d, p):
+    Z, w, idx = api.spgh_nodes(d, p)
+    Zo, wo, io = o.nwspgr(d, p, True)
+    assert np.array_equal(Z, Zo) and np.array_equal(idx, io)
+    assert np.allclose(w, wo, rtol=1e-11, atol=1e-16)
+    assert abs(w.sum() - 1) < 1e-9
+
+
+def test_generator_rejects_untabulated(lib):
+    with pytest.raises(api.GviError) as e:
+        api.spgh_count(3, 26)
+    assert e.value.status == 4

@@ -1,0 +1,471 @@
+"""GPU parity tests (-m gpu): every call goes through the C ABI (gaussianvi_amd.api -> libgvi_hip.so)
+and is compared with the CPU oracle on identical seeded inputs, against the committed golden
+fixtures, and -- at BASELINE sizes -- through size-independent properties.
+
+Tolerance (BASELINE.json north_star): 1e-6 relative, fp64.  Matrices are compared relative to
+their max-abs entry (Vddmu entries differ by orders of magnitude inside one block); the tolerances
+used here are 10-1000x tighter than the 1e-6 bar and are written at each assert."""
+import os
+
+import numpy as np
+import pytest
+
+import gvi_oracle as o
+from chains import make_chain, oracle_psi_batch
+from gaussianvi_amd import api, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6          # the bar
+TIGHT = 1e-9         # what we actually hold operator-level results to
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def single_set_ctx(kind, d, n, p, K, params, T=None, start=None, temperature=None):
+    ctx = api.Context(0)
+    T = T if T is not None else (2 if d == 2 * n else 1)
+    ctx.chain_set(T, n)
+    start = np.zeros(K, dtype=np.int32) if start is None else start
+    sid = ctx.factors_add(d, p, start, kind, params, temperature)
+    return ctx, sid
+
+
+def quad_params(rng, K, n):
+    Phi = np.stack([np.eye(n) + 0.1 * rng.normal(size=(n, n)) for _ in range(K)])
+    Qh = rng.normal(size=(K, n, n))
+    Qinv = Qh @ np.transpose(Qh, (0, 2, 1)) + 0.5 * np.eye(n)
+    return Phi, Qinv
+
+
+# ------------------------------------------------------------------------------------------
+# a4-a9: moments / costs, every psi kind, both kernel variants
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("n,p,K", [(1, 3, 5), (2, 3, 7), (3, 4, 4), (4, 3, 3), (6, 5, 6)])
+def test_moments_quad_prior_vs_oracle(n, p, K, variant):
+    rng = np.random.default_rng(100 + n)
+    d = 2 * n
+    Phi, Qinv = quad_params(rng, K, n)
+    params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+    temp = rng.uniform(0.5, 5.0, K)
+    ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params, temperature=temp)
+    ctx.set_variant(variant)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.3)
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == variant
+    Z, w = o.nwspgr(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_quad_prior(Phi, Qinv), temp)
+    assert rel(Ephi, r["E_phi"]) < TIGHT
+    assert rel(Vdmu, r["Vdmu"]) < TIGHT
+    assert rel(Vddmu, r["Vddmu"]) < TIGHT * 10
+    assert np.array_equal(Vddmu, np.transpose(Vddmu, (0, 2, 1)))      # exactly symmetric (mirrored upper)
+    cost = ctx.costs(sid, mu, Sigma)
+    assert rel(cost, r["cost"]) < TIGHT
+    E0, E1, E2 = ctx.raw_moments(sid, mu, Sigma)
+    assert rel(E0, r["E_phi"]) < TIGHT and rel(E1, r["E_xmuphi"]) < TIGHT and rel(E2, r["E_xxphi"]) < TIGHT
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("d,p", [(1, 5), (2, 3), (3, 3), (6, 5)])
+def test_moments_fixed_prior_vs_oracle(d, p, variant):
+    rng = np.random.default_rng(200 + d)
+    K = 4
+    mu0 = rng.normal(size=(K, d))
+    Kh = rng.normal(size=(K, d, d))
+    Kinv = Kh @ np.transpose(Kh, (0, 2, 1)) + 0.3 * np.eye(d)
+    params = np.concatenate([mu0, Kinv.reshape(K, -1)], axis=1)
+    ctx, sid = single_set_ctx(api.PSI_FIXED_PRIOR, d, d, p, K, params)
+    ctx.set_variant(variant)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.5)
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    Z, w = o.nwspgr(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_fixed_prior(mu0, Kinv), np.ones(K))
+    assert rel(Ephi, r["E_phi"]) < TIGHT and rel(Vdmu, r["Vdmu"]) < TIGHT and rel(Vddmu, r["Vddmu"]) < TIGHT * 10
+    ctx.close()
+
+
+def test_moments_indefinite_qinv_keeps_signs():
+    """psi = 1/2 r^T Qinv r with an indefinite Qinv (eigen-sign path of gvi_factors_add)."""
+    rng = np.random.default_rng(5)
+    K, n, p = 3, 2, 3
+    Phi = np.stack([np.eye(n)] * K)
+    Qinv = np.stack([np.array([[1.0, 2.0], [2.0, -0.5]])] * K)
+    params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+    ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, 4, n, p, K, params)
+    mu, Sigma = syn.random_marginals(rng, K, 4, 0.3)
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    Z, w = o.nwspgr(4, p)
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_quad_prior(Phi, Qinv), np.ones(K))
+    assert rel(Ephi, r["E_phi"]) < TIGHT and rel(Vddmu, r["Vddmu"]) < TIGHT * 10
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_moments_range_1d_nonlinear(variant):
+    """K3 integrals (tests/test_GH.cpp:134-161) and the 1-D range psi against the oracle."""
+    y = 40.0 / 20.0 + 0.05
+    params = np.array([[y, 20.0, 40.0, 0.09, 9.0]])
+    ctx, sid = single_set_ctx(api.PSI_RANGE_1D, 1, 1, 6, 1, params)
+    ctx.set_variant(variant)
+    E0, E1, _ = ctx.raw_moments(sid, np.array([[20.0]]), np.array([[[9.0]]]))
+    assert abs(E0[0] - 1.1129) <= 1e-4 and abs(E1[0, 0] + 1.2144) <= 1e-4
+    Z, w = o.nwspgr(1, 6)
+    r = o.batched_moments(Z, w, np.array([[20.0]]), np.array([[[9.0]]]), o.psi_batch_range_1d(y), np.ones(1))
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, np.array([[20.0]]), np.array([[[9.0]]]))
+    assert rel(Ephi, r["E_phi"]) < 1e-12 and rel(Vdmu, r["Vdmu"]) < 1e-11 and rel(Vddmu, r["Vddmu"]) < 1e-11
+    ctx.close()
+
+
+def test_k9_golden_fixture(golden_dir):
+    """Committed K9 vectors: device GH moments == oracle GH == closed form (ngd/NGDFactorizedLinear.h:93-129)."""
+    g = np.load(os.path.join(golden_dir, "k9_moments.npz"))
+    for tag, n in [("d4", 2), ("d12", 6)]:
+        d, K = 2 * n, g[f"{tag}_mu"].shape[0]
+        params = np.concatenate([g[f"{tag}_Phi"].reshape(K, -1), g[f"{tag}_Qinv"].reshape(K, -1)], axis=1)
+        ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, int(g[f"{tag}_p"]), K, params, temperature=g[f"{tag}_temp"])
+        Ephi, Vdmu, Vddmu = ctx.moments(sid, g[f"{tag}_mu"], g[f"{tag}_Sigma"])
+        assert rel(Ephi, g[f"{tag}_E_phi"]) < TIGHT and rel(Vdmu, g[f"{tag}_Vdmu"]) < TIGHT
+        assert rel(Vddmu, g[f"{tag}_Vddmu"]) < TIGHT * 10
+        assert rel(Vdmu, g[f"{tag}_cf_Vdmu"]) < 1e-8 and rel(Vddmu, g[f"{tag}_cf_Vddmu"]) < RTOL
+        assert rel(ctx.costs(sid, g[f"{tag}_mu"], g[f"{tag}_Sigma"]), g[f"{tag}_cf_cost"]) < 1e-9
+        ctx.close()
+
+
+def test_host_callback_route_and_sigma_points():
+    """gvi_expand gives the reference's sigma points (symmetric sqrt, [factor][dim][point]); a psi
+    evaluated on the host and reduced on the device equals the all-device path."""
+    rng = np.random.default_rng(9)
+    K, n, p = 3, 2, 3
+    d = 2 * n
+    Phi, Qinv = quad_params(rng, K, n)
+    ctx = api.Context(0)
+    ctx.chain_set(2, n)
+    s_cb = ctx.factors_add(d, p, np.zeros(K, np.int32), api.PSI_HOST_CALLBACK)
+    s_dev = ctx.factors_add(d, p, np.zeros(K, np.int32), api.PSI_QUAD_PRIOR,
+                            np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1))
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.4)
+    X = ctx.expand(s_cb, mu, Sigma)
+    Z, w = o.nwspgr(d, p)
+    for k in range(K):
+        gh = o.SparseGaussHermite(p, d, mu[k], Sigma[k])
+        assert rel(X[k].T, gh.sigmapts()) < 1e-12
+    psi = o.psi_batch_quad_prior(Phi, Qinv)(np.transpose(X, (0, 2, 1)))
+    a = ctx.moments_from_psi(s_cb, mu, Sigma, psi)
+    b = ctx.moments(s_dev, mu, Sigma)
+    for x, y in zip(a, b):
+        assert rel(x, y) < 1e-10
+    with pytest.raises(api.GviError):
+        ctx.moments(s_cb, mu, Sigma)
+    ctx.close()
+
+
+def test_user_table_override_and_empty_edge_cases():
+    rng = np.random.default_rng(3)
+    K, n, p = 2, 1, 3
+    Phi, Qinv = quad_params(rng, K, n)
+    params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+    ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, 2, n, p, K, params)
+    mu, Sigma = syn.random_marginals(rng, K, 2)
+    base = ctx.moments(sid, mu, Sigma)
+    Z, w = o.nwspgr(2, 7)                                  # ragged size (N not a multiple of 64)
+    ctx.factors_set_table(sid, Z, w)
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_quad_prior(Phi, Qinv), np.ones(K))
+    got = ctx.moments(sid, mu, Sigma)
+    assert rel(got[2], r["Vddmu"]) < TIGHT * 10
+    assert rel(got[2], base[2]) < 1e-8                     # both rules are exact for this integrand
+    with pytest.raises(api.GviError):
+        ctx.factors_add(3, 3, np.zeros(1, np.int32), api.PSI_FIXED_PRIOR, np.zeros((1, 12)))   # d not in {n, 2n}
+    with pytest.raises(api.GviError):
+        ctx.factors_add(2, 3, np.array([5], np.int32), api.PSI_QUAD_PRIOR, params[:1])          # start out of range
+    ctx.close()
+
+
+def test_non_psd_covariance_gives_nan_like_reference():
+    """sqrt of a negative eigenvalue is NaN in the reference (quadrature/SparseGaussHermite.h:232-240)."""
+    K, n, p = 1, 1, 3
+    params = np.array([[1.0, 1.0]])
+    ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, 2, n, p, K, params)
+    cost = ctx.costs(sid, np.zeros((1, 2)), np.array([[[1.0, 2.0], [2.0, 1.0]]]))
+    assert np.isnan(cost[0])
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------
+# joint level: assemble, solve, log-det, marginals, gather
+# ------------------------------------------------------------------------------------------
+def _spd_chain(T, n, rng):
+    D = np.zeros((T, n, n)); U = np.zeros((max(T - 1, 0), n, n))
+    for i in range(max(T - 1, 1)):
+        w = 2 * n if T > 1 else n
+        B = rng.normal(size=(w, w))
+        M = B @ B.T / w + 0.3 * np.eye(w)
+        D[i] += M[:n, :n]
+        if T > 1:
+            D[i + 1] += M[n:, n:]; U[i] += M[:n, n:]
+    return D, U
+
+
+@pytest.mark.parametrize("T,n", [(1, 1), (1, 4), (2, 2), (9, 3), (33, 6), (65, 2), (17, 12), (5, 16)])
+def test_bt_ops_vs_oracle(T, n):
+    rng = np.random.default_rng(T * 31 + n)
+    D, U = _spd_chain(T, n, rng)
+    ctx = api.Context(0)
+    ctx.chain_set(T, n)
+    SD, SU = ctx.bt_marginals(D, U)
+    eD, eU = o.inverse_gbp(D, U)
+    assert rel(SD, eD) < TIGHT and (T == 1 or rel(SU, eU) < TIGHT)
+    assert np.isclose(ctx.bt_logdet(D, U), o.logdet_half(o.bt_ldlt_pivots(D, U)), rtol=1e-12)
+    rhs = rng.normal(size=(T, n))
+    assert rel(ctx.bt_solve(D, U, rhs).reshape(-1), o.bt_solve(D, U, rhs.reshape(-1))) < TIGHT
+    if T * n <= 200:     # dense cross-checks incl. the reference's CG
+        A = o.bt_to_dense(D, U)
+        assert rel(ctx.bt_solve(D, U, rhs).reshape(-1), o.cg_eigen(A, rhs.reshape(-1))) < 1e-7
+        tD, tU = o.dense_to_bt(o.inv_sparse_takahashi(A, n), n)
+        assert rel(SD, tD) < TIGHT
+    ctx.close()
+
+
+def test_bt_logdet_nan_when_not_pd_and_solve_indefinite():
+    rng = np.random.default_rng(1)
+    T, n = 6, 2
+    D, U = _spd_chain(T, n, rng)
+    D[3] -= 5.0 * np.eye(n)                               # indefinite
+    ctx = api.Context(0)
+    ctx.chain_set(T, n)
+    assert np.isnan(ctx.bt_logdet(D, U))
+    assert np.isnan(o.logdet_half(o.bt_ldlt_pivots(D, U)))
+    rhs = rng.normal(size=(T, n))
+    x = ctx.bt_solve(D, U, rhs)                           # pivoted block solve still exact
+    assert rel(x.reshape(-1), np.linalg.solve(o.bt_to_dense(D, U), rhs.reshape(-1))) < 1e-9
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c2"])
+def test_assemble_and_gather_vs_oracle(name):
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    rng = np.random.default_rng(17)
+    T, n = ch["T"], ch["n"]
+    Vd = [rng.normal(size=(len(s["start"]), s["d"])) for s in ch["specs"]]
+    Vdd = []
+    for s in ch["specs"]:
+        B = rng.normal(size=(len(s["start"]), s["d"], s["d"]))
+        Vdd.append(B + np.transpose(B, (0, 2, 1)))
+    g, D, U = ctx.bt_assemble(ids, Vd, Vdd)
+    eg, eD, eU = o.bt_assemble(T, n, [(s["start"], a, b) for s, a, b in zip(ch["specs"], Vd, Vdd)])
+    assert np.array_equal(g, eg) and np.array_equal(D, eD) and np.array_equal(U, eU)   # same ordered sums: bit-exact
+    SD, SU = o.inverse_gbp(ch["D0"], ch["U0"])
+    for sid, s in zip(ids, ch["specs"]):
+        mk, Sk = ctx.gather_marginals(sid, ch["mu0"], SD, SU)
+        emk, eSk = o.gather_marginals(ch["mu0"], SD, SU, s["start"], s["d"])
+        assert np.array_equal(mk, emk) and np.array_equal(Sk, eSk)
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------
+# a12-a18: the NGD iteration, device-resident, against the oracle and the golden traces
+# ------------------------------------------------------------------------------------------
+def test_k8_golden_ngd_trace_on_device(golden_dir):
+    """src/1d_example.cpp on the device-resident NGD API reproduces data/1d/*.csv."""
+    csv = lambda nme: np.loadtxt(os.path.join(golden_dir, "ref_1d", nme + ".csv"), delimiter=",").ravel()
+    ctx = api.Context(0)
+    ctx.chain_set(1, 1)
+    sid = ctx.factors_add(1, 10, np.zeros(1, np.int32), api.PSI_RANGE_1D,
+                          np.array([[40.0 / 20.0 - 0.8, 20.0, 40.0, 0.09, 9.0]]), np.ones(1))
+    ctx.ngd_init(np.array([[20.0]]), np.array([[[1.0 / 9.0]]]), np.zeros((0, 1, 1)))
+    mean, prec, cov, cost, fcost = [], [], [], [], []
+    for it in range(10):
+        st = ctx.ngd_get_state()
+        mean.append(st["mu"][0, 0]); prec.append(st["D"][0, 0, 0]); cov.append(st["SigD"][0, 0, 0])
+        fcost.append(ctx.ngd_factor_costs(sid)[0])
+        r = ctx.ngd_step(0.75, 10)
+        cost.append(r["cost_iter"])
+        assert r["accepted"]
+    assert np.abs(np.array(mean) - csv("mean")).max() < 1e-9
+    assert np.abs(np.array(prec) - csv("precision")).max() < 1e-10
+    assert np.abs(np.array(cov) - csv("cov")).max() < 1e-9
+    assert np.abs(np.array(cost) - csv("cost")).max() < 1e-10
+    assert np.abs(np.array(fcost) - csv("factor_costs")).max() < 1e-10
+    ctx.close()
+
+
+def test_k8_costmap_corner_on_device(golden_dir):
+    ref = np.loadtxt(os.path.join(golden_dir, "ref_1d", "costmap.csv"), delimiter=",")
+    ctx = api.Context(0)
+    ctx.chain_set(1, 1)
+    ctx.factors_add(1, 10, np.zeros(1, np.int32), api.PSI_RANGE_1D, np.array([[1.2, 20.0, 40.0, 0.09, 9.0]]))
+    for i, j in [(0, 0), (39, 39), (7, 23), (20, 3)]:
+        ctx.ngd_init(np.array([[18 + 7 * i / 40]]), np.array([[[0.05 + 0.95 * j / 40]]]), np.zeros((0, 1, 1)))
+        assert abs(ctx.ngd_cost() - ref[j, i]) < 1e-10 * abs(ref[j, i])
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c3mini"])
+def test_chain_step_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "chain_step.npz"))
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    assert np.isclose(ctx.ngd_cost(), float(g[f"{name}_cost0"]), rtol=1e-10)
+    ctx.ngd_gradients()
+    gr = ctx.ngd_get_gradients()
+    assert rel(gr["g"], g[f"{name}_g"]) < TIGHT and rel(gr["VD"], g[f"{name}_VD"]) < TIGHT * 10
+    assert rel(gr["VU"], g[f"{name}_VU"]) < TIGHT * 10
+    assert rel(gr["dD"], g[f"{name}_dD"]) < TIGHT * 10 and rel(gr["dU"], g[f"{name}_dU"]) < TIGHT * 10
+    assert rel(gr["dmu"], g[f"{name}_dmu"]) < 1e-7
+    r = ctx.ngd_step(0.55, 10)
+    assert r["accepted"] == bool(g[f"{name}_ok"]) and r["ntrials"] == int(g[f"{name}_ntrials"])
+    assert np.isclose(r["new_cost"], float(g[f"{name}_cost1"]), rtol=1e-9)
+    st = ctx.ngd_get_state()
+    assert rel(st["mu"], g[f"{name}_mu1"]) < 1e-7          # NGD iterate vs CPU: bar is 1e-6
+    assert rel(st["D"], g[f"{name}_D1"]) < 1e-8 and rel(st["U"], g[f"{name}_U1"]) < 1e-8
+    assert rel(st["SigD"], g[f"{name}_SigD1"]) < 1e-8 and rel(st["SigU"], g[f"{name}_SigU1"]) < 1e-8
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,iters", [("c2", 3), ("c3small", 2)])
+def test_ngd_iterations_vs_oracle(name, iters):
+    """BASELINE configs[1] (64-factor d=4 p=3 chain) in full, and a 32-factor slice of the headline
+    d=12 p=5 LTV chain: several NGD iterations, iterate matching the CPU oracle to 1e-6."""
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    chain = o.ChainNGD(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"])
+    for it in range(iters):
+        r = ctx.ngd_step(0.55, 10)
+        ok, cost, ntr = chain.step()
+        assert r["accepted"] == ok and r["ntrials"] == ntr
+        assert np.isclose(r["new_cost"], cost, rtol=1e-9)
+        st = ctx.ngd_get_state()
+        assert rel(st["mu"], chain.mu) < RTOL / 10
+        assert rel(st["D"], chain.D) < RTOL / 10 and rel(st["U"], chain.U) < RTOL / 10
+        assert rel(st["SigD"], chain.SigD) < RTOL / 10
+    ctx.close()
+
+
+def test_linesearch_rejects_nan_and_backtracks():
+    """A huge base step makes the trial precision indefinite: log-det NaN -> rejected -> backtrack
+    (gvibase/GVI-GH-impl.h:92-117 with the NaN rule of section 3.1)."""
+    ch = make_chain("tiny")
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    chain = o.ChainNGD(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"], step_size_base=40.0)
+    r = ctx.ngd_step(40.0, 10)
+    ok, cost, ntr = chain.step()
+    assert r["ntrials"] == ntr and r["accepted"] == ok and ntr > 1
+    c0 = ctx.ngd_cost()
+    ctx.ngd_gradients()
+    assert np.isnan(ctx.ngd_trial(1e6))
+    assert ctx.ngd_cost() == c0                             # rejected trial leaves the proposal untouched
+    ctx.close()
+
+
+def test_temperature_switch():
+    ch = make_chain("tiny")
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    f0 = ctx.ngd_factor_costs(ids[0])
+    ctx.factors_set_temperature(ids[0], np.full(len(f0), 10.0))
+    assert np.allclose(ctx.ngd_factor_costs(ids[0]), f0 / 10.0, rtol=1e-13)
+    ctx.close()
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE full size (headline: 1024 factors, d=12, p=5): size-independent properties
+# ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3():
+    ch = make_chain("c3")
+    ctx, ids = api.context_for_chain(ch)
+    yield ch, ctx, ids
+    ctx.close()
+
+
+def test_c3_full_size_closed_form_and_variants(c3):
+    """All 1024 d=12 p=5 factors: GH (deg 5 >= 3) equals the closed form of NGDFactorizedLinear for
+    every factor; the generic and register kernels agree; a sample of factors matches the oracle."""
+    ch, ctx, ids = c3
+    spec = ch["specs"][0]
+    K, d, n = len(spec["start"]), spec["d"], ch["n"]
+    SD, SU = o.inverse_gbp(ch["D0"], ch["U0"])
+    mk, Sk = o.gather_marginals(ch["mu0"], SD, SU, spec["start"], d)
+    ctx.set_variant(2)
+    Ephi, Vdmu, Vddmu = ctx.moments(ids[0], mk, Sk)
+    ctx.set_variant(1)
+    Ephi1, Vdmu1, Vddmu1 = ctx.moments(ids[0], mk, Sk)
+    ctx.set_variant(0)
+    assert rel(Ephi, Ephi1) < 1e-10 and rel(Vdmu, Vdmu1) < 1e-9
+    for k in range(0, K, 37):
+        assert rel(Vddmu[k], Vddmu1[k]) < 1e-8
+    for k in range(0, K, 41):
+        Lam = np.hstack([-spec["Phi"][k], np.eye(n)])
+        e, vd, vdd = o.linear_factor_closed_form(mk[k], Sk[k], np.linalg.inv(Sk[k]), Lam, spec["Qinv"][k],
+                                                 np.zeros(n), 0.5, 1.0)
+        assert abs(Ephi[k] - e) < 1e-9 * abs(e)
+        assert rel(Vdmu[k], vd) < 1e-7 and rel(Vddmu[k], vdd) < RTOL
+    sel = np.arange(0, K, 128)
+    Z, w = o.nwspgr(d, spec["p"])
+    r = o.batched_moments(Z, w, mk[sel], Sk[sel], o.psi_batch_quad_prior(spec["Phi"][sel], spec["Qinv"][sel]), np.ones(len(sel)))
+    assert rel(Vdmu[sel], r["Vdmu"]) < TIGHT and rel(Vddmu[sel], r["Vddmu"]) < TIGHT * 10
+
+
+def test_c3_full_size_linearity_and_determinism(c3):
+    """E[psi] is linear in the psi parameters (Qinv -> 3 Qinv), permuting factors permutes outputs,
+    and two launches are bit-identical (no atomics, fixed reduction order)."""
+    ch, ctx, ids = c3
+    spec = ch["specs"][0]
+    K, d = len(spec["start"]), spec["d"]
+    rng = np.random.default_rng(2)
+    mk, Sk = syn.random_marginals(rng, K, d, 0.05)
+    a = ctx.moments(ids[0], mk, Sk)
+    b = ctx.moments(ids[0], mk, Sk)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    ctx2 = api.Context(0)
+    ctx2.chain_set(ch["T"], ch["n"])
+    perm = rng.permutation(K)
+    params3 = np.concatenate([spec["Phi"].reshape(K, -1), 3.0 * spec["Qinv"].reshape(K, -1)], axis=1)[perm]
+    s2 = ctx2.factors_add(d, spec["p"], spec["start"][perm], api.PSI_QUAD_PRIOR, params3)
+    c = ctx2.moments(s2, mk[perm], Sk[perm])
+    assert rel(c[0], 3.0 * a[0][perm]) < 1e-10 and rel(c[1], 3.0 * a[1][perm]) < 1e-9
+    ctx2.close()
+
+
+def test_c3_full_size_chain_round_trip(c3):
+    """marginals(Lambda) is the tridiagonal part of Lambda^-1: Lambda * Sigma restricted to the block
+    diagonal is I (checked via the block identities), log-det matches the oracle, solve residual."""
+    ch, ctx, ids = c3
+    D, U, T, n = ch["D0"], ch["U0"], ch["T"], ch["n"]
+    SD, SU = ctx.bt_marginals(D, U)
+    R = np.einsum("tij,tjk->tik", D, SD)
+    R[:-1] += np.einsum("tij,tkj->tik", U, SU)
+    R[1:] += np.einsum("tji,tjk->tik", U, SU)
+    assert np.abs(R - np.eye(n)).max() < 1e-8
+    assert np.isclose(ctx.bt_logdet(D, U), o.logdet_half(o.bt_ldlt_pivots(D, U)), rtol=1e-12)
+    rng = np.random.default_rng(4)
+    rhs = rng.normal(size=(T, n))
+    x = ctx.bt_solve(D, U, rhs)
+    Ax = np.einsum("tij,tj->ti", D, x)
+    Ax[:-1] += np.einsum("tij,tj->ti", U, x[1:])
+    Ax[1:] += np.einsum("tji,tj->ti", U, x[:-1])
+    assert np.abs(Ax - rhs).max() < 1e-8 * np.abs(rhs).max() * max(1.0, np.abs(D).max())
+
+
+def test_c3_full_size_ngd_step_vs_oracle(c3):
+    """One full NGD iteration of the headline chain against the oracle (takes the oracle ~1 min)."""
+    ch, ctx, ids = c3
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    r = ctx.ngd_step(0.55, 10)
+    chain = o.ChainNGD(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"])
+    c0 = chain.cost_value(chain.mu, chain.D, chain.U, chain.SigD, chain.SigU)
+    assert np.isclose(r["cost_iter"], c0, rtol=1e-9)
+    ok, cost, ntr = chain.step()
+    assert r["accepted"] == ok and r["ntrials"] == ntr and np.isclose(r["new_cost"], cost, rtol=1e-9)
+    st = ctx.ngd_get_state()
+    assert rel(st["mu"], chain.mu) < RTOL / 10 and rel(st["D"], chain.D) < RTOL / 10
+    assert rel(st["SigD"], chain.SigD) < RTOL / 10
