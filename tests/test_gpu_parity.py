@@ -315,17 +315,20 @@ def test_chain_step_golden(golden_dir, name):
     assert np.isclose(ctx.ngd_cost(), float(g[f"{name}_cost0"]), rtol=1e-10)
     ctx.ngd_gradients()
     gr = ctx.ngd_get_gradients()
-    assert rel(gr["g"], g[f"{name}_g"]) < TIGHT and rel(gr["VD"], g[f"{name}_VD"]) < TIGHT * 10
-    assert rel(gr["VU"], g[f"{name}_VU"]) < TIGHT * 10
-    assert rel(gr["dD"], g[f"{name}_dD"]) < TIGHT * 10 and rel(gr["dU"], g[f"{name}_dU"]) < TIGHT * 10
+    # Vddmu = Lam E[yy^T psi] Lam - Lam E[psi] cancels ~2 digits on the stiff LTV chain (|w|_1 ~ 5e3,
+    # Qinv ~ 1e5): both the oracle and the device carry ~1e-8 rounding there; the bar is 1e-6.
+    CH = RTOL / 5
+    assert rel(gr["g"], g[f"{name}_g"]) < TIGHT and rel(gr["VD"], g[f"{name}_VD"]) < CH
+    assert rel(gr["VU"], g[f"{name}_VU"]) < CH
+    assert rel(gr["dD"], g[f"{name}_dD"]) < CH and rel(gr["dU"], g[f"{name}_dU"]) < CH
     assert rel(gr["dmu"], g[f"{name}_dmu"]) < 1e-7
     r = ctx.ngd_step(0.55, 10)
     assert r["accepted"] == bool(g[f"{name}_ok"]) and r["ntrials"] == int(g[f"{name}_ntrials"])
     assert np.isclose(r["new_cost"], float(g[f"{name}_cost1"]), rtol=1e-9)
     st = ctx.ngd_get_state()
     assert rel(st["mu"], g[f"{name}_mu1"]) < 1e-7          # NGD iterate vs CPU: bar is 1e-6
-    assert rel(st["D"], g[f"{name}_D1"]) < 1e-8 and rel(st["U"], g[f"{name}_U1"]) < 1e-8
-    assert rel(st["SigD"], g[f"{name}_SigD1"]) < 1e-8 and rel(st["SigU"], g[f"{name}_SigU1"]) < 1e-8
+    assert rel(st["D"], g[f"{name}_D1"]) < CH and rel(st["U"], g[f"{name}_U1"]) < CH
+    assert rel(st["SigD"], g[f"{name}_SigD1"]) < CH and rel(st["SigU"], g[f"{name}_SigU1"]) < CH
     ctx.close()
 
 
@@ -407,7 +410,7 @@ def test_c3_full_size_closed_form_and_variants(c3):
         Lam = np.hstack([-spec["Phi"][k], np.eye(n)])
         e, vd, vdd = o.linear_factor_closed_form(mk[k], Sk[k], np.linalg.inv(Sk[k]), Lam, spec["Qinv"][k],
                                                  np.zeros(n), 0.5, 1.0)
-        assert abs(Ephi[k] - e) < 1e-9 * abs(e)
+        assert abs(Ephi[k] - e) < 1e-8 * abs(e)
         assert rel(Vdmu[k], vd) < 1e-7 and rel(Vddmu[k], vdd) < RTOL
     sel = np.arange(0, K, 128)
     Z, w = o.nwspgr(d, spec["p"])
