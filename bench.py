@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the NGD Gauss-Hermite hot path on MI355X (contract: see the round prompt).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the synthetic
+1024-factor LTV-prior chain, d = 12, sparse-GH p = 5 (N = 17 217 sigma points per factor), T = 1025
+states of size 6, fp64, plus one unary d = 6 measurement factor per state (see
+gaussianvi_amd/synthetic.py for why).  One STEP = one NGD iteration of GVIGH::optimize
+(gvibase/GVI-GH-impl.h:39-118) entirely on the device: moments pass of every factor, ordered
+assemble, block-tridiagonal solve, then line-search trials (axpy, chain factorisation = log-det +
+marginals, gather, cost pass) until the first accepted one.  Inputs are resident in HBM before the
+timed region.  `value` = every psi evaluation executed in the timed region (one per (factor, sigma
+point) per pass, counted once) / wall time, whole job.
+
+N > 1: the factor list is sharded contiguously over the ranks (strong scaling, BASELINE configs[3]);
+the assembled [g | D | U] partials and the trial cost are all-reduced over RCCL; the chain recursions
+are replicated.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_PEAK = 78.6e12        # FLOP/s, AMD public spec sheet (vector = matrix fp64 on MI355X); not in the guide
+
+
+def cpu_baseline(chain, seconds):
+    """Reference-shaped CPU port (oracle/c/gvi_oracle.c: per-factor symmetric sqrt + expand, three
+    Integrate passes with psi re-evaluated through a function pointer, OpenMP over factors) timed on
+    this box's host cores on a bounded sample of the SAME workload: the first 256 prior factors of
+    the chain at their start-state marginals, repeated until ~`seconds` of CPU work."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    import gvi_oracle as o
+    spec = chain["specs"][0]
+    K = min(256, len(spec["start"]))
+    d, n = spec["d"], chain["n"]
+    SD, SU = o.inverse_gbp(chain["D0"], chain["U0"])
+    mk, Sk = o.gather_marginals(chain["mu0"], SD, SU, spec["start"][:K], d)
+    Z, w = o.nwspgr(d, spec["p"])
+    threads = c_oracle.max_threads()
+    out = {}
+    for name, fused in (("reference_style", False), ("fused", True)):
+        c_oracle.moments(Z, w, mk[:8], Sk[:8], spec["kind"], spec["params"][:8], n, fused=fused)   # warm
+        reps, t0 = 0, time.perf_counter()
+        budget = seconds * (0.7 if not fused else 0.3)
+        while True:
+            c_oracle.moments(Z, w, mk, Sk, spec["kind"], spec["params"][:K], n, fused=fused)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget:
+                break
+        out[name] = K * len(w) * reps / el
+    return {"value": out["reference_style"], "unit": "psi-evals/s", "cores": threads, "kind": "port",
+            "sample": f"{K} of the 1024 d=12 p=5 prior factors x 17217 sigma points, full moments pass "
+                      f"(3 Integrate passes, psi x3 per point) repeated for ~{seconds:.0f} s, OpenMP {threads} threads",
+            "fused_single_pass_value": out["fused"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic LDS kernel, 2 register kernel")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from gaussianvi_amd import api, synthetic
+    from gaussianvi_amd.dist import HipEngine, ShardedNGD, shard_chain
+
+    chain = synthetic.make_chain(args.config)
+    local = shard_chain(chain, rank, world)
+    ctx, ids = api.context_for_chain(local, device=local_rank)
+    ctx.set_variant(args.variant)
+    engine = HipEngine(ctx, local_rank)
+    ngd = ShardedNGD(engine, world=world)
+    ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
+    ctx.profile_enable(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    evals_moments = sum(K * N for (K, d, p, N) in ctx.sets)       # local, per pass
+    for _ in range(args.warmup):
+        ngd.step(0.55, 10)
+    barrier()
+    t0 = time.perf_counter()
+    passes, kern_ms, cost_ms, log = 0, [], [], []
+    for _ in range(args.steps):
+        r = ngd.step(0.55, 10)
+        log.append(r)
+        passes += 1 + r["ntrials"]
+        kern_ms.append(ctx.profile_last(ids[0], 0))
+        cost_ms.append(ctx.profile_last(ids[0], 1))
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(passes * evals_moments)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed, total_evals = float(tmax[0]), float(stats[1])
+    else:
+        total_evals = float(stats[1])
+
+    if rank == 0:
+        K0, d0, p0, N0 = ctx.sets[0]
+        geo = ctx.profile_geometry(ids[0])
+        km = float(np.mean(kern_ms)) * 1e-3
+        alg_bytes = K0 * N0 * (d0 + 1) * 8                      # (d+1) s bytes per eval
+        n_half = d0 // 2
+        f_alg = 2 * (d0 * d0 + 2 * n_half * n_half + 2 * n_half + 1 + d0 + d0 * (d0 + 1) // 2)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "sigma-point psi-evals/sec + NGD iters/sec, 1024-factor d=12 p=5 chain",
+            "value": total_evals / elapsed, "unit": "psi-evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "c3: 1024-factor LTV-prior chain, d=12, sparse-GH p=5 (N=17217), T=1025 n=6, "
+                                   "+1025 unary d=6 p=5 factors; one step = one device-resident NGD iteration",
+                       "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
+                       "sharding": f"factors/{world} contiguous, all-reduce [g|D|U] + trial cost (RCCL)" if world > 1 else "none",
+                       "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"]},
+            "ngd_iters_per_s": args.steps / elapsed,
+            "accepted_steps": int(sum(r["accepted"] for r in log)),
+            "trials_per_step": float(np.mean([r["ntrials"] for r in log])),
+            "final_cost": log[-1]["new_cost"],
+            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": K0 * N0 / km,
+                               "cost_kernel_ms": float(np.mean(cost_ms))},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / km / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": alg_bytes / km / HBM_PEAK, "traffic": traffic,
+                         "kernel": "moments_reg_kernel<12, PsiQuad<12,6>, full>" if geo["variant"] == 2 else "moments_generic_kernel",
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "Z (1.65 MB) is L2-resident, so the binding roof is fp64 FMA issue, not HBM: see fp64",
+                         "fp64": {"algorithmic_flop_per_eval": f_alg, "achieved_tflops": f_alg * K0 * N0 / km / 1e12,
+                                  "peak_tflops": FP64_PEAK / 1e12, "frac": f_alg * K0 * N0 / km / FP64_PEAK,
+                                  "peak_source": "AMD MI355X spec sheet (fp64 vector = matrix 78.6 TF); not in the local guide"}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

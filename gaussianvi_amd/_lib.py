@@ -50,6 +50,8 @@ SIGNATURES = {
     "gvi_ngd_step": [C.c_void_p, C.c_double, C.c_int, c_double_p, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int)],
     "gvi_ngd_gradients_local": [C.c_void_p],
     "gvi_ngd_gradients_finish": [C.c_void_p],
+    "gvi_ngd_cost_local": [C.c_void_p],
+    "gvi_ngd_cost_finish": [C.c_void_p, c_double_p],
     "gvi_ngd_trial_local": [C.c_void_p, C.c_double],
     "gvi_ngd_trial_finish": [C.c_void_p, c_double_p],
     "gvi_ngd_exchange": [C.c_void_p, C.c_int, c_void_pp, C.POINTER(C.c_int64)],

@@ -204,6 +204,14 @@ class Context:
     def ngd_gradients_finish(self):
         self._ck(self.lib.gvi_ngd_gradients_finish(self.h))
 
+    def ngd_cost_local(self):
+        self._ck(self.lib.gvi_ngd_cost_local(self.h))
+
+    def ngd_cost_finish(self):
+        v = C.c_double()
+        self._ck(self.lib.gvi_ngd_cost_finish(self.h, C.byref(v)))
+        return v.value
+
     def ngd_trial(self, step):
         v = C.c_double()
         self._ck(self.lib.gvi_ngd_trial(self.h, step, C.byref(v)))

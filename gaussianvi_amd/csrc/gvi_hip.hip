@@ -872,6 +872,18 @@ gvi_status gvi_ngd_cost(gvi_ctx* ctx, double* cost) {
   return GVI_OK;
 }
 
+gvi_status gvi_ngd_cost_local(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  return ngd_cost_local(ctx, ctx->ngd.cur);
+}
+
+gvi_status gvi_ngd_cost_finish(gvi_ctx* ctx, double* cost) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  return ngd_cost_finish(ctx, ctx->ngd.cur, cost);
+}
+
 gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs) {
   GVICK(ngd_check(ctx));
   FactorSet* s = get_set(ctx, set_id);

@@ -157,6 +157,8 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
  * (RCCL); *_finish does the replicated chain work.  Single GPU: local; finish. */
 gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx);
 gvi_status gvi_ngd_gradients_finish(gvi_ctx* ctx);
+gvi_status gvi_ngd_cost_local(gvi_ctx* ctx);                  /* cost_value() at the current proposal, */
+gvi_status gvi_ngd_cost_finish(gvi_ctx* ctx, double* cost);   /* split the same way (exchange 1)        */
 gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step);
 gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost);
 /* which = 0: packed [g | D | U] partial sums (count = T n + (2T-1) n^2) written by gradients_local;
