@@ -56,8 +56,10 @@ struct FactorSet {
   int nchunk = 1;
   int64_t chunk = 0;
   bool use_reg = false;
+  int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   // operator outputs / NGD per-set state
   DevMem mu_k[2], Sigma_k[2], Ephi, cost, Vdmu, Vddmu, raw1, raw2, X, psi_ext;
+  DevMem in_mu, in_Sigma;             // staging of the host-pointer API (never aliases NGD state)
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [moments|cost][start|stop]
   bool ev_set[2] = {false, false};
   ~FactorSet() { for (auto& a : ev) for (auto& e : a) if (e) (void)hipEventDestroy(e); }
@@ -217,7 +219,9 @@ bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t s
 }
 
 // prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
-gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma) {
+gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma, int slot = -1) {
+  if (slot >= 0 && s.prep_slot == slot) return GVI_OK;     // products of this slot are still resident
+  s.prep_slot = slot;
   const int d = s.d, dp = d + (d & 1);
   const size_t lds = (size_t)(4 * d * d + 2 * dp + 3 * d) * 8 + (size_t)dp * 4 + 16;
   hipLaunchKernelGGL(prep_kernel, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
@@ -291,36 +295,77 @@ gvi_status ensure_set_buffers(gvi_ctx* c, FactorSet& s) {
   return GVI_OK;
 }
 
-gvi_status ensure_chain_ws(gvi_ctx* c) {
-  const size_t T = c->T, nn = nn_(c);
-  HIPCK(c, c->Wbuf.ensure(T * nn * 8));
-  HIPCK(c, c->Ibuf.ensure(T * nn * 8));
-  HIPCK(c, c->vbuf.ensure(T * c->n * 8));
-  HIPCK(c, c->hldtmp.ensure(8));
+gvi_status ensure_chain_ws(gvi_ctx* c, BcrWs& w) {
+  const size_t T = c->T, nn = nn_(c), n = c->n;
+  const size_t words = 8 * T * nn + 3 * T * n + T;
+  HIPCK(c, c->Wbuf.ensure(words * 8));
+  HIPCK(c, c->Ibuf.ensure(T * sizeof(int)));
+  double* p = c->Wbuf.d();
+  w.E = p; p += T * nn;  w.GA = p; p += T * nn; w.GB = p; p += T * nn; w.CL = p; p += T * nn;
+  w.CR = p; p += T * nn; w.NU = p; p += T * nn; w.SL = p; p += T * nn; w.SR = p; p += T * nn;
+  w.v = p; p += T * n;   w.yL = p; p += T * n;  w.yR = p; p += T * n;
+  w.logp = p;
+  w.bad = (int*)c->Ibuf.p;
+  return GVI_OK;
+}
+
+int bcr_levels(int T) {
+  int L = 0;
+  while ((1 << L) < T) ++L;
+  return L;
+}
+
+// forward block cyclic reduction of (D, U) [+ rhs]: one launch per level + the root
+gvi_status run_bcr_forward(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale,
+                           bool pivot, bool need_E, BcrWs& w) {
+  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
+  GVICK(ensure_chain_ws(c, w));
+  BcrArgs a;
+  a.T = c->T; a.n = c->n; a.nlevels = bcr_levels(c->T);
+  a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.need_E = need_E ? 1 : 0; a.w = w;
+  const size_t n = c->n, lds = (n * (4 * n + 1) + 2 * n * n) * 8;
+  for (int l = 0; l <= a.nlevels; ++l) {
+    const bool root = l == a.nlevels;
+    a.level = root ? -1 : l;
+    const int cnt = root ? 1 : (int)(((int64_t)c->T + (1 << l) - 1) >> l) / 2;
+    if (cnt < 1) continue;
+    if (pivot) hipLaunchKernelGGL(bcr_forward_kernel<true>, dim3(cnt), dim3(64), lds, c->stream, a);
+    else hipLaunchKernelGGL(bcr_forward_kernel<false>, dim3(cnt), dim3(64), lds, c->stream, a);
+  }
+  HIPCK(c, hipGetLastError());
   return GVI_OK;
 }
 
 // log-det (+ optionally marginals) of the chain (D, U) device arrays
 gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* SigD, double* SigU, double* hld) {
-  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
-  GVICK(ensure_chain_ws(c));
-  FactorArgs a;
-  a.T = c->T; a.n = c->n; a.D = D; a.U = U; a.Wbuf = c->Wbuf.d(); a.Ibuf = c->Ibuf.d();
-  a.SigD = SigD; a.SigU = SigU; a.half_logdet = hld;
-  const size_t n = c->n, lds = (n * 3 * n + 4 * n * n) * 8;
-  hipLaunchKernelGGL(bt_factor_kernel, dim3(1), dim3(64), lds, c->stream, a);
+  BcrWs w;
+  GVICK(run_bcr_forward(c, D, U, nullptr, 1.0, false, SigD != nullptr, w));
+  hipLaunchKernelGGL(bcr_logdet_kernel, dim3(1), dim3(256), 0, c->stream, c->T, w.logp, w.bad, hld);
+  if (SigD) {
+    const int L = bcr_levels(c->T);
+    const size_t lds = (size_t)7 * c->n * c->n * 8;
+    hipLaunchKernelGGL(bcr_back_marginals_kernel, dim3(1), dim3(64), lds, c->stream, c->T, c->n, -1, w, SigD, SigU);
+    for (int l = L - 1; l >= 0; --l) {
+      const int cnt = (int)(((int64_t)c->T + (1 << l) - 1) >> l) / 2;
+      if (cnt < 1) continue;
+      hipLaunchKernelGGL(bcr_back_marginals_kernel, dim3(cnt), dim3(64), lds, c->stream, c->T, c->n, l, w, SigD, SigU);
+    }
+  }
   HIPCK(c, hipGetLastError());
   return GVI_OK;
 }
 
 gvi_status run_bt_solve(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, double* x) {
-  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
-  GVICK(ensure_chain_ws(c));
-  SolveArgs a;
-  a.T = c->T; a.n = c->n; a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale;
-  a.Wbuf = c->Wbuf.d(); a.vbuf = c->vbuf.d(); a.x = x;
-  const size_t n = c->n, lds = (n * (2 * n + 1) + 2 * n * n + 2 * n) * 8;
-  hipLaunchKernelGGL(bt_solve_kernel, dim3(1), dim3(64), lds, c->stream, a);
+  BcrWs w;
+  GVICK(run_bcr_forward(c, D, U, rhs, scale, true, false, w));
+  const int L = bcr_levels(c->T), n = c->n;
+  hipLaunchKernelGGL(bcr_back_solve_kernel, dim3(1), dim3(256), 0, c->stream, c->T, n, -1, w, x);
+  for (int l = L - 1; l >= 0; --l) {
+    const int cnt = (int)(((int64_t)c->T + (1 << l) - 1) >> l) / 2;
+    if (cnt < 1) continue;
+    hipLaunchKernelGGL(bcr_back_solve_kernel, dim3((unsigned)((cnt * n + 255) / 256)), dim3(256), 0, c->stream,
+                       c->T, n, l, w, x);
+  }
   HIPCK(c, hipGetLastError());
   return GVI_OK;
 }
@@ -603,8 +648,10 @@ gvi_status gvi_costs_dev(gvi_ctx* ctx, int set_id, const double* mu, const doubl
 }
 
 static gvi_status upload_pass_inputs(gvi_ctx* ctx, FactorSet* s, const double* mu, const double* Sigma) {
-  GVICK(h2d(ctx, s->mu_k[0].p, mu, (size_t)s->K * s->d * 8));
-  return h2d(ctx, s->Sigma_k[0].p, Sigma, (size_t)s->K * s->d * s->d * 8);
+  HIPCK(ctx, s->in_mu.ensure((size_t)s->K * s->d * 8));
+  HIPCK(ctx, s->in_Sigma.ensure((size_t)s->K * s->d * s->d * 8));
+  GVICK(h2d(ctx, s->in_mu.p, mu, (size_t)s->K * s->d * 8));
+  return h2d(ctx, s->in_Sigma.p, Sigma, (size_t)s->K * s->d * s->d * 8);
 }
 
 gvi_status gvi_moments(gvi_ctx* ctx, int set_id, const double* mu, const double* Sigma, double* Ephi,
@@ -613,7 +660,7 @@ gvi_status gvi_moments(gvi_ctx* ctx, int set_id, const double* mu, const double*
   GVICK(check_pass_args(ctx, s, mu, Sigma));
   HIPCK(ctx, hipSetDevice(ctx->device));
   GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
-  GVICK(gvi_moments_dev(ctx, set_id, s->mu_k[0].d(), s->Sigma_k[0].d(), s->Ephi.d(), s->Vdmu.d(), s->Vddmu.d()));
+  GVICK(gvi_moments_dev(ctx, set_id, s->in_mu.d(), s->in_Sigma.d(), s->Ephi.d(), s->Vdmu.d(), s->Vddmu.d()));
   if (Ephi) GVICK(d2h(ctx, Ephi, s->Ephi.p, (size_t)s->K * 8));
   if (Vdmu) GVICK(d2h(ctx, Vdmu, s->Vdmu.p, (size_t)s->K * s->d * 8));
   if (Vddmu) GVICK(d2h(ctx, Vddmu, s->Vddmu.p, (size_t)s->K * s->d * s->d * 8));
@@ -629,8 +676,8 @@ gvi_status gvi_raw_moments(gvi_ctx* ctx, int set_id, const double* mu, const dou
   GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
   HIPCK(ctx, s->raw1.ensure((size_t)s->K * s->d * 8));
   HIPCK(ctx, s->raw2.ensure((size_t)s->K * s->d * s->d * 8));
-  GVICK(run_prep(ctx, *s, s->mu_k[0].d(), s->Sigma_k[0].d()));
-  GVICK(run_moments(ctx, *s, s->mu_k[0].d(), nullptr, 1));
+  GVICK(run_prep(ctx, *s, s->in_mu.d(), s->in_Sigma.d()));
+  GVICK(run_moments(ctx, *s, s->in_mu.d(), nullptr, 1));
   GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), nullptr, nullptr, nullptr, s->raw1.d(), s->raw2.d()));
   if (E_phi) GVICK(d2h(ctx, E_phi, s->Ephi.p, (size_t)s->K * 8));
   if (E_xmuphi) GVICK(d2h(ctx, E_xmuphi, s->raw1.p, (size_t)s->K * s->d * 8));
@@ -644,7 +691,7 @@ gvi_status gvi_costs(gvi_ctx* ctx, int set_id, const double* mu, const double* S
   if (!cost) return fail(ctx, GVI_ERR_ARG, "cost is NULL");
   HIPCK(ctx, hipSetDevice(ctx->device));
   GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
-  GVICK(gvi_costs_dev(ctx, set_id, s->mu_k[0].d(), s->Sigma_k[0].d(), s->cost.d()));
+  GVICK(gvi_costs_dev(ctx, set_id, s->in_mu.d(), s->in_Sigma.d(), s->cost.d()));
   GVICK(d2h(ctx, cost, s->cost.p, (size_t)s->K * 8));
   return sync(ctx);
 }
@@ -657,9 +704,9 @@ gvi_status gvi_expand(gvi_ctx* ctx, int set_id, const double* mu, const double* 
   GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
   const size_t bytes = (size_t)s->K * s->d * s->table->N * 8;
   HIPCK(ctx, s->X.ensure(bytes));
-  GVICK(run_prep(ctx, *s, s->mu_k[0].d(), s->Sigma_k[0].d()));
+  GVICK(run_prep(ctx, *s, s->in_mu.d(), s->in_Sigma.d()));
   hipLaunchKernelGGL(expand_kernel, dim3((unsigned)((s->table->N + 255) / 256), s->K), dim3(256), 0, ctx->stream,
-                     s->dev(), s->mu_k[0].d(), s->X.d());
+                     s->dev(), s->in_mu.d(), s->X.d());
   HIPCK(ctx, hipGetLastError());
   GVICK(d2h(ctx, X, s->X.p, bytes));
   return sync(ctx);
@@ -675,8 +722,8 @@ gvi_status gvi_moments_from_psi(gvi_ctx* ctx, int set_id, const double* mu, cons
   const size_t bytes = (size_t)s->K * s->table->N * 8;
   HIPCK(ctx, s->psi_ext.ensure(bytes));
   GVICK(h2d(ctx, s->psi_ext.p, psi, bytes));
-  GVICK(run_prep(ctx, *s, s->mu_k[0].d(), s->Sigma_k[0].d()));
-  GVICK(run_moments(ctx, *s, s->mu_k[0].d(), s->psi_ext.d(), 1));
+  GVICK(run_prep(ctx, *s, s->in_mu.d(), s->in_Sigma.d()));
+  GVICK(run_moments(ctx, *s, s->in_mu.d(), s->psi_ext.d(), 1));
   GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), nullptr, s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr));
   if (Ephi) GVICK(d2h(ctx, Ephi, s->Ephi.p, (size_t)s->K * 8));
   if (Vdmu) GVICK(d2h(ctx, Vdmu, s->Vdmu.p, (size_t)s->K * s->d * 8));
@@ -774,9 +821,11 @@ gvi_status gvi_gather_marginals(gvi_ctx* ctx, int set_id, const double* mu, cons
   GVICK(h2d(ctx, dmu, mu, T * n * 8));
   GVICK(h2d(ctx, sD, SigD, T * nn * 8));
   if (T > 1) GVICK(h2d(ctx, sU, SigU, (T - 1) * nn * 8));
-  GVICK(run_gather(ctx, *s, dmu, sD, sU, s->mu_k[0].d(), s->Sigma_k[0].d()));
-  GVICK(d2h(ctx, mu_k, s->mu_k[0].p, (size_t)s->K * s->d * 8));
-  GVICK(d2h(ctx, Sigma_k, s->Sigma_k[0].p, (size_t)s->K * s->d * s->d * 8));
+  HIPCK(ctx, s->in_mu.ensure((size_t)s->K * s->d * 8));
+  HIPCK(ctx, s->in_Sigma.ensure((size_t)s->K * s->d * s->d * 8));
+  GVICK(run_gather(ctx, *s, dmu, sD, sU, s->in_mu.d(), s->in_Sigma.d()));
+  GVICK(d2h(ctx, mu_k, s->in_mu.p, (size_t)s->K * s->d * 8));
+  GVICK(d2h(ctx, Sigma_k, s->in_Sigma.p, (size_t)s->K * s->d * s->d * 8));
   return sync(ctx);
 }
 
@@ -796,7 +845,10 @@ static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
   double* sD = g.Sig[i].d();
   double* sU = sD + T * nn;
   GVICK(run_bt_factor(ctx, D, U, sD, sU, g.hld[i].d()));
-  for (auto& s : ctx->sets) GVICK(run_gather(ctx, *s, g.mu[i].d(), sD, sU, s->mu_k[i].d(), s->Sigma_k[i].d()));
+  for (auto& s : ctx->sets) {
+    if (s->prep_slot == i) s->prep_slot = -1;
+    GVICK(run_gather(ctx, *s, g.mu[i].d(), sD, sU, s->mu_k[i].d(), s->Sigma_k[i].d()));
+  }
   return GVI_OK;
 }
 
@@ -807,7 +859,7 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i) {
   if (ctx->sets.empty()) HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
   for (auto& s : ctx->sets) {
     if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
-    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d()));
+    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i));
     GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0));
     GVICK(run_epilogue(ctx, *s, 0, nullptr, s->cost.d(), nullptr, nullptr, nullptr, nullptr));
     hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, s->K, s->cost.d(), g.exch1.d(), first);
@@ -850,6 +902,7 @@ gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const d
   HIPCK(ctx, g.total.ensure(8));
   for (auto& s : ctx->sets) GVICK(ensure_set_buffers(ctx, *s));
   g.cur = 0; g.have_trial = false;
+  for (auto& s : ctx->sets) s->prep_slot = -1;
   g.cost_valid[0] = g.cost_valid[1] = false;
   GVICK(h2d(ctx, g.mu[0].p, mu, T * n * 8));
   GVICK(h2d(ctx, g.Lam[0].p, D, T * nn * 8));
@@ -907,7 +960,7 @@ gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx) {
   HIPCK(ctx, hipMemsetAsync(eg, 0, (T * n + bt_count(ctx)) * 8, ctx->stream));
   for (auto& s : ctx->sets) {
     if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
-    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d()));
+    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i));
     GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 1));
     GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), s->cost.d(), s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr));
     GVICK(run_scatter(ctx, *s, s->Vdmu.d(), s->Vddmu.d(), eg, eD, eU));

@@ -3,27 +3,42 @@
 //
 // Replaces, per SURVEY.md section 8(a):
 //   a10/a12  local2joint_*_insertion + sparse "+=" (ngd/NGDFactorizedBaseGH.h:91-106, ngd/NGD-GH-impl.h:39-55)
-//   a12      ConjugateGradient solve (ngd/NGD-GH-impl.h:59-60)            -> bt_solve_kernel
-//   a14      SimplicialLDLT log-det (gvibase/GVI-GH-impl.h:192-196)       -> bt_factor_kernel
+//   a12      ConjugateGradient solve (ngd/NGD-GH-impl.h:59-60)            -> bcr_forward + bcr_back_solve
+//   a14      SimplicialLDLT log-det (gvibase/GVI-GH-impl.h:192-196)       -> bcr_forward + bcr_logdet
 //   a16/a17  inv_sparse / inverse_GBP (helpers/EigenWrapper.h:282-381,
-//            gvibase/GVI-GH-GBP-impl.h:246-342)                           -> bt_factor_kernel
+//            gvibase/GVI-GH-GBP-impl.h:246-342)                           -> bcr_forward + bcr_back_marginals
 //   a11      extract_*_from_joint (gvibase/GVIFactorizedBase.h:104-122)   -> gather_kernel
 //
-// Chain recursions (blocks n x n, S_0 = D_0):
-//   forward   Gauss-Jordan on [S_i | I | U_i] -> pivots (= natural-order LDL^T pivots), S_i^-1,
-//             W_i = S_i^-1 U_i;   S_{i+1} = D_{i+1} - U_i^T W_i
-//   backward  Sig_{T-1,T-1} = S_{T-1}^-1;  G = W_i Sig_{i+1,i+1};  Sig_{i,i+1} = -G;
-//             Sig_{ii} = S_i^-1 + G W_i^T          (block form of the Takahashi recursion)
-// One wave walks the chain; blocks live in LDS, the next step's operands are prefetched into
-// registers while the current step computes.  Latency-bound by construction (T dependent steps).
+// Chain algorithm: BLOCK CYCLIC REDUCTION instead of the reference's strictly sequential sweeps
+// (T dependent steps of tiny n x n blocks are latency-bound on a GPU: 5.8 ms per sweep at T = 1025,
+// profiles/r01_a_*).  Level l keeps the nodes that are multiples of s = 2^l and eliminates the odd
+// ones; all eliminations of a level are independent (one wave each), ceil(log2 T) levels.
+//
+//   eliminate e (neighbours a = e - s, b = e + s, couplings Ua = A[a,e], Ub = A[e,b]):
+//     Gauss-Jordan [D_e | I | Ua^T | Ub | y_e] -> [I | E | GA | GB | v]   (E = D_e^-1, GA = E Ua^T, GB = E Ub)
+//     CL[e] = Ua GA   (pending  -=  on D_a)        CR[e] = Ub^T GB  (pending -= on D_b)
+//     NU[e] = -Ua GB  (new coupling A[a,b])        yL[e] = Ua v,  yR[e] = Ub^T v  (pending -= on y_a, y_b)
+//   Pending updates are applied lazily, in fixed order, when a node is itself eliminated:
+//     D_e(eff) = D_e - sum_{l<L} (CR[e - 2^l] + CL[e + 2^l]), so no two waves ever write one block.
+//   back-substitution (solve):   x_e = v - GA x_a - GB x_b
+//   selected inverse (Takahashi recursion on the elimination tree):
+//     Sig[e,a] = -(GA Sig_aa + GB Sig_ba),  Sig[e,b] = -(GA Sig_ab + GB Sig_bb),
+//     Sig_ee = E - Sig[e,a] GA^T - Sig[e,b] GB^T ;  level 0 yields exactly the tridiagonal blocks.
+//   log-det = sum over nodes of the log-pivots of its Gauss-Jordan (no pivoting): every pivot is
+//   positive iff the matrix is positive definite (any symmetric elimination order), so the
+//   reference's "NaN when not PD" rule is preserved; the value is order-independent.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_common.hpp"
+
 namespace gvi {
 
-constexpr int BT_MAX_N = 16;                       // block size limit of the LDS/regs budget
-constexpr int BT_EPL = (3 * BT_MAX_N * BT_MAX_N + 63) / 64;   // elements per lane of an n x 3n tile
+constexpr int BT_MAX_N = 16;                                   // block size limit (LDS / register budget)
+constexpr int BT_EPL = (4 * BT_MAX_N * BT_MAX_N + BT_MAX_N + 63) / 64;   // elements per lane of an n x (4n+1) tile
+constexpr int BT_EPB = (BT_MAX_N * BT_MAX_N + 63) / 64;        // elements per lane of an n x n block
+
 
 // ---- assemble: one thread per output element, ordered gather over the factors of a state ----
 struct ScatterArgs {
@@ -71,17 +86,18 @@ __global__ __launch_bounds__(256) void axpy_kernel(int64_t n, double alpha, cons
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = x[i] + alpha * y[i];
 }
-// out = x - y   (dprecision = Vddmu - Lambda), and optional negation (rhs = -Vdmu)
+// out = x - y   (dprecision = Vddmu - Lambda)
 __global__ __launch_bounds__(256) void sub_kernel(int64_t n, const double* __restrict__ x,
                                                   const double* __restrict__ y, double* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) out[i] = x[i] - (y ? y[i] : 2.0 * x[i]);
+  if (i < n) out[i] = x[i] - y[i];
 }
 
 // ---- Gauss-Jordan on an n x nc tile in LDS by one wave ----
-// Reads for a pivot step are completed into registers before anything is written (barrier between).
-// PIVOT: partial (row) pivoting folded into the reads as a row permutation of the old tile.
-// Returns the product-relevant info through *logsum (sum of log pivots) and *bad (pivot <= 0).
+// Reads of a pivot step complete into registers before anything is written.  PIVOT: partial (row)
+// pivoting folded into the reads as a row permutation of the old tile (used for the possibly
+// indefinite Vddmu solve).  logsum / bad: log-pivots and "pivot <= 0" flag (no-pivot form only
+// meaningful).
 template <bool PIVOT>
 __device__ inline void gauss_jordan(double* Ts, int n, int nc, int lane, double& logsum, int& bad) {
   const int total = n * nc;
@@ -109,294 +125,239 @@ __device__ inline void gauss_jordan(double* Ts, int n, int nc, int lane, double&
         nv[q] = (r == p) ? prc : Ts[rr * nc + c] - Ts[rr * nc + p] * prc;
       }
     }
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int q = 0; q < BT_EPL; ++q) {
       const int e = lane + q * 64;
       if (e < total) Ts[e] = nv[q];
     }
-    __syncthreads();
+    wave_lds_sync();
   }
 }
 
-// ---- chain factorisation: log-det/2 and the tridiagonal blocks of the inverse ----
-struct FactorArgs {
-  int T, n;
-  const double* D;       // [T][n][n]
-  const double* U;       // [T-1][n][n]
-  double* Wbuf;          // [T][n][n] workspace: W_i
-  double* Ibuf;          // [T][n][n] workspace: S_i^-1
-  double* SigD;          // [T][n][n] or null (log-det only)
-  double* SigU;          // [T-1][n][n]
-  double* half_logdet;   // [1]; NaN when not positive definite
+// ---- workspace of one cyclic reduction (all [T][n][n] unless noted) ----
+struct BcrWs {
+  double *E, *GA, *GB, *CL, *CR, *NU, *SL, *SR;
+  double *v, *yL, *yR;     // [T][n]
+  double* logp;            // [T]
+  int* bad;                // [T]
 };
 
-__global__ __launch_bounds__(64) void bt_factor_kernel(FactorArgs a) {
+struct BcrArgs {
+  int T, n, level;         // eliminate nodes (2u+1) 2^level; level < 0: the root node 0 after `nlevels`
+  int nlevels;
+  const double* D;         // [T][n][n]
+  const double* U;         // [T-1][n][n]
+  const double* rhs;       // [T][n] or null
+  double rhs_scale;
+  int need_E;
+  BcrWs w;
+};
+
+// forward elimination of one level: block u -> node e = (2u+1) s, one wave per node
+template <bool PIVOT>
+__global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
   extern __shared__ double sm[];
-  const int n = a.n, nn = n * n, nc = 3 * n, lane = threadIdx.x, T = a.T;
-  double* Ts = sm;                 // [n][3n]  [S | I | U]
-  double* Sn = Ts + n * nc;        // [n][n]   next Schur complement
-  double* Us = Sn + nn;            // [n][n]   U_i
-  double* Sg = Us + nn;            // [n][n]   Sig_{i+1,i+1} (backward)
-  double* Gs = Sg + nn;            // [n][n]
-  constexpr int EPB = (BT_MAX_N * BT_MAX_N + 63) / 64;   // elements per lane of an n x n block
+  const int n = a.n, nn = n * n, lane = threadIdx.x, T = a.T;
+  const bool root = a.level < 0;
+  const int L = root ? a.nlevels : a.level;
+  const int s = root ? 0 : (1 << L);
+  const int e = root ? 0 : (2 * (int)blockIdx.x + 1) * s;
+  const bool has_a = !root;
+  const int b = e + s;
+  const bool has_b = !root && b < T;
+  const bool rhs = a.rhs != nullptr;
+  const int cE = n, cA = a.need_E ? 2 * n : n, cB = cA + n, cY = cB + n;
+  const int nc = cY + (rhs ? 1 : 0);
+  double* Ts = sm;                 // [n][nc]
+  double* Ua = Ts + n * nc;        // [n][n]  A[a,e]
+  double* Ub = Ua + nn;            // [n][n]  A[e,b]
+  // ---- gather the effective diagonal block / rhs and the two couplings ----
+  double de[BT_EPB];
+#pragma unroll
+  for (int q = 0; q < BT_EPB; ++q) {
+    const int el = lane + q * 64;
+    de[q] = el < nn ? a.D[(size_t)e * nn + el] : 0.0;
+  }
+  double ye = (rhs && lane < n) ? a.rhs_scale * a.rhs[(size_t)e * n + lane] : 0.0;
+  for (int l = 0; l < L; ++l) {
+    const int h = 1 << l;
+    const bool left = e - h >= 0, right = e + h < T;
+#pragma unroll
+    for (int q = 0; q < BT_EPB; ++q) {
+      const int el = lane + q * 64;
+      if (el < nn) {
+        if (left) de[q] -= a.w.CR[(size_t)(e - h) * nn + el];
+        if (right) de[q] -= a.w.CL[(size_t)(e + h) * nn + el];
+      }
+    }
+    if (rhs && lane < n) {
+      if (left) ye -= a.w.yR[(size_t)(e - h) * n + lane];
+      if (right) ye -= a.w.yL[(size_t)(e + h) * n + lane];
+    }
+  }
+  const double* pUa = !has_a ? nullptr : (L == 0 ? a.U + (size_t)(e - s) * nn : a.w.NU + (size_t)(e - s / 2) * nn);
+  const double* pUb = !has_b ? nullptr : (L == 0 ? a.U + (size_t)e * nn : a.w.NU + (size_t)(e + s / 2) * nn);
+#pragma unroll
+  for (int q = 0; q < BT_EPB; ++q) {
+    const int el = lane + q * 64;
+    if (el < nn) {
+      const int r = el / n, c = el % n;
+      const double ua = has_a ? pUa[el] : 0.0, ub = has_b ? pUb[el] : 0.0;
+      Ua[el] = ua;
+      Ub[el] = ub;
+      Ts[r * nc + c] = de[q];
+      if (a.need_E) Ts[r * nc + cE + c] = r == c ? 1.0 : 0.0;
+      Ts[c * nc + cA + r] = ua;            // Ua^T
+      Ts[r * nc + cB + c] = ub;
+    }
+  }
+  if (rhs && lane < n) Ts[lane * nc + cY] = ye;
+  wave_lds_sync();
   double logsum = 0.0;
   int bad = 0;
-  double pd[EPB], pu[EPB];
-  for (int q = 0; q < EPB; ++q) { pd[q] = 0.0; pu[q] = 0.0; }
+  gauss_jordan<PIVOT>(Ts, n, nc, lane, logsum, bad);
+  if (lane == 0) { a.w.logp[e] = logsum; a.w.bad[e] = bad; }
+  // ---- store E, GA, GB, v and the pending updates ----
 #pragma unroll
-  for (int q = 0; q < EPB; ++q) {
-    const int e = lane + q * 64;
-    if (e < nn) { Sn[e] = a.D[e]; pu[q] = T > 1 ? a.U[e] : 0.0; }
-  }
-  __syncthreads();
-  for (int i = 0; i < T; ++i) {
-    const bool more = i + 1 < T;
-    // prefetch D_{i+1}, U_{i+1} while this step computes
-    double nd[EPB], nu[EPB];
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      nd[q] = 0.0; nu[q] = 0.0;
-      if (e < nn) {
-        if (more) nd[q] = a.D[(size_t)(i + 1) * nn + e];
-        if (i + 2 < T) nu[q] = a.U[(size_t)(i + 1) * nn + e];
+  for (int q = 0; q < BT_EPB; ++q) {
+    const int el = lane + q * 64;
+    if (el < nn) {
+      const int r = el / n, c = el % n;
+      if (a.need_E) a.w.E[(size_t)e * nn + el] = Ts[r * nc + cE + c];
+      if (has_a) {
+        a.w.GA[(size_t)e * nn + el] = Ts[r * nc + cA + c];
+        double cl = 0.0;
+        for (int k = 0; k < n; ++k) cl += Ua[r * n + k] * Ts[k * nc + cA + c];
+        a.w.CL[(size_t)e * nn + el] = cl;
       }
-    }
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      if (e < nn) {
-        const int r = e / n, c = e % n;
-        Ts[r * nc + c] = Sn[e];
-        Ts[r * nc + n + c] = r == c ? 1.0 : 0.0;
-        Ts[r * nc + 2 * n + c] = pu[q];
-        Us[e] = pu[q];
-      }
-    }
-    __syncthreads();
-    gauss_jordan<false>(Ts, n, nc, lane, logsum, bad);
-    if (a.SigD) {
-#pragma unroll
-      for (int q = 0; q < EPB; ++q) {
-        const int e = lane + q * 64;
-        if (e < nn) {
-          const int r = e / n, c = e % n;
-          a.Ibuf[(size_t)i * nn + e] = Ts[r * nc + n + c];
-          a.Wbuf[(size_t)i * nn + e] = Ts[r * nc + 2 * n + c];
+      if (has_b) {
+        a.w.GB[(size_t)e * nn + el] = Ts[r * nc + cB + c];
+        double cr = 0.0, nu = 0.0;
+        for (int k = 0; k < n; ++k) {
+          cr += Ub[k * n + r] * Ts[k * nc + cB + c];
+          nu += Ua[r * n + k] * Ts[k * nc + cB + c];
         }
+        a.w.CR[(size_t)e * nn + el] = cr;
+        a.w.NU[(size_t)e * nn + el] = -nu;
       }
-    }
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < EPB; ++q) {
-        const int e = lane + q * 64;
-        if (e < nn) {
-          const int r = e / n, c = e % n;
-          double s = nd[q];
-          for (int k = 0; k < n; ++k) s -= Us[k * n + r] * Ts[k * nc + 2 * n + c];
-          Sn[e] = s;
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) pu[q] = nu[q];
-  }
-  if (lane == 0) a.half_logdet[0] = bad ? __builtin_nan("") : 0.5 * logsum;
-  if (!a.SigD) return;
-  // backward: Ts[:, n:2n] still holds S_{T-1}^-1
-#pragma unroll
-  for (int q = 0; q < EPB; ++q) {
-    const int e = lane + q * 64;
-    if (e < nn) {
-      const int r = e / n, c = e % n;
-      const double v = Ts[r * nc + n + c];
-      Sg[e] = v;
-      a.SigD[(size_t)(T - 1) * nn + e] = v;
     }
   }
-  double wv[EPB], iv[EPB];
-#pragma unroll
-  for (int q = 0; q < EPB; ++q) {
-    const int e = lane + q * 64;
-    wv[q] = 0.0; iv[q] = 0.0;
-    if (e < nn && T > 1) { wv[q] = a.Wbuf[(size_t)(T - 2) * nn + e]; iv[q] = a.Ibuf[(size_t)(T - 2) * nn + e]; }
-  }
-  __syncthreads();
-  for (int i = T - 2; i >= 0; --i) {
-    double nw[EPB], ni[EPB];
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      nw[q] = 0.0; ni[q] = 0.0;
-      if (e < nn && i > 0) { nw[q] = a.Wbuf[(size_t)(i - 1) * nn + e]; ni[q] = a.Ibuf[(size_t)(i - 1) * nn + e]; }
+  if (rhs && lane < n) {
+    a.w.v[(size_t)e * n + lane] = Ts[lane * nc + cY];
+    if (has_a) {
+      double yl = 0.0;
+      for (int k = 0; k < n; ++k) yl += Ua[lane * n + k] * Ts[k * nc + cY];
+      a.w.yL[(size_t)e * n + lane] = yl;
     }
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      if (e < nn) Us[e] = wv[q];                 // W_i
+    if (has_b) {
+      double yr = 0.0;
+      for (int k = 0; k < n; ++k) yr += Ub[k * n + lane] * Ts[k * nc + cY];
+      a.w.yR[(size_t)e * n + lane] = yr;
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {              // G = W_i Sig_{i+1,i+1}
-      const int e = lane + q * 64;
-      if (e < nn) {
-        const int r = e / n, c = e % n;
-        double s = 0.0;
-        for (int k = 0; k < n; ++k) s += Us[r * n + k] * Sg[k * n + c];
-        Gs[e] = s;
-        a.SigU[(size_t)i * nn + e] = -s;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {              // Sig_ii = S_i^-1 + G W_i^T
-      const int e = lane + q * 64;
-      if (e < nn) {
-        const int r = e / n, c = e % n;
-        double s = iv[q];
-        for (int k = 0; k < n; ++k) s += Gs[r * n + k] * Us[c * n + k];
-        a.SigD[(size_t)i * nn + e] = s;
-        Sg[e] = s;                               // Sg was last read before the barrier above
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) { wv[q] = nw[q]; iv[q] = ni[q]; }
   }
 }
 
-// ---- chain solve A x = rhs, A = (D, U) symmetric block-tridiagonal (possibly indefinite) ----
-struct SolveArgs {
-  int T, n;
-  const double* D;
-  const double* U;
-  const double* rhs;     // [T][n]
-  double rhs_scale;      // x = A^-1 (rhs_scale * rhs)   (-1 for dmu = Vddmu^-1 (-Vdmu))
-  double* Wbuf;          // [T][n][n] workspace
-  double* vbuf;          // [T][n] workspace
-  double* x;             // [T][n]
-};
+// half_logdet = 1/2 sum_t logp[t]  (fixed-order tree), NaN if any node saw a non-positive pivot
+__global__ __launch_bounds__(256) void bcr_logdet_kernel(int T, const double* __restrict__ logp,
+                                                         const int* __restrict__ bad, double* out) {
+  __shared__ double sh[256];
+  __shared__ int sb[256];
+  double s = 0.0;
+  int bflag = 0;
+  for (int t = threadIdx.x; t < T; t += 256) { s += logp[t]; bflag |= bad[t]; }
+  sh[threadIdx.x] = s; sb[threadIdx.x] = bflag;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) { sh[threadIdx.x] += sh[threadIdx.x + w]; sb[threadIdx.x] |= sb[threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sb[0] ? __builtin_nan("") : 0.5 * sh[0];
+}
 
-__global__ __launch_bounds__(64) void bt_solve_kernel(SolveArgs a) {
+// back-substitution of one level: thread per (node, row)
+__global__ __launch_bounds__(256) void bcr_back_solve_kernel(int T, int n, int level, BcrWs w, double* __restrict__ x) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (level < 0) {                                   // root
+    if (gid < n) x[gid] = w.v[gid];
+    return;
+  }
+  const int s = 1 << level, nn = n * n;
+  const int u = gid / n, r = gid % n;
+  const int e = (2 * u + 1) * s;
+  if (e >= T) return;
+  const int a = e - s, b = e + s;
+  double xe = w.v[(size_t)e * n + r];
+  const double* GA = w.GA + (size_t)e * nn + r * n;
+  for (int k = 0; k < n; ++k) xe -= GA[k] * x[(size_t)a * n + k];
+  if (b < T) {
+    const double* GB = w.GB + (size_t)e * nn + r * n;
+    for (int k = 0; k < n; ++k) xe -= GB[k] * x[(size_t)b * n + k];
+  }
+  x[(size_t)e * n + r] = xe;
+}
+
+// selected-inverse recursion of one level: one wave per eliminated node
+__global__ __launch_bounds__(64) void bcr_back_marginals_kernel(int T, int n, int level, BcrWs w,
+                                                                double* __restrict__ SigD, double* __restrict__ SigU) {
   extern __shared__ double sm[];
-  const int n = a.n, nn = n * n, nc = 2 * n + 1, lane = threadIdx.x, T = a.T;
-  double* Ts = sm;                 // [n][2n+1]  [S | U | y]
-  double* Sn = Ts + n * nc;        // [n][n]
-  double* Us = Sn + nn;            // [n][n]
-  double* yn = Us + nn;            // [n]
-  double* xs = yn + n;             // [n]
-  constexpr int EPB = (BT_MAX_N * BT_MAX_N + 63) / 64;
-  double logsum = 0.0;
-  int bad = 0;
-  double pu[EPB];
-#pragma unroll
-  for (int q = 0; q < EPB; ++q) {
-    const int e = lane + q * 64;
-    pu[q] = 0.0;
-    if (e < nn) { Sn[e] = a.D[e]; pu[q] = T > 1 ? a.U[e] : 0.0; }
+  const int nn = n * n, lane = threadIdx.x;
+  if (level < 0) {                                   // root: Sig_00 = E_0
+    for (int el = lane; el < nn; el += 64) SigD[el] = w.E[el];
+    return;
   }
-  if (lane < n) yn[lane] = a.rhs_scale * a.rhs[lane];
-  __syncthreads();
-  for (int i = 0; i < T; ++i) {
-    const bool more = i + 1 < T;
-    double nd[EPB], nu[EPB], nr = 0.0;
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      nd[q] = 0.0; nu[q] = 0.0;
-      if (e < nn) {
-        if (more) nd[q] = a.D[(size_t)(i + 1) * nn + e];
-        if (i + 2 < T) nu[q] = a.U[(size_t)(i + 1) * nn + e];
-      }
+  const int s = 1 << level;
+  const int e = (2 * (int)blockIdx.x + 1) * s;
+  const int a = e - s, b = e + s;
+  const bool has_b = b < T;
+  double* GA = sm;            // [n][n]
+  double* GB = GA + nn;
+  double* Saa = GB + nn;
+  double* Sbb = Saa + nn;
+  double* Sab = Sbb + nn;     // Sig[a,b]
+  double* SLs = Sab + nn;     // Sig[e,a]
+  double* SRs = SLs + nn;     // Sig[e,b]
+  // Sig[a,b]: a, b are adjacent at level+1; the odd one of the pair was eliminated there
+  const bool a_odd = has_b && (((a / (2 * s)) & 1) != 0);
+  for (int el = lane; el < nn; el += 64) {
+    const int r = el / n, c = el % n;
+    GA[el] = w.GA[(size_t)e * nn + el];
+    Saa[el] = SigD[(size_t)a * nn + el];
+    if (has_b) {
+      GB[el] = w.GB[(size_t)e * nn + el];
+      Sbb[el] = SigD[(size_t)b * nn + el];
+      Sab[el] = a_odd ? w.SR[(size_t)a * nn + el] : w.SL[(size_t)b * nn + c * n + r];
     }
-    if (more && lane < n) nr = a.rhs_scale * a.rhs[(size_t)(i + 1) * n + lane];
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      if (e < nn) {
-        const int r = e / n, c = e % n;
-        Ts[r * nc + c] = Sn[e];
-        Ts[r * nc + n + c] = pu[q];
-        Us[e] = pu[q];
-      }
-    }
-    if (lane < n) Ts[lane * nc + 2 * n] = yn[lane];
-    __syncthreads();
-    gauss_jordan<true>(Ts, n, nc, lane, logsum, bad);
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      if (e < nn) {
-        const int r = e / n, c = e % n;
-        a.Wbuf[(size_t)i * nn + e] = Ts[r * nc + n + c];
-      }
-    }
-    if (lane < n) a.vbuf[(size_t)i * n + lane] = Ts[lane * nc + 2 * n];
-    if (more) {
-#pragma unroll
-      for (int q = 0; q < EPB; ++q) {
-        const int e = lane + q * 64;
-        if (e < nn) {
-          const int r = e / n, c = e % n;
-          double s = nd[q];
-          for (int k = 0; k < n; ++k) s -= Us[k * n + r] * Ts[k * nc + n + c];
-          Sn[e] = s;
-        }
-      }
-      if (lane < n) {
-        double s = nr;
-        for (int k = 0; k < n; ++k) s -= Us[k * n + lane] * Ts[k * nc + 2 * n];
-        yn[lane] = s;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) pu[q] = nu[q];
   }
-  // backward: x_{T-1} = v_{T-1};  x_i = v_i - W_i x_{i+1}
-  if (lane < n) {
-    const double v = Ts[lane * nc + 2 * n];
-    xs[lane] = v;
-    a.x[(size_t)(T - 1) * n + lane] = v;
+  wave_lds_sync();
+  for (int el = lane; el < nn; el += 64) {
+    const int r = el / n, c = el % n;
+    double sl = 0.0, sr = 0.0;
+    for (int k = 0; k < n; ++k) {
+      sl += GA[r * n + k] * Saa[k * n + c];
+      if (has_b) {
+        sl += GB[r * n + k] * Sab[c * n + k];        // Sig_ba[k][c] = Sig_ab[c][k]
+        sr += GA[r * n + k] * Sab[k * n + c] + GB[r * n + k] * Sbb[k * n + c];
+      }
+    }
+    SLs[el] = -sl;
+    SRs[el] = -sr;
+    w.SL[(size_t)e * nn + el] = -sl;
+    if (has_b) w.SR[(size_t)e * nn + el] = -sr;
   }
-  double wv[EPB], vv = 0.0;
-#pragma unroll
-  for (int q = 0; q < EPB; ++q) {
-    const int e = lane + q * 64;
-    wv[q] = 0.0;
-    if (e < nn && T > 1) wv[q] = a.Wbuf[(size_t)(T - 2) * nn + e];
-  }
-  if (lane < n && T > 1) vv = a.vbuf[(size_t)(T - 2) * n + lane];
-  __syncthreads();
-  for (int i = T - 2; i >= 0; --i) {
-    double nw[EPB], nv = 0.0;
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      nw[q] = 0.0;
-      if (e < nn && i > 0) nw[q] = a.Wbuf[(size_t)(i - 1) * nn + e];
+  wave_lds_sync();
+  for (int el = lane; el < nn; el += 64) {
+    const int r = el / n, c = el % n;
+    double see = w.E[(size_t)e * nn + el];
+    for (int k = 0; k < n; ++k) {
+      see -= SLs[r * n + k] * GA[c * n + k];
+      if (has_b) see -= SRs[r * n + k] * GB[c * n + k];
     }
-    if (lane < n && i > 0) nv = a.vbuf[(size_t)(i - 1) * n + lane];
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      const int e = lane + q * 64;
-      if (e < nn) Us[e] = wv[q];
+    SigD[(size_t)e * nn + el] = see;
+    if (level == 0) {                                 // tridiagonal blocks of the original chain
+      SigU[(size_t)a * nn + c * n + r] = SLs[el];     // Sig[a,e] = Sig[e,a]^T
+      if (has_b) SigU[(size_t)e * nn + el] = SRs[el];
     }
-    __syncthreads();
-    double xi = 0.0;
-    if (lane < n) {
-      xi = vv;
-      for (int k = 0; k < n; ++k) xi -= Us[lane * n + k] * xs[k];
-      a.x[(size_t)i * n + lane] = xi;
-    }
-    __syncthreads();
-    if (lane < n) xs[lane] = xi;
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) wv[q] = nw[q];
-    vv = nv;
-    __syncthreads();
   }
 }
 

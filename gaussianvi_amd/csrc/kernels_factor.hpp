@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_common.hpp"
+
 namespace gvi {
 
 enum { KIND_RANGE_1D = 0, KIND_QUAD_PRIOR = 1, KIND_FIXED_PRIOR = 2, KIND_HOST_CALLBACK = 3 };
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
     A0[e] = i >= j ? Sg[i * d + j] : Sg[j * d + i];   // lower triangle, like SelfAdjointEigenSolver
     V0[e] = i == j ? 1.0 : 0.0;
   }
-  __syncthreads();
+  wave_lds_sync();
   double* A = A0; double* An = A1; double* V = V0; double* Vn = V1;
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0, dg = 0.0;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
         al[p] = c; be[p] = -s; pa[p] = valid ? q : p;
         al[q] = c; be[q] = s;  pa[q] = valid ? p : q;
       }
-      __syncthreads();
+      wave_lds_sync();
       for (int e = lane; e < dd; e += 64) {
         const int i = e / d, j = e % d;
         const int pi = pa[i], pj = pa[j];
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
         An[e] = ai * (aj * A[i * d + j] + bj * A[i * d + pj]) + bi * (aj * A[pi * d + j] + bj * A[pi * d + pj]);
         Vn[e] = aj * V[i * d + j] + bj * V[i * d + pj];
       }
-      __syncthreads();
+      wave_lds_sync();
       double* t = A; A = An; An = t;
       t = V; V = Vn; Vn = t;
     }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
     lam[d + lane] = 1.0 / sqrt(l);
     lam[2 * d + lane] = 1.0 / l;
   }
-  __syncthreads();
+  wave_lds_sync();
   // S, S^-1, Lam = V f(lambda) V^T; S is also kept in LDS (An) for H = A_k S
   for (int e = lane; e < dd; e += 64) {
     const int i = e / d, j = e % d;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
     f.Sinv[(size_t)k * dd + e] = s1;
     f.Lam[(size_t)k * dd + e] = s2;
   }
-  __syncthreads();
+  wave_lds_sync();
   if (f.m > 0) {
     const int m = f.m;
     const double* Ak = f.A + (size_t)k * m * d;
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
     for (int c = 0; c < a.nchunk; ++c) s += P[(size_t)c * npo + j];   // fixed order: deterministic
     Ms[j] = s;
   }
-  __syncthreads();
+  wave_lds_sync();
   const double m0 = Ms[0];
   const double Tk = f.temperature[k];
   if (lane == 0) {
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
     const int i = e / d, j = e % d;
     M2[e] = i <= j ? Ms[pair_index(d, i, j)] : Ms[pair_index(d, j, i)];
   }
-  __syncthreads();
+  wave_lds_sync();
   const double* Sinv = f.Sinv + (size_t)k * dd;
   const double* Lam = f.Lam + (size_t)k * dd;
   const double* S = f.S + (size_t)k * dd;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
       for (int c = 0; c < d; ++c) s += Sinv[i * d + c] * M2[c * d + j];
       Tm[e] = s;
     }
-    __syncthreads();
+    wave_lds_sync();
     for (int e = lane; e < dd; e += 64) {
       const int i = e / d, j = e % d;
       if (i <= j) {           // upper triangle, mirrored (ngd/NGDFactorizedBaseGH.h:71-72)
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
         a.Vddmu[(size_t)k * dd + j * d + i] = v;
       }
     }
-    __syncthreads();
+    wave_lds_sync();
   }
   if (a.E_xmuphi) {
     for (int i = lane; i < d; i += 64) {
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
       for (int c = 0; c < d; ++c) s += S[i * d + c] * M2[c * d + j];
       Tm[e] = s;
     }
-    __syncthreads();
+    wave_lds_sync();
     for (int e = lane; e < dd; e += 64) {
       const int i = e / d, j = e % d;
       double s = 0.0;
