@@ -92,7 +92,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_pg = world > 1 or "RANK" in os.environ
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -105,11 +106,12 @@ def main():
     ctx.set_variant(args.variant)
     engine = HipEngine(ctx, local_rank)
     ngd = ShardedNGD(engine, world=world)
+    ngd.group_forced = use_pg and world == 1
     ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
     ctx.profile_enable(True)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -181,7 +183,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -224,7 +224,10 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
   s.prep_slot = slot;
   const int d = s.d, dp = d + (d & 1);
   const size_t lds = (size_t)(4 * d * d + 2 * dp + 3 * d) * 8 + (size_t)dp * 4 + 16;
-  hipLaunchKernelGGL(prep_kernel, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
+  if (d <= 8) hipLaunchKernelGGL(prep_kernel<1>, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
+  else if (d <= 16) hipLaunchKernelGGL(prep_kernel<4>, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
+  else if (d <= 32) hipLaunchKernelGGL(prep_kernel<16>, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
+  else return fail(c, GVI_ERR_UNSUPPORTED, "factor dimension > 32");
   HIPCK(c, hipGetLastError());
   return GVI_OK;
 }
@@ -315,41 +318,76 @@ int bcr_levels(int T) {
   return L;
 }
 
-// forward block cyclic reduction of (D, U) [+ rhs]: one launch per level + the root
-gvi_status run_bcr_forward(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale,
-                           bool pivot, bool need_E, BcrWs& w) {
-  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
-  GVICK(ensure_chain_ws(c, w));
-  BcrArgs a;
-  a.T = c->T; a.n = c->n; a.nlevels = bcr_levels(c->T);
-  a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.need_E = need_E ? 1 : 0; a.w = w;
-  const size_t n = c->n, lds = (n * (4 * n + 1) + 2 * n * n) * 8;
-  for (int l = 0; l <= a.nlevels; ++l) {
-    const bool root = l == a.nlevels;
-    a.level = root ? -1 : l;
-    const int cnt = root ? 1 : (int)(((int64_t)c->T + (1 << l) - 1) >> l) / 2;
-    if (cnt < 1) continue;
-    if (pivot) hipLaunchKernelGGL(bcr_forward_kernel<true>, dim3(cnt), dim3(64), lds, c->stream, a);
-    else hipLaunchKernelGGL(bcr_forward_kernel<false>, dim3(cnt), dim3(64), lds, c->stream, a);
+struct BcrPlan { int nlevels, tail_from, waves; };
+BcrPlan bcr_plan(const gvi_ctx* c) {
+  BcrPlan p;
+  p.nlevels = bcr_levels(c->T);
+  p.waves = c->n <= 12 ? BCR_TAIL_WAVES_MAX : 8;
+  p.tail_from = p.nlevels;
+  for (int l = 0; l < p.nlevels; ++l)
+    if (bcr_count(c->T, l) <= p.waves) { p.tail_from = l; break; }
+  return p;
+}
+
+template <bool PIVOT, int NMAX>
+gvi_status launch_bcr_forward(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
+  const size_t unit = (size_t)bcr_unit_lds_doubles(c->n) * 8;
+  for (int l = 0; l < pl.tail_from; ++l) {
+    a.level = l;
+    hipLaunchKernelGGL((bcr_forward_kernel<PIVOT, NMAX>), dim3(bcr_count(c->T, l)), dim3(64), unit, c->stream, a);
   }
+  a.tail_from = pl.tail_from;
+  const size_t lds = unit * pl.waves;
+  static bool attr = false;
+  if (!attr) {
+    HIPCK(c, hipFuncSetAttribute((const void*)bcr_forward_tail_kernel<PIVOT, NMAX>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL((bcr_forward_tail_kernel<PIVOT, NMAX>), dim3(1), dim3(64 * pl.waves), lds, c->stream, a);
   HIPCK(c, hipGetLastError());
   return GVI_OK;
+}
+
+template <bool PIVOT>
+gvi_status launch_bcr_forward_n(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
+  if (c->n <= 6) return launch_bcr_forward<PIVOT, 6>(c, a, pl);
+  if (c->n <= 8) return launch_bcr_forward<PIVOT, 8>(c, a, pl);
+  if (c->n <= 12) return launch_bcr_forward<PIVOT, 12>(c, a, pl);
+  return launch_bcr_forward<PIVOT, 16>(c, a, pl);
+}
+
+// forward block cyclic reduction of (D, U) [+ rhs]: one launch per wide level + one for the tail
+gvi_status run_bcr_forward(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale,
+                           bool pivot, bool need_E, BcrWs& w, BcrPlan& pl) {
+  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
+  GVICK(ensure_chain_ws(c, w));
+  pl = bcr_plan(c);
+  BcrArgs a;
+  a.T = c->T; a.n = c->n; a.nlevels = pl.nlevels; a.level = 0; a.tail_from = pl.tail_from;
+  a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.need_E = need_E ? 1 : 0; a.w = w;
+  return pivot ? launch_bcr_forward_n<true>(c, a, pl) : launch_bcr_forward_n<false>(c, a, pl);
 }
 
 // log-det (+ optionally marginals) of the chain (D, U) device arrays
 gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* SigD, double* SigU, double* hld) {
   BcrWs w;
-  GVICK(run_bcr_forward(c, D, U, nullptr, 1.0, false, SigD != nullptr, w));
+  BcrPlan pl;
+  GVICK(run_bcr_forward(c, D, U, nullptr, 1.0, false, SigD != nullptr, w, pl));
   hipLaunchKernelGGL(bcr_logdet_kernel, dim3(1), dim3(256), 0, c->stream, c->T, w.logp, w.bad, hld);
   if (SigD) {
-    const int L = bcr_levels(c->T);
-    const size_t lds = (size_t)7 * c->n * c->n * 8;
-    hipLaunchKernelGGL(bcr_back_marginals_kernel, dim3(1), dim3(64), lds, c->stream, c->T, c->n, -1, w, SigD, SigU);
-    for (int l = L - 1; l >= 0; --l) {
-      const int cnt = (int)(((int64_t)c->T + (1 << l) - 1) >> l) / 2;
-      if (cnt < 1) continue;
-      hipLaunchKernelGGL(bcr_back_marginals_kernel, dim3(cnt), dim3(64), lds, c->stream, c->T, c->n, l, w, SigD, SigU);
+    const size_t unit = (size_t)7 * c->n * c->n * 8;
+    static bool attr = false;
+    if (!attr) {
+      HIPCK(c, hipFuncSetAttribute((const void*)bcr_back_marginals_head_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
     }
+    hipLaunchKernelGGL(bcr_back_marginals_head_kernel, dim3(1), dim3(64 * pl.waves), unit * pl.waves, c->stream,
+                       c->T, c->n, pl.nlevels, pl.tail_from, w, SigD, SigU);
+    for (int l = pl.tail_from - 1; l >= 0; --l)
+      hipLaunchKernelGGL(bcr_back_marginals_kernel, dim3(bcr_count(c->T, l)), dim3(64), unit, c->stream, c->T, c->n,
+                         l, w, SigD, SigU);
   }
   HIPCK(c, hipGetLastError());
   return GVI_OK;
@@ -357,12 +395,13 @@ gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* S
 
 gvi_status run_bt_solve(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, double* x) {
   BcrWs w;
-  GVICK(run_bcr_forward(c, D, U, rhs, scale, true, false, w));
-  const int L = bcr_levels(c->T), n = c->n;
-  hipLaunchKernelGGL(bcr_back_solve_kernel, dim3(1), dim3(256), 0, c->stream, c->T, n, -1, w, x);
-  for (int l = L - 1; l >= 0; --l) {
-    const int cnt = (int)(((int64_t)c->T + (1 << l) - 1) >> l) / 2;
-    if (cnt < 1) continue;
+  BcrPlan pl;
+  GVICK(run_bcr_forward(c, D, U, rhs, scale, true, false, w, pl));
+  const int n = c->n;
+  hipLaunchKernelGGL(bcr_back_solve_head_kernel, dim3(1), dim3(1024), 0, c->stream, c->T, n, pl.nlevels, pl.tail_from,
+                     w, x);
+  for (int l = pl.tail_from - 1; l >= 0; --l) {
+    const int cnt = bcr_count(c->T, l);
     hipLaunchKernelGGL(bcr_back_solve_kernel, dim3((unsigned)((cnt * n + 255) / 256)), dim3(256), 0, c->stream,
                        c->T, n, l, w, x);
   }

@@ -36,9 +36,12 @@
 namespace gvi {
 
 constexpr int BT_MAX_N = 16;                                   // block size limit (LDS / register budget)
-constexpr int BT_EPL = (4 * BT_MAX_N * BT_MAX_N + BT_MAX_N + 63) / 64;   // elements per lane of an n x (4n+1) tile
-constexpr int BT_EPB = (BT_MAX_N * BT_MAX_N + 63) / 64;        // elements per lane of an n x n block
-
+// per-lane element counts of an n x (4n+1) tile / an n x n block for n <= NMAX (kernels are
+// instantiated for NMAX in {6, 8, 12, 16} so the unrolled per-lane loops stay short)
+__host__ __device__ constexpr int bt_epl(int nmax) { return (nmax * (4 * nmax + 1) + 63) / 64; }
+__host__ __device__ constexpr int bt_epb(int nmax) { return (nmax * nmax + 63) / 64; }
+__host__ __device__ inline int bcr_unit_lds_doubles(int n) { return n * (4 * n + 1) + 2 * n * n + n; }
+constexpr int BCR_TAIL_WAVES_MAX = 16;
 
 // ---- assemble: one thread per output element, ordered gather over the factors of a state ----
 struct ScatterArgs {
@@ -94,13 +97,13 @@ __global__ __launch_bounds__(256) void sub_kernel(int64_t n, const double* __res
 }
 
 // ---- Gauss-Jordan on an n x nc tile in LDS by one wave ----
+// Each lane owns the elements e = lane + 64 q; their (row, col) are computed once (er < 0: none).
 // Reads of a pivot step complete into registers before anything is written.  PIVOT: partial (row)
-// pivoting folded into the reads as a row permutation of the old tile (used for the possibly
-// indefinite Vddmu solve).  logsum / bad: log-pivots and "pivot <= 0" flag (no-pivot form only
-// meaningful).
-template <bool PIVOT>
-__device__ inline void gauss_jordan(double* Ts, int n, int nc, int lane, double& logsum, int& bad) {
-  const int total = n * nc;
+// pivoting folded into the reads as a row permutation of the old tile (for the possibly indefinite
+// Vddmu solve).  The pivots are parked in pv[] (LDS) so their logs are taken once, in parallel.
+template <bool PIVOT, int EPL>
+__device__ inline void gauss_jordan(double* Ts, int n, int nc, const int (&er)[EPL], const int (&ec)[EPL],
+                                    double* pv, int lane, int& bad) {
   for (int p = 0; p < n; ++p) {
     int rs = p;
     if (PIVOT) {
@@ -112,14 +115,13 @@ __device__ inline void gauss_jordan(double* Ts, int n, int nc, int lane, double&
     }
     const double piv = Ts[rs * nc + p];
     if (!(piv > 0.0)) bad = 1;
-    logsum += log(piv);
+    if (lane == 0) pv[p] = piv;
     const double ipiv = 1.0 / piv;
-    double nv[BT_EPL];
+    double nv[EPL];
 #pragma unroll
-    for (int q = 0; q < BT_EPL; ++q) {
-      const int e = lane + q * 64;
-      if (e < total) {
-        const int r = e / nc, c = e % nc;
+    for (int q = 0; q < EPL; ++q) {
+      if (er[q] >= 0) {
+        const int r = er[q], c = ec[q];
         const int rr = (r == p) ? rs : ((r == rs) ? p : r);     // row swap p <-> rs
         const double prc = Ts[rs * nc + c] * ipiv;              // scaled pivot row
         nv[q] = (r == p) ? prc : Ts[rr * nc + c] - Ts[rr * nc + p] * prc;
@@ -127,10 +129,8 @@ __device__ inline void gauss_jordan(double* Ts, int n, int nc, int lane, double&
     }
     wave_lds_sync();
 #pragma unroll
-    for (int q = 0; q < BT_EPL; ++q) {
-      const int e = lane + q * 64;
-      if (e < total) Ts[e] = nv[q];
-    }
+    for (int q = 0; q < EPL; ++q)
+      if (er[q] >= 0) Ts[er[q] * nc + ec[q]] = nv[q];
     wave_lds_sync();
   }
 }
@@ -144,7 +144,9 @@ struct BcrWs {
 };
 
 struct BcrArgs {
-  int T, n, level;         // eliminate nodes (2u+1) 2^level; level < 0: the root node 0 after `nlevels`
+  int T, n;
+  int level;               // per-level kernel: eliminate nodes (2u+1) 2^level
+  int tail_from;           // tail kernel: levels tail_from .. nlevels-1, then the root, in one workgroup
   int nlevels;
   const double* D;         // [T][n][n]
   const double* U;         // [T-1][n][n]
@@ -154,15 +156,15 @@ struct BcrArgs {
   BcrWs w;
 };
 
-// forward elimination of one level: block u -> node e = (2u+1) s, one wave per node
-template <bool PIVOT>
-__global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
-  extern __shared__ double sm[];
-  const int n = a.n, nn = n * n, lane = threadIdx.x, T = a.T;
-  const bool root = a.level < 0;
-  const int L = root ? a.nlevels : a.level;
+// number of nodes eliminated at level l
+__host__ __device__ inline int bcr_count(int T, int l) { return (int)((((int64_t)T + (1 << l) - 1) >> l) / 2); }
+
+// Forward elimination of ONE node by one wave.  L = its level (root: L = nlevels, e = 0).
+template <bool PIVOT, int NMAX>
+__device__ inline void bcr_eliminate(const BcrArgs& a, int L, int e, bool root, int lane, double* sm) {
+  constexpr int EPL = bt_epl(NMAX), EPB = bt_epb(NMAX);
+  const int n = a.n, nn = n * n, T = a.T;
   const int s = root ? 0 : (1 << L);
-  const int e = root ? 0 : (2 * (int)blockIdx.x + 1) * s;
   const bool has_a = !root;
   const int b = e + s;
   const bool has_b = !root && b < T;
@@ -170,23 +172,35 @@ __global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
   const int cE = n, cA = a.need_E ? 2 * n : n, cB = cA + n, cY = cB + n;
   const int nc = cY + (rhs ? 1 : 0);
   double* Ts = sm;                 // [n][nc]
-  double* Ua = Ts + n * nc;        // [n][n]  A[a,e]
+  double* Ua = Ts + n * (4 * n + 1);   // [n][n]  A[a,e]
   double* Ub = Ua + nn;            // [n][n]  A[e,b]
-  // ---- gather the effective diagonal block / rhs and the two couplings ----
-  double de[BT_EPB];
+  double* pv = Ub + nn;            // [n] pivots
+  int br[EPB], bc[EPB];
 #pragma unroll
-  for (int q = 0; q < BT_EPB; ++q) {
+  for (int q = 0; q < EPB; ++q) {
     const int el = lane + q * 64;
-    de[q] = el < nn ? a.D[(size_t)e * nn + el] : 0.0;
+    br[q] = el < nn ? el / n : -1;
+    bc[q] = el < nn ? el % n : 0;
   }
+  int er[EPL], ec[EPL];
+#pragma unroll
+  for (int q = 0; q < EPL; ++q) {
+    const int el = lane + q * 64;
+    er[q] = el < n * nc ? el / nc : -1;
+    ec[q] = el < n * nc ? el % nc : 0;
+  }
+  // ---- gather the effective diagonal block / rhs and the two couplings ----
+  double de[EPB];
+#pragma unroll
+  for (int q = 0; q < EPB; ++q) de[q] = br[q] >= 0 ? a.D[(size_t)e * nn + lane + q * 64] : 0.0;
   double ye = (rhs && lane < n) ? a.rhs_scale * a.rhs[(size_t)e * n + lane] : 0.0;
   for (int l = 0; l < L; ++l) {
     const int h = 1 << l;
     const bool left = e - h >= 0, right = e + h < T;
 #pragma unroll
-    for (int q = 0; q < BT_EPB; ++q) {
-      const int el = lane + q * 64;
-      if (el < nn) {
+    for (int q = 0; q < EPB; ++q) {
+      if (br[q] >= 0) {
+        const int el = lane + q * 64;
         if (left) de[q] -= a.w.CR[(size_t)(e - h) * nn + el];
         if (right) de[q] -= a.w.CL[(size_t)(e + h) * nn + el];
       }
@@ -199,10 +213,9 @@ __global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
   const double* pUa = !has_a ? nullptr : (L == 0 ? a.U + (size_t)(e - s) * nn : a.w.NU + (size_t)(e - s / 2) * nn);
   const double* pUb = !has_b ? nullptr : (L == 0 ? a.U + (size_t)e * nn : a.w.NU + (size_t)(e + s / 2) * nn);
 #pragma unroll
-  for (int q = 0; q < BT_EPB; ++q) {
-    const int el = lane + q * 64;
-    if (el < nn) {
-      const int r = el / n, c = el % n;
+  for (int q = 0; q < EPB; ++q) {
+    if (br[q] >= 0) {
+      const int el = lane + q * 64, r = br[q], c = bc[q];
       const double ua = has_a ? pUa[el] : 0.0, ub = has_b ? pUb[el] : 0.0;
       Ua[el] = ua;
       Ub[el] = ub;
@@ -214,16 +227,17 @@ __global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
   }
   if (rhs && lane < n) Ts[lane * nc + cY] = ye;
   wave_lds_sync();
-  double logsum = 0.0;
   int bad = 0;
-  gauss_jordan<PIVOT>(Ts, n, nc, lane, logsum, bad);
-  if (lane == 0) { a.w.logp[e] = logsum; a.w.bad[e] = bad; }
+  gauss_jordan<PIVOT, EPL>(Ts, n, nc, er, ec, pv, lane, bad);
+  double lg = lane < n ? log(pv[lane]) : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+  if (lane == 0) { a.w.logp[e] = lg; a.w.bad[e] = bad; }
   // ---- store E, GA, GB, v and the pending updates ----
 #pragma unroll
-  for (int q = 0; q < BT_EPB; ++q) {
-    const int el = lane + q * 64;
-    if (el < nn) {
-      const int r = el / n, c = el % n;
+  for (int q = 0; q < EPB; ++q) {
+    if (br[q] >= 0) {
+      const int el = lane + q * 64, r = br[q], c = bc[q];
       if (a.need_E) a.w.E[(size_t)e * nn + el] = Ts[r * nc + cE + c];
       if (has_a) {
         a.w.GA[(size_t)e * nn + el] = Ts[r * nc + cA + c];
@@ -256,6 +270,30 @@ __global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
       a.w.yR[(size_t)e * n + lane] = yr;
     }
   }
+  wave_lds_sync();
+}
+
+// one level, one wave per eliminated node
+template <bool PIVOT, int NMAX>
+__global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
+  extern __shared__ double sm[];
+  const int e = (2 * (int)blockIdx.x + 1) << a.level;
+  bcr_eliminate<PIVOT, NMAX>(a, a.level, e, false, threadIdx.x, sm);
+}
+
+// the top of the tree in ONE workgroup: levels tail_from .. nlevels-1 (each with <= blockDim/64
+// nodes, one wave per node) then the root, separated by workgroup barriers (the waves share the CU's
+// L1, so a workgroup-scope barrier makes the previous level's global stores visible).
+template <bool PIVOT, int NMAX>
+__global__ __launch_bounds__(1024) void bcr_forward_tail_kernel(BcrArgs a) {
+  extern __shared__ double sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* my = sm + (size_t)wave * bcr_unit_lds_doubles(a.n);
+  for (int l = a.tail_from; l < a.nlevels; ++l) {
+    if (wave < bcr_count(a.T, l)) bcr_eliminate<PIVOT, NMAX>(a, l, (2 * wave + 1) << l, false, lane, my);
+    __syncthreads();
+  }
+  if (wave == 0) bcr_eliminate<PIVOT, NMAX>(a, a.nlevels, 0, true, lane, my);
 }
 
 // half_logdet = 1/2 sum_t logp[t]  (fixed-order tree), NaN if any node saw a non-positive pivot
@@ -275,15 +313,9 @@ __global__ __launch_bounds__(256) void bcr_logdet_kernel(int T, const double* __
   if (threadIdx.x == 0) out[0] = sb[0] ? __builtin_nan("") : 0.5 * sh[0];
 }
 
-// back-substitution of one level: thread per (node, row)
-__global__ __launch_bounds__(256) void bcr_back_solve_kernel(int T, int n, int level, BcrWs w, double* __restrict__ x) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (level < 0) {                                   // root
-    if (gid < n) x[gid] = w.v[gid];
-    return;
-  }
+// ---- back-substitution ----
+__device__ inline void bcr_solve_row(int T, int n, int level, const BcrWs& w, double* __restrict__ x, int u, int r) {
   const int s = 1 << level, nn = n * n;
-  const int u = gid / n, r = gid % n;
   const int e = (2 * u + 1) * s;
   if (e >= T) return;
   const int a = e - s, b = e + s;
@@ -297,17 +329,29 @@ __global__ __launch_bounds__(256) void bcr_back_solve_kernel(int T, int n, int l
   x[(size_t)e * n + r] = xe;
 }
 
-// selected-inverse recursion of one level: one wave per eliminated node
-__global__ __launch_bounds__(64) void bcr_back_marginals_kernel(int T, int n, int level, BcrWs w,
-                                                                double* __restrict__ SigD, double* __restrict__ SigU) {
-  extern __shared__ double sm[];
-  const int nn = n * n, lane = threadIdx.x;
-  if (level < 0) {                                   // root: Sig_00 = E_0
-    for (int el = lane; el < nn; el += 64) SigD[el] = w.E[el];
-    return;
+// one level: thread per (node, row)
+__global__ __launch_bounds__(256) void bcr_back_solve_kernel(int T, int n, int level, BcrWs w, double* __restrict__ x) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  bcr_solve_row(T, n, level, w, x, gid / n, gid % n);
+}
+
+// root + levels nlevels-1 .. head_to in one workgroup (each with <= blockDim / n nodes)
+__global__ __launch_bounds__(1024) void bcr_back_solve_head_kernel(int T, int n, int nlevels, int head_to, BcrWs w,
+                                                                   double* __restrict__ x) {
+  const int tid = threadIdx.x;
+  if (tid < n) x[tid] = w.v[tid];
+  __syncthreads();
+  for (int l = nlevels - 1; l >= head_to; --l) {
+    if (tid < bcr_count(T, l) * n) bcr_solve_row(T, n, l, w, x, tid / n, tid % n);
+    __syncthreads();
   }
+}
+
+// ---- selected-inverse recursion: one wave per eliminated node ----
+__device__ inline void bcr_marginal_node(int T, int n, int level, int e, const BcrWs& w, double* __restrict__ SigD,
+                                         double* __restrict__ SigU, int lane, double* sm) {
+  const int nn = n * n;
   const int s = 1 << level;
-  const int e = (2 * (int)blockIdx.x + 1) * s;
   const int a = e - s, b = e + s;
   const bool has_b = b < T;
   double* GA = sm;            // [n][n]
@@ -358,6 +402,27 @@ __global__ __launch_bounds__(64) void bcr_back_marginals_kernel(int T, int n, in
       SigU[(size_t)a * nn + c * n + r] = SLs[el];     // Sig[a,e] = Sig[e,a]^T
       if (has_b) SigU[(size_t)e * nn + el] = SRs[el];
     }
+  }
+  wave_lds_sync();
+}
+
+__global__ __launch_bounds__(64) void bcr_back_marginals_kernel(int T, int n, int level, BcrWs w,
+                                                                double* __restrict__ SigD, double* __restrict__ SigU) {
+  extern __shared__ double sm[];
+  bcr_marginal_node(T, n, level, (2 * (int)blockIdx.x + 1) << level, w, SigD, SigU, threadIdx.x, sm);
+}
+
+// root (Sig_00 = E_0) + levels nlevels-1 .. head_to in one workgroup, one wave per node
+__global__ __launch_bounds__(1024) void bcr_back_marginals_head_kernel(int T, int n, int nlevels, int head_to, BcrWs w,
+                                                                       double* __restrict__ SigD,
+                                                                       double* __restrict__ SigU) {
+  extern __shared__ double sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nn = n * n;
+  for (int el = threadIdx.x; el < nn; el += blockDim.x) SigD[el] = w.E[el];
+  __syncthreads();
+  for (int l = nlevels - 1; l >= head_to; --l) {
+    if (wave < bcr_count(T, l)) bcr_marginal_node(T, n, l, (2 * wave + 1) << l, w, SigD, SigU, lane, sm + (size_t)wave * 7 * nn);
+    __syncthreads();
   }
 }
 

@@ -66,6 +66,7 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+template <int EPLP>   // elements of the d x d block per lane: 1 (d <= 8), 4 (d <= 16), 16 (d <= 32)
 __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __restrict__ mu,
                                                   const double* __restrict__ Sigma) {
   extern __shared__ double sm[];
@@ -79,21 +80,32 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
   double* be = al + dp;          // [dp]
   double* lam = be + dp;         // [d] (3 functions of lambda: sqrt, 1/sqrt, 1/x)
   int* pa = (int*)(lam + 3 * d); // [dp]
-
+  int ei[EPLP], ej[EPLP];        // (row, col) of this lane's elements, computed once (-1: none)
+#pragma unroll
+  for (int q = 0; q < EPLP; ++q) {
+    const int e = lane + q * 64;
+    ei[q] = e < dd ? e / d : -1;
+    ej[q] = e < dd ? e % d : 0;
+  }
   const double* Sg = Sigma + (size_t)k * dd;
-  for (int e = lane; e < dd; e += 64) {
-    const int i = e / d, j = e % d;
-    A0[e] = i >= j ? Sg[i * d + j] : Sg[j * d + i];   // lower triangle, like SelfAdjointEigenSolver
-    V0[e] = i == j ? 1.0 : 0.0;
+#pragma unroll
+  for (int q = 0; q < EPLP; ++q) {
+    if (ei[q] >= 0) {
+      const int i = ei[q], j = ej[q], e = lane + q * 64;
+      A0[e] = i >= j ? Sg[i * d + j] : Sg[j * d + i];   // lower triangle, like SelfAdjointEigenSolver
+      V0[e] = i == j ? 1.0 : 0.0;
+    }
   }
   wave_lds_sync();
   double* A = A0; double* An = A1; double* V = V0; double* Vn = V1;
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0.0, dg = 0.0;
-    for (int e = lane; e < dd; e += 64) {
-      const int i = e / d, j = e % d;
-      const double v = A[e];
-      if (i == j) dg += v * v; else if (i < j) off += v * v;
+#pragma unroll
+    for (int q = 0; q < EPLP; ++q) {
+      if (ei[q] >= 0) {
+        const double v = A[lane + q * 64];
+        if (ei[q] == ej[q]) dg += v * v; else if (ei[q] < ej[q]) off += v * v;
+      }
     }
     off = wave_sum(off);
     dg = wave_sum(dg);
@@ -102,7 +114,10 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
       if (lane < dp / 2) {
         int p, q;
         if (lane == 0) { p = dp - 1; q = r; }
-        else { p = (r + lane) % (dp - 1); q = (r - lane + dp - 1) % (dp - 1); }
+        else {
+          p = r + lane; if (p >= dp - 1) p -= dp - 1;
+          q = r - lane; if (q < 0) q += dp - 1;
+        }
         if (p > q) { const int t = p; p = q; q = t; }
         double c = 1.0, s = 0.0;
         const bool valid = q < d;
@@ -119,12 +134,15 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
         al[q] = c; be[q] = s;  pa[q] = valid ? p : q;
       }
       wave_lds_sync();
-      for (int e = lane; e < dd; e += 64) {
-        const int i = e / d, j = e % d;
-        const int pi = pa[i], pj = pa[j];
-        const double ai = al[i], bi = be[i], aj = al[j], bj = be[j];
-        An[e] = ai * (aj * A[i * d + j] + bj * A[i * d + pj]) + bi * (aj * A[pi * d + j] + bj * A[pi * d + pj]);
-        Vn[e] = aj * V[i * d + j] + bj * V[i * d + pj];
+#pragma unroll
+      for (int q = 0; q < EPLP; ++q) {
+        if (ei[q] >= 0) {
+          const int i = ei[q], j = ej[q], e = lane + q * 64;
+          const int pi = pa[i], pj = pa[j];
+          const double ai = al[i], bi = be[i], aj = al[j], bj = be[j];
+          An[e] = ai * (aj * A[i * d + j] + bj * A[i * d + pj]) + bi * (aj * A[pi * d + j] + bj * A[pi * d + pj]);
+          Vn[e] = aj * V[i * d + j] + bj * V[i * d + pj];
+        }
       }
       wave_lds_sync();
       double* t = A; A = An; An = t;
@@ -139,17 +157,20 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
   }
   wave_lds_sync();
   // S, S^-1, Lam = V f(lambda) V^T; S is also kept in LDS (An) for H = A_k S
-  for (int e = lane; e < dd; e += 64) {
-    const int i = e / d, j = e % d;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < d; ++c) {
-      const double vv = V[i * d + c] * V[j * d + c];
-      s0 += vv * lam[c]; s1 += vv * lam[d + c]; s2 += vv * lam[2 * d + c];
+#pragma unroll
+  for (int q = 0; q < EPLP; ++q) {
+    if (ei[q] >= 0) {
+      const int i = ei[q], j = ej[q], e = lane + q * 64;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int c = 0; c < d; ++c) {
+        const double vv = V[i * d + c] * V[j * d + c];
+        s0 += vv * lam[c]; s1 += vv * lam[d + c]; s2 += vv * lam[2 * d + c];
+      }
+      An[e] = s0;
+      f.S[(size_t)k * dd + e] = s0;
+      f.Sinv[(size_t)k * dd + e] = s1;
+      f.Lam[(size_t)k * dd + e] = s2;
     }
-    An[e] = s0;
-    f.S[(size_t)k * dd + e] = s0;
-    f.Sinv[(size_t)k * dd + e] = s1;
-    f.Lam[(size_t)k * dd + e] = s2;
   }
   wave_lds_sync();
   if (f.m > 0) {
