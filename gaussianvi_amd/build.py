@@ -56,5 +56,23 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_examples(force: bool = False) -> str:
+    """C++ drivers over the host shim (include/gvi/gvi_host.hpp), linked against the C-ABI library."""
+    build_lib()
+    out_dir = os.path.join(ROOT, "examples", "bin")
+    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(ROOT, "examples", "1d_example.cpp")
+    exe = os.path.join(out_dir, "1d_example")
+    deps = [src, os.path.join(ROOT, "include", "gvi", "gvi_host.hpp"), os.path.join(ROOT, "include", "gvi_hip.h")]
+    if force or _stale(exe, deps):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src,
+               "-L", HERE, "-lgvi_hip", "-Wl,-rpath," + HERE, "-o", exe]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("g++ failed:\n" + " ".join(cmd) + "\n" + r.stderr[-4000:])
+    return exe
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_examples(force="--force" in sys.argv))
