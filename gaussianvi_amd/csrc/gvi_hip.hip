@@ -193,6 +193,29 @@ void launch_reg(const MomArgs& a, dim3 grid, hipStream_t st) {
   else hipLaunchKernelGGL((moments_reg_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
 }
 
+template <int D, int M>
+void launch_sgpr(const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (a.full) hipLaunchKernelGGL((moments_sgpr_kernel<D, M, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((moments_sgpr_kernel<D, M, false>), grid, dim3(256), 0, st, a);
+}
+
+// scalar-operand kernel: instantiated for the shapes of the BASELINE configs
+bool dispatch_sgpr(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (s.kind == KIND_QUAD_PRIOR) {
+    switch (s.d) {
+      case 4: launch_sgpr<4, 2>(a, grid, st); return true;
+      case 12: launch_sgpr<12, 6>(a, grid, st); return true;
+    }
+  }
+  if (s.kind == KIND_FIXED_PRIOR) {
+    switch (s.d) {
+      case 2: launch_sgpr<2, 2>(a, grid, st); return true;
+      case 6: launch_sgpr<6, 6>(a, grid, st); return true;
+    }
+  }
+  return false;
+}
+
 bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
   const int d = s.d;
   if (s.kind == KIND_RANGE_1D && d == 1) { launch_reg<1, PsiRange1D>(a, grid, st); return true; }
@@ -252,7 +275,9 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   }
   if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
-    if (!dispatch_reg(s, a, grid, c->stream)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
+    bool done = false;
+    if (c->variant == 3) done = dispatch_sgpr(s, a, grid, c->stream);
+    if (!done && !dispatch_reg(s, a, grid, c->stream)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
     if (s.d > 32) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel supports d <= 32");
     const int d = s.d, m = s.m;
@@ -300,13 +325,14 @@ gvi_status ensure_set_buffers(gvi_ctx* c, FactorSet& s) {
 
 gvi_status ensure_chain_ws(gvi_ctx* c, BcrWs& w) {
   const size_t T = c->T, nn = nn_(c), n = c->n;
-  const size_t words = 8 * T * nn + 3 * T * n + T;
+  const size_t words = 9 * T * nn + 4 * T * n + T;
   HIPCK(c, c->Wbuf.ensure(words * 8));
   HIPCK(c, c->Ibuf.ensure(T * sizeof(int)));
   double* p = c->Wbuf.d();
   w.E = p; p += T * nn;  w.GA = p; p += T * nn; w.GB = p; p += T * nn; w.CL = p; p += T * nn;
   w.CR = p; p += T * nn; w.NU = p; p += T * nn; w.SL = p; p += T * nn; w.SR = p; p += T * nn;
-  w.v = p; p += T * n;   w.yL = p; p += T * n;  w.yR = p; p += T * n;
+  w.Deff = p; p += T * nn;
+  w.v = p; p += T * n;   w.yL = p; p += T * n;  w.yR = p; p += T * n; w.yeff = p; p += T * n;
   w.logp = p;
   w.bad = (int*)c->Ibuf.p;
   return GVI_OK;
@@ -334,7 +360,8 @@ gvi_status launch_bcr_forward(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
   const size_t unit = (size_t)bcr_unit_lds_doubles(c->n) * 8;
   for (int l = 0; l < pl.tail_from; ++l) {
     a.level = l;
-    hipLaunchKernelGGL((bcr_forward_kernel<PIVOT, NMAX>), dim3(bcr_count(c->T, l)), dim3(64), unit, c->stream, a);
+    const int blocks = bcr_count(c->T, l) + (l > 0 ? bcr_survivors(c->T, l) : 0);
+    hipLaunchKernelGGL((bcr_forward_kernel<PIVOT, NMAX>), dim3(blocks), dim3(64), unit, c->stream, a);
   }
   a.tail_from = pl.tail_from;
   const size_t lds = unit * pl.waves;
@@ -1149,7 +1176,7 @@ gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nch
 }
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 2) return GVI_ERR_ARG;
+  if (!ctx || variant < 0 || variant > 3) return GVI_ERR_ARG;
   ctx->variant = variant;
   return GVI_OK;
 }

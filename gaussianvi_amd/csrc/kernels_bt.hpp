@@ -18,8 +18,10 @@
 //     Gauss-Jordan [D_e | I | Ua^T | Ub | y_e] -> [I | E | GA | GB | v]   (E = D_e^-1, GA = E Ua^T, GB = E Ub)
 //     CL[e] = Ua GA   (pending  -=  on D_a)        CR[e] = Ub^T GB  (pending -= on D_b)
 //     NU[e] = -Ua GB  (new coupling A[a,b])        yL[e] = Ua v,  yR[e] = Ub^T v  (pending -= on y_a, y_b)
-//   Pending updates are applied lazily, in fixed order, when a node is itself eliminated:
-//     D_e(eff) = D_e - sum_{l<L} (CR[e - 2^l] + CL[e + 2^l]), so no two waves ever write one block.
+//   Pending updates of level l-1 are applied at level l, in fixed order: by the eliminating wave for
+//   the nodes eliminated at level l, and by "update units" of the same launch for the surviving
+//   nodes (Deff[x] = base(x) - CR[x - s/2] - CL[x + s/2]); no two waves ever write one block, and a
+//   node's loads are independent of its depth in the tree.
 //   back-substitution (solve):   x_e = v - GA x_a - GB x_b
 //   selected inverse (Takahashi recursion on the elimination tree):
 //     Sig[e,a] = -(GA Sig_aa + GB Sig_ba),  Sig[e,b] = -(GA Sig_ab + GB Sig_bb),
@@ -137,8 +139,8 @@ __device__ inline void gauss_jordan(double* Ts, int n, int nc, const int (&er)[E
 
 // ---- workspace of one cyclic reduction (all [T][n][n] unless noted) ----
 struct BcrWs {
-  double *E, *GA, *GB, *CL, *CR, *NU, *SL, *SR;
-  double *v, *yL, *yR;     // [T][n]
+  double *E, *GA, *GB, *CL, *CR, *NU, *SL, *SR, *Deff;
+  double *v, *yL, *yR, *yeff;   // [T][n]
   double* logp;            // [T]
   int* bad;                // [T]
 };
@@ -189,26 +191,27 @@ __device__ inline void bcr_eliminate(const BcrArgs& a, int L, int e, bool root, 
     er[q] = el < n * nc ? el / nc : -1;
     ec[q] = el < n * nc ? el % nc : 0;
   }
-  // ---- gather the effective diagonal block / rhs and the two couplings ----
+  // ---- gather the effective diagonal block / rhs (base + the previous level's pending updates) ----
+  const int h = L > 0 ? (1 << (L - 1)) : 0;
+  const bool cl = L > 0 && e - h >= 0, cr = L > 0 && e + h < T;
+  const double* baseD = (L <= 1 ? a.D : a.w.Deff) + (size_t)e * nn;
   double de[EPB];
 #pragma unroll
-  for (int q = 0; q < EPB; ++q) de[q] = br[q] >= 0 ? a.D[(size_t)e * nn + lane + q * 64] : 0.0;
-  double ye = (rhs && lane < n) ? a.rhs_scale * a.rhs[(size_t)e * n + lane] : 0.0;
-  for (int l = 0; l < L; ++l) {
-    const int h = 1 << l;
-    const bool left = e - h >= 0, right = e + h < T;
-#pragma unroll
-    for (int q = 0; q < EPB; ++q) {
-      if (br[q] >= 0) {
-        const int el = lane + q * 64;
-        if (left) de[q] -= a.w.CR[(size_t)(e - h) * nn + el];
-        if (right) de[q] -= a.w.CL[(size_t)(e + h) * nn + el];
-      }
+  for (int q = 0; q < EPB; ++q) {
+    const int el = lane + q * 64;
+    double v = 0.0;
+    if (br[q] >= 0) {
+      v = baseD[el];
+      if (cl) v -= a.w.CR[(size_t)(e - h) * nn + el];
+      if (cr) v -= a.w.CL[(size_t)(e + h) * nn + el];
     }
-    if (rhs && lane < n) {
-      if (left) ye -= a.w.yR[(size_t)(e - h) * n + lane];
-      if (right) ye -= a.w.yL[(size_t)(e + h) * n + lane];
-    }
+    de[q] = v;
+  }
+  double ye = 0.0;
+  if (rhs && lane < n) {
+    ye = L <= 1 ? a.rhs_scale * a.rhs[(size_t)e * n + lane] : a.w.yeff[(size_t)e * n + lane];
+    if (cl) ye -= a.w.yR[(size_t)(e - h) * n + lane];
+    if (cr) ye -= a.w.yL[(size_t)(e + h) * n + lane];
   }
   const double* pUa = !has_a ? nullptr : (L == 0 ? a.U + (size_t)(e - s) * nn : a.w.NU + (size_t)(e - s / 2) * nn);
   const double* pUb = !has_b ? nullptr : (L == 0 ? a.U + (size_t)e * nn : a.w.NU + (size_t)(e + s / 2) * nn);
@@ -273,24 +276,59 @@ __device__ inline void bcr_eliminate(const BcrArgs& a, int L, int e, bool root, 
   wave_lds_sync();
 }
 
-// one level, one wave per eliminated node
+// Surviving node x = 2 j s of level L >= 1: fold the pending updates of level L-1 into Deff / yeff.
+__device__ inline void bcr_update_survivor(const BcrArgs& a, int L, int x, int lane) {
+  const int n = a.n, nn = n * n, T = a.T, h = 1 << (L - 1);
+  const bool cl = x - h >= 0, cr = x + h < T;
+  const double* baseD = (L <= 1 ? a.D : a.w.Deff) + (size_t)x * nn;
+  for (int el = lane; el < nn; el += 64) {
+    double v = baseD[el];
+    if (cl) v -= a.w.CR[(size_t)(x - h) * nn + el];
+    if (cr) v -= a.w.CL[(size_t)(x + h) * nn + el];
+    a.w.Deff[(size_t)x * nn + el] = v;
+  }
+  if (a.rhs != nullptr && lane < n) {
+    double y = L <= 1 ? a.rhs_scale * a.rhs[(size_t)x * n + lane] : a.w.yeff[(size_t)x * n + lane];
+    if (cl) y -= a.w.yR[(size_t)(x - h) * n + lane];
+    if (cr) y -= a.w.yL[(size_t)(x + h) * n + lane];
+    a.w.yeff[(size_t)x * n + lane] = y;
+  }
+}
+
+// number of surviving (even-index) nodes of level l
+__host__ __device__ inline int bcr_survivors(int T, int l) {
+  const int cnt = (int)(((int64_t)T + (1 << l) - 1) >> l);
+  return (cnt + 1) / 2;
+}
+
+// one level: blocks [0, elim) eliminate the odd nodes, blocks [elim, elim + surv) update the even ones
 template <bool PIVOT, int NMAX>
 __global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
   extern __shared__ double sm[];
-  const int e = (2 * (int)blockIdx.x + 1) << a.level;
-  bcr_eliminate<PIVOT, NMAX>(a, a.level, e, false, threadIdx.x, sm);
+  const int elim = bcr_count(a.T, a.level);
+  if ((int)blockIdx.x < elim) {
+    bcr_eliminate<PIVOT, NMAX>(a, a.level, (2 * (int)blockIdx.x + 1) << a.level, false, threadIdx.x, sm);
+  } else {
+    bcr_update_survivor(a, a.level, (2 * ((int)blockIdx.x - elim)) << a.level, threadIdx.x);
+  }
 }
 
 // the top of the tree in ONE workgroup: levels tail_from .. nlevels-1 (each with <= blockDim/64
-// nodes, one wave per node) then the root, separated by workgroup barriers (the waves share the CU's
-// L1, so a workgroup-scope barrier makes the previous level's global stores visible).
+// eliminated nodes, one wave per node; the surviving nodes are updated by the remaining waves) then
+// the root, separated by workgroup barriers (the waves share the CU's L1, so a workgroup-scope barrier
+// makes the previous phase's global stores visible).
 template <bool PIVOT, int NMAX>
 __global__ __launch_bounds__(1024) void bcr_forward_tail_kernel(BcrArgs a) {
   extern __shared__ double sm[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   double* my = sm + (size_t)wave * bcr_unit_lds_doubles(a.n);
   for (int l = a.tail_from; l < a.nlevels; ++l) {
-    if (wave < bcr_count(a.T, l)) bcr_eliminate<PIVOT, NMAX>(a, l, (2 * wave + 1) << l, false, lane, my);
+    const int elim = bcr_count(a.T, l);
+    if (wave < elim) bcr_eliminate<PIVOT, NMAX>(a, l, (2 * wave + 1) << l, false, lane, my);
+    if (l > 0) {
+      const int surv = bcr_survivors(a.T, l);
+      for (int j = wave; j < surv; j += nwaves) bcr_update_survivor(a, l, (2 * j) << l, lane);
+    }
     __syncthreads();
   }
   if (wave == 0) bcr_eliminate<PIVOT, NMAX>(a, a.nlevels, 0, true, lane, my);

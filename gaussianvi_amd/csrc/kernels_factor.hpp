@@ -422,6 +422,102 @@ __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// moments_sgpr_kernel<D, M, FULL>: second-generation hot kernel for the sum-of-squares psi kinds.
+// Same decomposition as moments_reg_kernel, but
+//   * the factor index is wave-uniform by construction (readfirstlane), so H / u0 / sgn are fetched
+//     with SCALAR loads and enter the FMAs as SGPR operands: no LDS traffic and no VGPRs for psi
+//     operands (the LDS broadcast reads kept the LDS pipe ~2/3 busy and exposed its latency);
+//   * Z rows are addressed as uniform row base + one 32-bit per-lane byte offset (saddr form), no
+//     64-bit vector address arithmetic per row;
+//   * the next iteration's z / w are loaded before the current one is consumed (software prefetch).
+// ---------------------------------------------------------------------------------------------
+template <int D, int M, bool FULL>
+__global__ __launch_bounds__(256, 2) void moments_sgpr_kernel(MomArgs a) {
+  constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
+  constexpr int NB = (NP + 15) / 16;
+  __shared__ double red[4][16][65];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int kq = blockIdx.x * 4 + wave;
+  const bool active = kq < a.f.K;
+  const int k = active ? kq : a.f.K - 1;                    // wave-uniform
+  const double* __restrict__ Hk = a.f.H + (size_t)k * M * D;
+  const double* __restrict__ u0k = a.f.u0 + (size_t)k * M;
+  const double* __restrict__ sgk = a.f.sgn + (size_t)k * M;
+  double acc[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const char* __restrict__ Zb = (const char*)a.f.Zt;
+  const char* __restrict__ wb = (const char*)a.f.w;
+  const size_t rowb = (size_t)Np * 8;
+  const unsigned nvalid = (unsigned)a.f.N;
+  unsigned idx = (unsigned)(i0 + lane);
+  const unsigned iend = (unsigned)i1;
+  double zn[D], wn = 0.0;
+  if (idx < iend) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) zn[c] = *(const double*)(Zb + c * rowb + (size_t)idx * 8u);
+    wn = *(const double*)(wb + (size_t)idx * 8u);
+  } else {
+#pragma unroll
+    for (int c = 0; c < D; ++c) zn[c] = 0.0;
+  }
+  for (; idx < iend; idx += 64) {
+    double z[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) z[c] = zn[c];
+    const double wi = idx < nvalid ? wn : 0.0;
+    const unsigned nxt = idx + 64;
+    if (nxt < iend) {                                      // prefetch (wave-uniform: chunks are multiples of 64)
+#pragma unroll
+      for (int c = 0; c < D; ++c) zn[c] = *(const double*)(Zb + c * rowb + (size_t)nxt * 8u);
+      wn = *(const double*)(wb + (size_t)nxt * 8u);
+    }
+    double u[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) u[r] = u0k[r];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+#pragma unroll
+      for (int r = 0; r < M; ++r) u[r] = fma(Hk[r * D + c], z[c], u[r]);
+    }
+    double psi = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) psi = fma(sgk[r] * u[r], u[r], psi);
+    const double cw = wi * psi;
+    acc[0] += cw;
+    if (FULL) {
+      int q = 1 + D;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const double t = cw * z[c];
+        acc[1 + c] += t;
+#pragma unroll
+        for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
+      }
+    }
+  }
+  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * NP;
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (bb * 16 + j < NP) red[wave][j][lane] = acc[bb * 16 + j];
+    __syncthreads();
+    const int j = lane & 15, part = lane >> 4;
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += red[wave][j][part * 16 + t];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // epilogue_kernel: one wave per factor.
 // ---------------------------------------------------------------------------------------------
 struct EpiArgs {
