@@ -170,14 +170,21 @@ def main():
             "final_cost": log[-1]["new_cost"],
             "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": K0 * N0 / km,
                                "cost_kernel_ms": float(np.mean(cost_ms))},
-            "roofline": {"bound": "hbm", "achieved": alg_bytes / km / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": alg_bytes / km / HBM_PEAK, "traffic": traffic,
+            # The dominant kernel streams only the (d,p) table, which is L2-resident (profiles/r01_traffic.json:
+            # HBM traffic ~0.5 % of the algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.
+            # The schema's compute label is "mfma"; fp64 MFMA and fp64 VALU share one pipe on MI355X and the
+            # VALU form is the faster one (profiles/r01_fp64_pipes.txt), so the kernel uses v_fma_f64.
+            "roofline": {"bound": "mfma", "achieved": f_alg * K0 * N0 / km / 1e12, "peak": FP64_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": f_alg * K0 * N0 / km / FP64_PEAK, "traffic": traffic,
                          "kernel": "moments_reg_kernel<12, PsiQuad<12,6>, full>" if geo["variant"] == 2 else "moments_generic_kernel",
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "Z (1.65 MB) is L2-resident, so the binding roof is fp64 FMA issue, not HBM: see fp64",
-                         "fp64": {"algorithmic_flop_per_eval": f_alg, "achieved_tflops": f_alg * K0 * N0 / km / 1e12,
-                                  "peak_tflops": FP64_PEAK / 1e12, "frac": f_alg * K0 * N0 / km / FP64_PEAK,
-                                  "peak_source": "AMD MI355X spec sheet (fp64 vector = matrix 78.6 TF); not in the local guide"}},
+                         "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": 188,
+                         "executed_tflops": 2 * 188 * K0 * N0 / km / 1e12,
+                         "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "
+                                        "Measured on this box (tools/ubench/fp64_pipes.hip): 70 TF v_fma_f64, 48 TF v_mfma_f64_16x16x4",
+                         "hbm_algorithmic": {"bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / km / 1e9,
+                                             "peak_GBps": HBM_PEAK / 1e9, "frac": alg_bytes / km / HBM_PEAK,
+                                             "note": "BASELINE's '>= 60 % of HBM roofline' figure: (d+1)*8 B per eval over 8 TB/s; "
+                                                     "exceeds 1 because the table is served from L2"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds)

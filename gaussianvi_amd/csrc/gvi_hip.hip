@@ -193,24 +193,24 @@ void launch_reg(const MomArgs& a, dim3 grid, hipStream_t st) {
   else hipLaunchKernelGGL((moments_reg_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
 }
 
-template <int D, int M>
-void launch_sgpr(const MomArgs& a, dim3 grid, hipStream_t st) {
-  if (a.full) hipLaunchKernelGGL((moments_sgpr_kernel<D, M, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((moments_sgpr_kernel<D, M, false>), grid, dim3(256), 0, st, a);
+template <int D, typename Psi>
+void launch_wide(const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (a.full) hipLaunchKernelGGL((moments_wide_kernel<D, Psi, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((moments_wide_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
 }
 
-// scalar-operand kernel: instantiated for the shapes of the BASELINE configs
-bool dispatch_sgpr(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
+// operand-resident kernel: instantiated for the shapes of the BASELINE configs
+bool dispatch_wide(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
   if (s.kind == KIND_QUAD_PRIOR) {
     switch (s.d) {
-      case 4: launch_sgpr<4, 2>(a, grid, st); return true;
-      case 12: launch_sgpr<12, 6>(a, grid, st); return true;
+      case 4: launch_wide<4, PsiQuad<4, 2>>(a, grid, st); return true;
+      case 12: launch_wide<12, PsiQuad<12, 6>>(a, grid, st); return true;
     }
   }
   if (s.kind == KIND_FIXED_PRIOR) {
     switch (s.d) {
-      case 2: launch_sgpr<2, 2>(a, grid, st); return true;
-      case 6: launch_sgpr<6, 6>(a, grid, st); return true;
+      case 2: launch_wide<2, PsiQuad<2, 2>>(a, grid, st); return true;
+      case 6: launch_wide<6, PsiQuad<6, 6>>(a, grid, st); return true;
     }
   }
   return false;
@@ -276,7 +276,9 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
-    if (c->variant == 3) done = dispatch_sgpr(s, a, grid, c->stream);
+    // auto: the operand-resident kernel wins for the cost pass (operands hoisted into VGPRs, 2 waves/SIMD),
+    // the LDS-operand kernel for the full pass (the 91 accumulators own the register file)
+    if (c->variant == 3 || (c->variant == 0 && !full)) done = dispatch_wide(s, a, grid, c->stream);
     if (!done && !dispatch_reg(s, a, grid, c->stream)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
     if (s.d > 32) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel supports d <= 32");

@@ -50,7 +50,7 @@ struct FactorDev {
   double* S;                // [K][d][d]
   double* Sinv;             // [K][d][d]
   double* Lam;              // [K][d][d]
-  double* H;                // [K][m][d]
+  double* H;                // [K][d][m]  H = A S, stored column by column
   double* u0;               // [K][m]
 };
 
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
       const int r = e / d, a = e % d;
       double h = 0.0;
       for (int c = 0; c < d; ++c) h += Ak[r * d + c] * An[c * d + a];
-      f.H[(size_t)k * m * d + e] = h;
+      f.H[(size_t)k * m * d + a * m + r] = h;            // column-major [d][m]: a column's m entries contiguous
     }
     if (lane < m) {
       double u = f.b[(size_t)k * m + lane];
@@ -330,6 +330,7 @@ __global__ __launch_bounds__(GEN_BS) void moments_generic_kernel(MomArgs a) {
 template <int D, int M>
 struct PsiQuad {
   static constexpr int LDS = M * D + 2 * M;
+  static constexpr bool GUARD = false;
   __device__ static void load(const MomArgs& a, int k, double* hs, int lane) {
     for (int e = lane; e < M * D; e += 64) hs[e] = a.f.H[(size_t)k * M * D + e];
     if (lane < M) {
@@ -344,7 +345,7 @@ struct PsiQuad {
 #pragma unroll
     for (int c = 0; c < D; ++c) {
 #pragma unroll
-      for (int r = 0; r < M; ++r) u[r] = fma(hs[r * D + c], z[c], u[r]);
+      for (int r = 0; r < M; ++r) u[r] = fma(hs[c * M + r], z[c], u[r]);
     }
     double psi = 0.0;
 #pragma unroll
@@ -355,6 +356,7 @@ struct PsiQuad {
 
 struct PsiRange1D {
   static constexpr int LDS = 8;
+  static constexpr bool GUARD = true;
   __device__ static void load(const MomArgs& a, int k, double* hs, int lane) {
     if (lane == 0) { hs[0] = a.mu[k]; hs[1] = a.f.S[k]; }
     if (lane < 5) hs[2 + lane] = a.f.raw[(size_t)k * a.f.raw_stride + lane];
@@ -422,27 +424,25 @@ __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// moments_sgpr_kernel<D, M, FULL>: second-generation hot kernel for the sum-of-squares psi kinds.
-// Same decomposition as moments_reg_kernel, but
-//   * the factor index is wave-uniform by construction (readfirstlane), so H / u0 / sgn are fetched
-//     with SCALAR loads and enter the FMAs as SGPR operands: no LDS traffic and no VGPRs for psi
-//     operands (the LDS broadcast reads kept the LDS pipe ~2/3 busy and exposed its latency);
-//   * Z rows are addressed as uniform row base + one 32-bit per-lane byte offset (saddr form), no
-//     64-bit vector address arithmetic per row;
-//   * the next iteration's z / w are loaded before the current one is consumed (software prefetch).
+// moments_wide_kernel<D, Psi, FULL>: same decomposition as moments_reg_kernel, different register
+// economy.  With the wave index made uniform (readfirstlane) the psi operands are loop-invariant, so
+// the compiler keeps all of them in VGPRs: no LDS traffic inside the loop.  FULL needs ~400 VGPRs
+// (91 accumulators + 78 operands + double-buffered z) = ONE wave per SIMD, latency hidden by an
+// explicit prefetch of the next 64 points; the cost pass fits two waves.
+//   Z rows are addressed as wave-uniform row base + one 32-bit per-lane byte offset (saddr form).
 // ---------------------------------------------------------------------------------------------
-template <int D, int M, bool FULL>
-__global__ __launch_bounds__(256, 2) void moments_sgpr_kernel(MomArgs a) {
+template <int D, typename Psi, bool FULL>
+__global__ __launch_bounds__(256, FULL ? 1 : 2) void moments_wide_kernel(MomArgs a) {
   constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
   constexpr int NB = (NP + 15) / 16;
+  __shared__ double hs[4][Psi::LDS];
   __shared__ double red[4][16][65];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int kq = blockIdx.x * 4 + wave;
   const bool active = kq < a.f.K;
-  const int k = active ? kq : a.f.K - 1;                    // wave-uniform
-  const double* __restrict__ Hk = a.f.H + (size_t)k * M * D;
-  const double* __restrict__ u0k = a.f.u0 + (size_t)k * M;
-  const double* __restrict__ sgk = a.f.sgn + (size_t)k * M;
+  const int k = active ? kq : a.f.K - 1;                    // wave-uniform; inactive waves redo the last factor
+  Psi::load(a, k, hs[wave], lane);
+  __syncthreads();
   double acc[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) acc[j] = 0.0;
@@ -456,37 +456,27 @@ __global__ __launch_bounds__(256, 2) void moments_sgpr_kernel(MomArgs a) {
   unsigned idx = (unsigned)(i0 + lane);
   const unsigned iend = (unsigned)i1;
   double zn[D], wn = 0.0;
+#pragma unroll
+  for (int c = 0; c < D; ++c) zn[c] = 0.0;
   if (idx < iend) {
 #pragma unroll
     for (int c = 0; c < D; ++c) zn[c] = *(const double*)(Zb + c * rowb + (size_t)idx * 8u);
     wn = *(const double*)(wb + (size_t)idx * 8u);
-  } else {
-#pragma unroll
-    for (int c = 0; c < D; ++c) zn[c] = 0.0;
   }
   for (; idx < iend; idx += 64) {
     double z[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) z[c] = zn[c];
-    const double wi = idx < nvalid ? wn : 0.0;
+    const double wi = wn;                                   // padded tail: w = 0, z = 0
     const unsigned nxt = idx + 64;
-    if (nxt < iend) {                                      // prefetch (wave-uniform: chunks are multiples of 64)
+    if (nxt < iend) {                                       // software prefetch of the next 64 points
 #pragma unroll
       for (int c = 0; c < D; ++c) zn[c] = *(const double*)(Zb + c * rowb + (size_t)nxt * 8u);
       wn = *(const double*)(wb + (size_t)nxt * 8u);
     }
-    double u[M];
-#pragma unroll
-    for (int r = 0; r < M; ++r) u[r] = u0k[r];
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-#pragma unroll
-      for (int r = 0; r < M; ++r) u[r] = fma(Hk[r * D + c], z[c], u[r]);
-    }
-    double psi = 0.0;
-#pragma unroll
-    for (int r = 0; r < M; ++r) psi = fma(sgk[r] * u[r], u[r], psi);
-    const double cw = wi * psi;
+    const double psi = Psi::eval(z, hs[wave]);
+    // GUARD kinds may be non-finite at the padded z = 0 (x = mu): keep 0 * inf out of the sums
+    const double cw = Psi::GUARD ? (idx < nvalid ? wi * psi : 0.0) : wi * psi;
     acc[0] += cw;
     if (FULL) {
       int q = 1 + D;
