@@ -14,6 +14,7 @@
 
 #include "host_linalg.hpp"
 #include "kernels_bt.hpp"
+#include "kernels_bcr_seg.hpp"
 #include "kernels_factor.hpp"
 #include "spgh.hpp"
 
@@ -57,12 +58,18 @@ struct FactorSet {
   int64_t chunk = 0;
   bool use_reg = false;
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
+  hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
+  hipEvent_t done = nullptr;
   // operator outputs / NGD per-set state
   DevMem mu_k[2], Sigma_k[2], Ephi, cost, Vdmu, Vddmu, raw1, raw2, X, psi_ext;
   DevMem in_mu, in_Sigma;             // staging of the host-pointer API (never aliases NGD state)
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [moments|cost][start|stop]
   bool ev_set[2] = {false, false};
-  ~FactorSet() { for (auto& a : ev) for (auto& e : a) if (e) (void)hipEventDestroy(e); }
+  ~FactorSet() {
+    for (auto& a : ev) for (auto& e : a) if (e) (void)hipEventDestroy(e);
+    if (done) (void)hipEventDestroy(done);
+    if (st) (void)hipStreamDestroy(st);
+  }
   FactorDev dev() const {
     FactorDev f;
     f.K = K; f.d = d; f.m = m; f.kind = kind;
@@ -99,8 +106,12 @@ struct gvi_ctx {
   DevMem Wbuf, Ibuf, vbuf, scratch, hldtmp;
   std::string err;
   int variant = 0;
+  int bcr_variant = 0;                // 0 auto (segmented where instantiated), 1 per-level kernels
   bool profile = false;
   int target_waves = 2048;
+  hipEvent_t fork = nullptr;
+  double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet}
+  double* host_slot_dev = nullptr;
 };
 
 namespace {
@@ -242,21 +253,25 @@ bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t s
 }
 
 // prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
-gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma, int slot = -1) {
+gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma, int slot = -1,
+                    hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
   if (slot >= 0 && s.prep_slot == slot) return GVI_OK;     // products of this slot are still resident
   s.prep_slot = slot;
   const int d = s.d, dp = d + (d & 1);
   const size_t lds = (size_t)(4 * d * d + 2 * dp + 3 * d) * 8 + (size_t)dp * 4 + 16;
-  if (d <= 8) hipLaunchKernelGGL(prep_kernel<1>, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
-  else if (d <= 16) hipLaunchKernelGGL(prep_kernel<4>, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
-  else if (d <= 32) hipLaunchKernelGGL(prep_kernel<16>, dim3(s.K), dim3(64), lds, c->stream, s.dev(), mu, Sigma);
+  if (d <= 8) hipLaunchKernelGGL(prep_kernel<1>, dim3(s.K), dim3(64), lds, st, s.dev(), mu, Sigma);
+  else if (d <= 16) hipLaunchKernelGGL(prep_kernel<4>, dim3(s.K), dim3(64), lds, st, s.dev(), mu, Sigma);
+  else if (d <= 32) hipLaunchKernelGGL(prep_kernel<16>, dim3(s.K), dim3(64), lds, st, s.dev(), mu, Sigma);
   else return fail(c, GVI_ERR_UNSUPPORTED, "factor dimension > 32");
   HIPCK(c, hipGetLastError());
   return GVI_OK;
 }
 
 // moments (full=1) or cost (full=0) pass for one set; prep must have run for (mu, Sigma).
-gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full) {
+gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full,
+                       hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
   bool reg = reg_supported(s.kind, s.d, s.m) && !psi_ext && c->variant != 1;
   if (c->variant == 2 && !reg && !psi_ext)
     return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
@@ -271,15 +286,15 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   if (c->profile) {
     for (int e = 0; e < 2; ++e)
       if (!s.ev[which][e]) HIPCK(c, hipEventCreate(&s.ev[which][e]));
-    HIPCK(c, hipEventRecord(s.ev[which][0], c->stream));
+    HIPCK(c, hipEventRecord(s.ev[which][0], st));
   }
   if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
     // auto: the operand-resident kernel wins for the cost pass (operands hoisted into VGPRs, 2 waves/SIMD),
     // the LDS-operand kernel for the full pass (the 91 accumulators own the register file)
-    if (c->variant == 3 || (c->variant == 0 && !full)) done = dispatch_wide(s, a, grid, c->stream);
-    if (!done && !dispatch_reg(s, a, grid, c->stream)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
+    if (c->variant == 3 || (c->variant == 0 && !full)) done = dispatch_wide(s, a, grid, st);
+    if (!done && !dispatch_reg(s, a, grid, st)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
     if (s.d > 32) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel supports d <= 32");
     const int d = s.d, m = s.m;
@@ -291,23 +306,24 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(moments_generic_kernel, dim3(s.K, s.nchunk), dim3(GEN_BS), lds, c->stream, a);
+    hipLaunchKernelGGL(moments_generic_kernel, dim3(s.K, s.nchunk), dim3(GEN_BS), lds, st, a);
   }
   HIPCK(c, hipGetLastError());
   if (c->profile) {
-    HIPCK(c, hipEventRecord(s.ev[which][1], c->stream));
+    HIPCK(c, hipEventRecord(s.ev[which][1], st));
     s.ev_set[which] = true;
   }
   return GVI_OK;
 }
 
 gvi_status run_epilogue(gvi_ctx* c, FactorSet& s, int full, double* Ephi, double* cost, double* Vdmu,
-                        double* Vddmu, double* Ex, double* Exx) {
+                        double* Vddmu, double* Ex, double* Exx, hipStream_t st = nullptr) {
+  if (!st) st = c->stream;
   EpiArgs e;
   e.f = s.dev(); e.partial = s.partial.d(); e.nchunk = s.nchunk; e.full = full;
   e.Ephi = Ephi; e.cost = cost; e.Vdmu = Vdmu; e.Vddmu = Vddmu; e.E_xmuphi = Ex; e.E_xxphi = Exx;
   const size_t lds = (size_t)(npairs(s.d) + 2 * s.d * s.d) * 8;
-  hipLaunchKernelGGL(epilogue_kernel, dim3(s.K), dim3(64), lds, c->stream, e);
+  hipLaunchKernelGGL(epilogue_kernel, dim3(s.K), dim3(64), lds, st, e);
   HIPCK(c, hipGetLastError());
   return GVI_OK;
 }
@@ -380,6 +396,16 @@ gvi_status launch_bcr_forward(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
 
 template <bool PIVOT>
 gvi_status launch_bcr_forward_n(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
+  switch (c->n) {                      // exact sizes: register-resident elimination (kernels_bt.hpp)
+    case 1: return launch_bcr_forward<PIVOT, 101>(c, a, pl);
+    case 2: return launch_bcr_forward<PIVOT, 102>(c, a, pl);
+    case 3: return launch_bcr_forward<PIVOT, 103>(c, a, pl);
+    case 4: return launch_bcr_forward<PIVOT, 104>(c, a, pl);
+    case 6: return launch_bcr_forward<PIVOT, 106>(c, a, pl);
+    case 8: return launch_bcr_forward<PIVOT, 108>(c, a, pl);
+    case 12: return launch_bcr_forward<PIVOT, 112>(c, a, pl);
+    default: break;
+  }
   if (c->n <= 6) return launch_bcr_forward<PIVOT, 6>(c, a, pl);
   if (c->n <= 8) return launch_bcr_forward<PIVOT, 8>(c, a, pl);
   if (c->n <= 12) return launch_bcr_forward<PIVOT, 12>(c, a, pl);
@@ -398,8 +424,94 @@ gvi_status run_bcr_forward(gvi_ctx* c, const double* D, const double* U, const d
   return pivot ? launch_bcr_forward_n<true>(c, a, pl) : launch_bcr_forward_n<false>(c, a, pl);
 }
 
+// ---- segmented BCR (kernels_bcr_seg.hpp): three launches instead of ~2 log2(T) ----
+struct SegPass { int level0, m, S, prev0, top; };
+struct SegPlan { std::vector<SegPass> passes; int threads; };
+
+bool seg_supported(int n) { return n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12; }
+
+SegPlan seg_plan(const gvi_ctx* c) {
+  const int n = c->n, T = c->T;
+  const int m_seg = n <= 6 ? 5 : (n <= 8 ? 4 : 3);
+  const int cap = n <= 6 ? 64 : (n <= 8 ? 32 : 16);
+  SegPlan p;
+  const int nlevels = bcr_levels(T);
+  int level0 = 0, prev0 = 0;
+  auto alive = [&](int l) { return (int)(((int64_t)T + (1 << l) - 1) >> l); };
+  while (alive(level0) > cap) {
+    p.passes.push_back({level0, m_seg, 1 << m_seg, prev0, 0});
+    prev0 = level0;
+    level0 += m_seg;
+  }
+  p.passes.push_back({level0, nlevels - level0, alive(level0), prev0, 1});
+  p.threads = 1024;
+  return p;
+}
+
+template <bool PIVOT, int N>
+gvi_status launch_seg(gvi_ctx* c, SegArgs a, const SegPlan& pl) {
+  static bool attr = false;
+  if (!attr) {
+    HIPCK(c, hipFuncSetAttribute((const void*)bcr_seg_forward_kernel<PIVOT, N>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCK(c, hipFuncSetAttribute((const void*)bcr_seg_backward_kernel<N>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  const bool rhs = a.rhs != nullptr;
+  for (const SegPass& ps : pl.passes) {
+    a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.prev0 = ps.prev0; a.top = ps.top;
+    const size_t lds = seg_fwd_lds_doubles(N, ps.S, rhs) * 8;
+    if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: LDS budget");
+    const int stride = ps.S << ps.level0;
+    const int blocks = ps.top ? 1 : (c->T + stride - 1) / stride;
+    hipLaunchKernelGGL((bcr_seg_forward_kernel<PIVOT, N>), dim3(blocks), dim3(pl.threads), lds, c->stream, a);
+  }
+  if (rhs || a.need_E) {
+    for (int i = (int)pl.passes.size() - 2; i >= 0; --i) {
+      const SegPass& ps = pl.passes[i];
+      a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.prev0 = ps.prev0; a.top = 0;
+      const size_t lds = seg_bwd_lds_doubles(N, ps.S, rhs) * 8;
+      const int stride = ps.S << ps.level0;
+      hipLaunchKernelGGL((bcr_seg_backward_kernel<N>), dim3((c->T + stride - 1) / stride), dim3(pl.threads), lds,
+                         c->stream, a);
+    }
+  }
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+template <bool PIVOT>
+gvi_status launch_seg_n(gvi_ctx* c, const SegArgs& a, const SegPlan& pl) {
+  switch (c->n) {
+    case 1: return launch_seg<PIVOT, 1>(c, a, pl);
+    case 2: return launch_seg<PIVOT, 2>(c, a, pl);
+    case 3: return launch_seg<PIVOT, 3>(c, a, pl);
+    case 4: return launch_seg<PIVOT, 4>(c, a, pl);
+    case 6: return launch_seg<PIVOT, 6>(c, a, pl);
+    case 8: return launch_seg<PIVOT, 8>(c, a, pl);
+    case 12: return launch_seg<PIVOT, 12>(c, a, pl);
+  }
+  return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: block size");
+}
+
+gvi_status run_seg(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, bool pivot,
+                   bool need_E, double* SigD, double* SigU, double* x, double* hld) {
+  BcrWs w;
+  GVICK(ensure_chain_ws(c, w));
+  SegArgs a;
+  a.T = c->T; a.n = c->n; a.need_E = need_E ? 1 : 0;
+  a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.w = w;
+  a.SigD = SigD; a.SigU = SigU; a.x = x; a.hld = hld;
+  a.level0 = a.m = a.S = a.prev0 = a.top = 0;
+  const SegPlan pl = seg_plan(c);
+  return pivot ? launch_seg_n<true>(c, a, pl) : launch_seg_n<false>(c, a, pl);
+}
+
 // log-det (+ optionally marginals) of the chain (D, U) device arrays
 gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* SigD, double* SigU, double* hld) {
+  if (seg_supported(c->n) && c->bcr_variant != 1)
+    return run_seg(c, D, U, nullptr, 1.0, false, SigD != nullptr, SigD, SigU, nullptr, hld);
   BcrWs w;
   BcrPlan pl;
   GVICK(run_bcr_forward(c, D, U, nullptr, 1.0, false, SigD != nullptr, w, pl));
@@ -423,6 +535,8 @@ gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* S
 }
 
 gvi_status run_bt_solve(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, double* x) {
+  if (seg_supported(c->n) && c->bcr_variant != 1)
+    return run_seg(c, D, U, rhs, scale, true, false, nullptr, nullptr, x, nullptr);
   BcrWs w;
   BcrPlan pl;
   GVICK(run_bcr_forward(c, D, U, rhs, scale, true, false, w, pl));
@@ -490,6 +604,11 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
+  if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
+  if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
+      hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
+    return fail(nullptr, GVI_ERR_HIP, "event / host-mapped slot allocation failed");
   *out = c.release();
   return GVI_OK;
 }
@@ -499,6 +618,8 @@ gvi_status gvi_ctx_destroy(gvi_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->sets.clear();
+  if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+  if (ctx->host_slot) (void)hipHostFree(ctx->host_slot);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return GVI_OK;
@@ -655,6 +776,8 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   HIPCK(ctx, s->H.ensure((size_t)K * std::max(m, 1) * d * 8));
   HIPCK(ctx, s->u0.ensure((size_t)K * std::max(m, 1) * 8));
   GVICK(ensure_set_buffers(ctx, *s));
+  HIPCK(ctx, hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+  HIPCK(ctx, hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
   ctx->sets.push_back(std::move(s));
   ctx->ngd.ready = false;
   if (set_id) *set_id = (int)ctx->sets.size() - 1;
@@ -904,7 +1027,37 @@ static gvi_status ngd_check(gvi_ctx* ctx) {
   return GVI_OK;
 }
 
-// marginals + log-det of Lam[i], then gather every set's (mu_k, Sigma_k) into slot i
+static SetList make_set_list(gvi_ctx* ctx, int slot) {
+  SetList L;
+  L.nsets = (int)ctx->sets.size();
+  for (int i = 0; i < L.nsets; ++i) {
+    FactorSet& s = *ctx->sets[i];
+    SetDesc& d = L.s[i];
+    d.K = s.K; d.d = s.d;
+    d.start = s.dstart.i(); d.ptr = s.dptr.i(); d.idx = s.didx.i();
+    d.Vdmu = s.Vdmu.d(); d.Vddmu = s.Vddmu.d();
+    d.mu_k = s.mu_k[slot].d(); d.Sigma_k = s.Sigma_k[slot].d();
+    d.cost = s.cost.d();
+  }
+  return L;
+}
+
+// fork: every set stream waits for what is queued on the main stream so far
+static gvi_status ngd_fork(gvi_ctx* ctx) {
+  HIPCK(ctx, hipEventRecord(ctx->fork, ctx->stream));
+  for (auto& s : ctx->sets) HIPCK(ctx, hipStreamWaitEvent(s->st, ctx->fork, 0));
+  return GVI_OK;
+}
+// join: the main stream waits for every set stream
+static gvi_status ngd_join(gvi_ctx* ctx) {
+  for (auto& s : ctx->sets) {
+    HIPCK(ctx, hipEventRecord(s->done, s->st));
+    HIPCK(ctx, hipStreamWaitEvent(ctx->stream, s->done, 0));
+  }
+  return GVI_OK;
+}
+
+// marginals + log-det of Lam[i], then gather every set's (mu_k, Sigma_k) into slot i (one launch)
 static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, nn = nn_(ctx);
@@ -913,37 +1066,42 @@ static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
   double* sD = g.Sig[i].d();
   double* sU = sD + T * nn;
   GVICK(run_bt_factor(ctx, D, U, sD, sU, g.hld[i].d()));
+  if (ctx->sets.empty()) return GVI_OK;
+  if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
+  int64_t maxwork = 0;
   for (auto& s : ctx->sets) {
     if (s->prep_slot == i) s->prep_slot = -1;
-    GVICK(run_gather(ctx, *s, g.mu[i].d(), sD, sU, s->mu_k[i].d(), s->Sigma_k[i].d()));
+    maxwork = std::max<int64_t>(maxwork, (int64_t)s->K * (s->d + s->d * s->d));
   }
+  hipLaunchKernelGGL(gather_all_kernel, dim3((unsigned)((maxwork + 255) / 256), (unsigned)ctx->sets.size()), dim3(256), 0,
+                     ctx->stream, make_set_list(ctx, i), ctx->n, g.mu[i].d(), sD, sU);
+  HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
 
-// sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0]
+// sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0]; the sets run concurrently on their own streams
 static gvi_status ngd_cost_local(gvi_ctx* ctx, int i) {
   NgdState& g = ctx->ngd;
-  int first = 1;
-  if (ctx->sets.empty()) HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
+  if (ctx->sets.empty()) { HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream)); return GVI_OK; }
+  GVICK(ngd_fork(ctx));
   for (auto& s : ctx->sets) {
     if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
-    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i));
-    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0));
-    GVICK(run_epilogue(ctx, *s, 0, nullptr, s->cost.d(), nullptr, nullptr, nullptr, nullptr));
-    hipLaunchKernelGGL(cost_sum_kernel, dim3(1), dim3(256), 0, ctx->stream, s->K, s->cost.d(), g.exch1.d(), first);
-    HIPCK(ctx, hipGetLastError());
-    first = 0;
+    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i, s->st));
+    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0, s->st));
+    GVICK(run_epilogue(ctx, *s, 0, nullptr, s->cost.d(), nullptr, nullptr, nullptr, nullptr, s->st));
   }
+  GVICK(ngd_join(ctx));
+  hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, i), g.exch1.d());
+  HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
 
 static gvi_status ngd_cost_finish(gvi_ctx* ctx, int i, double* out) {
   NgdState& g = ctx->ngd;
-  hipLaunchKernelGGL(cost_total_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), g.total.d());
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev);
   HIPCK(ctx, hipGetLastError());
-  double v = 0.0;
-  GVICK(d2h(ctx, &v, g.total.p, 8));
   GVICK(sync(ctx));
+  const double v = ctx->host_slot[0] + ctx->host_slot[1];     // cost_value = sum of factor costs + 1/2 log det
   g.cost[i] = v;
   g.cost_valid[i] = true;
   if (out) *out = v;
@@ -1025,14 +1183,19 @@ gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx) {
   double* eg = g.exch0.d();
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
-  HIPCK(ctx, hipMemsetAsync(eg, 0, (T * n + bt_count(ctx)) * 8, ctx->stream));
+  if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
+  GVICK(ngd_fork(ctx));
   for (auto& s : ctx->sets) {
     if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
-    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i));
-    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 1));
-    GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), s->cost.d(), s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr));
-    GVICK(run_scatter(ctx, *s, s->Vdmu.d(), s->Vddmu.d(), eg, eD, eU));
+    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i, s->st));
+    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 1, s->st));
+    GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), s->cost.d(), s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr, s->st));
   }
+  GVICK(ngd_join(ctx));
+  const int64_t total = (int64_t)T * (n + 2 * nn);
+  hipLaunchKernelGGL(bt_scatter_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     make_set_list(ctx, i), ctx->T, ctx->n, eg, eD, eU);
+  HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
 
@@ -1040,14 +1203,11 @@ gvi_status gvi_ngd_gradients_finish(gvi_ctx* ctx) {
   GVICK(ngd_check(ctx));
   HIPCK(ctx, hipSetDevice(ctx->device));
   NgdState& g = ctx->ngd;
-  const size_t T = ctx->T, n = ctx->n, nn = n * n, bt = bt_count(ctx);
+  const size_t T = ctx->T, n = ctx->n, nn = n * n;
   double* eg = g.exch0.d();
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
-  hipLaunchKernelGGL(sub_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)bt, eD,
-                     g.Lam[g.cur].d(), g.dLam.d());
-  HIPCK(ctx, hipGetLastError());
-  return run_bt_solve(ctx, eD, eU, eg, -1.0, g.dmu.d());
+  return run_bt_solve(ctx, eD, eU, eg, -1.0, g.dmu.d());     // dprecision = V - Lambda is formed inside the trial
 }
 
 gvi_status gvi_ngd_gradients(gvi_ctx* ctx) {
@@ -1061,10 +1221,8 @@ gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step) {
   NgdState& g = ctx->ngd;
   const size_t Tn = (size_t)ctx->T * ctx->n, bt = bt_count(ctx);
   const int c = g.cur, t = 1 - c;
-  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((Tn + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn, step,
-                     g.mu[c].d(), g.dmu.d(), g.mu[t].d());
-  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)bt, step,
-                     g.Lam[c].d(), g.dLam.d(), g.Lam[t].d());
+  hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn,
+                     (int64_t)bt, step, g.mu[c].d(), g.dmu.d(), g.Lam[c].d(), g.exch0.d() + Tn, g.mu[t].d(), g.Lam[t].d());
   HIPCK(ctx, hipGetLastError());
   g.cost_valid[t] = false;
   GVICK(ngd_refresh(ctx, t));
@@ -1142,14 +1300,24 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
   GVICK(ngd_check(ctx));
   HIPCK(ctx, hipSetDevice(ctx->device));
   NgdState& g = ctx->ngd;
-  const size_t T = ctx->T, n = ctx->n, nn = n * n;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n, bt = bt_count(ctx);
   if (dmu) GVICK(d2h(ctx, dmu, g.dmu.p, T * n * 8));
-  if (dD) GVICK(d2h(ctx, dD, g.dLam.p, T * nn * 8));
-  if (dU && T > 1) GVICK(d2h(ctx, dU, g.dLam.d() + T * nn, (T - 1) * nn * 8));
   if (gq) GVICK(d2h(ctx, gq, g.exch0.p, T * n * 8));
-  if (VD) GVICK(d2h(ctx, VD, g.exch0.d() + T * n, T * nn * 8));
-  if (VU && T > 1) GVICK(d2h(ctx, VU, g.exch0.d() + T * n + T * nn, (T - 1) * nn * 8));
-  return sync(ctx);
+  std::vector<double> V, L;
+  if (dD || dU || VD || VU) {
+    V.resize(bt);
+    GVICK(d2h(ctx, V.data(), g.exch0.d() + T * n, bt * 8));
+  }
+  if (dD || dU) {
+    L.resize(bt);
+    GVICK(d2h(ctx, L.data(), g.Lam[g.cur].p, bt * 8));
+  }
+  GVICK(sync(ctx));
+  if (VD) memcpy(VD, V.data(), T * nn * 8);
+  if (VU && T > 1) memcpy(VU, V.data() + T * nn, (T - 1) * nn * 8);
+  if (dD) for (size_t j = 0; j < T * nn; ++j) dD[j] = V[j] - L[j];          // dprecision = Vddmu - Lambda
+  if (dU) for (size_t j = 0; j < (T - 1) * nn; ++j) dU[j] = V[T * nn + j] - L[T * nn + j];
+  return GVI_OK;
 }
 
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on) {

@@ -1,0 +1,482 @@
+// Segmented block cyclic reduction: the chain solve / log-det / selected inverse in THREE launches.
+//
+// The per-level BCR of kernels_bt.hpp needs ~2 log2(T) dependent launches and every tiny launch costs
+// ~5 us on this part (profiles/r01_c_*): at T = 1025 the two chain operations of an NGD iteration were
+// 260 us of mostly launch floor.  Here a workgroup owns a SEGMENT of S = 2^m consecutive alive nodes and
+// runs m levels of cyclic reduction on it inside LDS (workgroup barriers only, eliminations in
+// registers, see bcr_eliminate_reg); segments never need each other within a pass:
+//
+//   pass A  (grid = T / S segments)   levels 0 .. m-1 inside every segment; the segment's first node
+//                                     survives; pending updates that cross a segment boundary and the
+//                                     per-node factors (E, GA, GB, v) go to global memory
+//   pass B  (one workgroup)           the <= CAP surviving nodes: fold the pending updates, remaining
+//                                     levels, root, log-det; then the BACKWARD recursion for the same
+//                                     nodes (solution / selected inverse), still in LDS
+//   pass C  (grid = T / S segments)   backward recursion inside every segment
+//
+// (If more than CAP nodes survive pass A it is repeated at the coarser spacing -- not needed below
+// T ~ 2 000 at n = 6.)  The algebra is exactly that of kernels_bt.hpp (same elimination tree, same
+// fixed summation orders => deterministic); only where the blocks live and who waits for whom changes.
+//
+// Instantiated for the block sizes with a register elimination (N in {1,2,3,4,6,8,12}); other n use
+// the per-level kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_bt.hpp"
+
+namespace gvi {
+
+// LDS-only workgroup barrier: unlike __syncthreads() it does not drain outstanding global stores
+// (vmcnt); everything the phases exchange goes through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct SegArgs {
+  int T, n;
+  int level0;        // first level of this pass; node spacing st = 1 << level0
+  int m;             // levels handled in this pass
+  int S;             // local slots per workgroup (segment size 2^m, or the number of alive nodes in the top pass)
+  int prev0;         // first level of the previous pass (pending updates of levels [prev0, level0) are folded at load)
+  int top;           // last pass: node 0 is the root, log-det, then the backward recursion for these nodes
+  int need_E;        // selected inverse wanted (else log-det only / solve)
+  const double* D;
+  const double* U;
+  const double* rhs;     // null: factor; else solve
+  double rhs_scale;
+  BcrWs w;
+  double* SigD;      // [T][n][n]   (marginals)
+  double* SigU;      // [T-1][n][n]
+  double* x;         // [T][n]      (solve)
+  double* hld;       // [1]
+};
+
+constexpr int SEG_MAX_WAVES = 16;
+// forward / top kernel: 5 block arrays, 4 rhs vectors, per-wave backward scratch, reduction area
+__host__ __device__ inline size_t seg_fwd_lds_doubles(int n, int S, bool rhs) {
+  return (size_t)5 * S * n * n + (rhs ? (size_t)4 * (S + 1) * n : 0) + (size_t)SEG_MAX_WAVES * (4 * n * n + n) + 1600;
+}
+__host__ __device__ inline size_t seg_bwd_lds_doubles(int n, int S, bool rhs) {
+  return rhs ? (size_t)(S + 1) * n + 16 : (size_t)3 * (S + 1) * n * n + (size_t)SEG_MAX_WAVES * 2 * n * n;
+}
+
+// ---- forward elimination of one node from LDS-resident operands (register Gauss-Jordan) ----
+// Dl_e: its effective diagonal block; Ua = A[a,e], Ub = A[e,b] (LDS, null when absent); y_e (LDS).
+// Results: per-node factors to global (node id x), pending updates to the LDS slot arrays AND global.
+template <bool PIVOT, int N>
+__device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e, const double* Ua, const double* Ub,
+                                     const double* y_e, double* CLs, double* CRs, double* NUs, double* yLs,
+                                     double* yRs, double* Tl, int lane) {
+  constexpr int nn = N * N, NC = 4 * N + 1;
+  const bool has_a = Ua != nullptr, has_b = Ub != nullptr, rhs = a.rhs != nullptr;
+  const int cE = N, cA = a.need_E ? 2 * N : N, cB = cA + N, cY = cB + N;
+  double col[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) col[r] = 0.0;
+  if (lane < N) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) col[r] = Dl_e[lane * N + r];        // symmetric: row = column
+  } else if (a.need_E && lane < 2 * N) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) col[r] = (r == lane - cE) ? 1.0 : 0.0;
+  } else if (lane >= cA && lane < cA + N) {
+    if (has_a) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) col[r] = Ua[(lane - cA) * N + r];   // column j of Ua^T = row j of Ua
+    }
+  } else if (lane >= cB && lane < cB + N) {
+    if (has_b) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) col[r] = Ub[r * N + (lane - cB)];
+    }
+  } else if (rhs && lane == cY) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) col[r] = y_e[r];
+  }
+  double pivs[N];
+  int bad = 0;
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    double ap[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) ap[r] = readlane_f64(col[r], p);
+    if (PIVOT) {
+      int rs = p;
+      double best = fabs(ap[p]);
+#pragma unroll
+      for (int r = p + 1; r < N; ++r)
+        if (fabs(ap[r]) > best) { best = fabs(ap[r]); rs = r; }
+#pragma unroll
+      for (int r = p + 1; r < N; ++r) {
+        if (r == rs) {
+          const double t = col[p]; col[p] = col[r]; col[r] = t;
+          const double u = ap[p]; ap[p] = ap[r]; ap[r] = u;
+        }
+      }
+    }
+    const double piv = ap[p];
+    if (!(piv > 0.0)) bad = 1;
+    pivs[p] = piv;
+    double ip = __builtin_amdgcn_rcp(piv);               // reciprocal + two Newton steps (full fp64 accuracy)
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
+    ip = fma(fma(-piv, ip, 1.0), ip, ip);
+    const double f = col[p] * ip;
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      if (r != p) col[r] = fma(-ap[r], f, col[r]);
+    col[p] = f;
+  }
+  double lg = 0.0;
+#pragma unroll
+  for (int p = 0; p < N; ++p) lg = (lane == p) ? pivs[p] : lg;
+  lg = lane < N ? log(lg) : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+  if (lane == 0) { a.w.logp[x] = lg; a.w.bad[x] = bad; }
+  // ---- park the reduced tile [I | E | GA | GB | v] in LDS, then finish element-wise on all lanes ----
+  if (lane < NC) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) Tl[r * NC + lane] = col[r];
+  }
+  wave_lds_sync();
+  for (int el = lane; el < nn; el += 64) {
+    const int r = el / N, c = el % N;
+    if (a.need_E) a.w.E[(size_t)x * nn + el] = Tl[r * NC + cE + c];
+    if (has_a) {
+      a.w.GA[(size_t)x * nn + el] = Tl[r * NC + cA + c];
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) v = fma(Ua[r * N + k], Tl[k * NC + cA + c], v);
+      CLs[el] = v;
+      a.w.CL[(size_t)x * nn + el] = v;
+    }
+    if (has_b) {
+      a.w.GB[(size_t)x * nn + el] = Tl[r * NC + cB + c];
+      double v = 0.0, u = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const double gb = Tl[k * NC + cB + c];
+        v = fma(Ub[k * N + r], gb, v);
+        if (has_a) u = fma(Ua[r * N + k], gb, u);
+      }
+      CRs[el] = v;
+      a.w.CR[(size_t)x * nn + el] = v;
+      if (has_a) { NUs[el] = -u; a.w.NU[(size_t)x * nn + el] = -u; }
+    }
+  }
+  if (rhs && lane < N) {
+    const int r = lane;
+    a.w.v[(size_t)x * N + r] = Tl[r * NC + cY];
+    if (has_a) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) v = fma(Ua[r * N + k], Tl[k * NC + cY], v);
+      yLs[r] = v;
+      a.w.yL[(size_t)x * N + r] = v;
+    }
+    if (has_b) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) v = fma(Ub[k * N + r], Tl[k * NC + cY], v);
+      yRs[r] = v;
+      a.w.yR[(size_t)x * N + r] = v;
+    }
+  }
+  wave_lds_sync();
+}
+
+// ---- backward step of one node: selected inverse (marginals) ----
+// Saa / Sbb / Sab: LDS blocks of its neighbours' covariance; writes Sig_ee, Sig[e,a], Sig[e,b] to the
+// LDS slots and to global.
+__device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int level, bool has_b, const double* Saa,
+                                         const double* Sbb, const double* Sab, bool sab_transposed, double* See_s,
+                                         double* SL_s, double* SR_s, double* scratch, int lane) {
+  const int n = a.n, nn = n * n;
+  double* GA = scratch;          // [n][n]
+  double* GB = GA + nn;
+  for (int el = lane; el < nn; el += 64) {
+    GA[el] = a.w.GA[(size_t)x * nn + el];
+    if (has_b) GB[el] = a.w.GB[(size_t)x * nn + el];
+  }
+  wave_lds_sync();
+  for (int el = lane; el < nn; el += 64) {
+    const int r = el / n, c = el % n;
+    double sl = 0.0, sr = 0.0;
+    for (int k = 0; k < n; ++k) {
+      sl += GA[r * n + k] * Saa[k * n + c];
+      if (has_b) {
+        const double sab_kc = sab_transposed ? Sab[c * n + k] : Sab[k * n + c];   // Sig_ab[k][c]
+        const double sba_kc = sab_transposed ? Sab[k * n + c] : Sab[c * n + k];   // Sig_ba[k][c] = Sig_ab[c][k]
+        sl += GB[r * n + k] * sba_kc;
+        sr += GA[r * n + k] * sab_kc + GB[r * n + k] * Sbb[k * n + c];
+      }
+    }
+    SL_s[el] = -sl;
+    SR_s[el] = -sr;
+    a.w.SL[(size_t)x * nn + el] = -sl;
+    if (has_b) a.w.SR[(size_t)x * nn + el] = -sr;
+  }
+  wave_lds_sync();
+  for (int el = lane; el < nn; el += 64) {
+    const int r = el / n, c = el % n;
+    double see = a.w.E[(size_t)x * nn + el];
+    for (int k = 0; k < n; ++k) {
+      see -= SL_s[r * n + k] * GA[c * n + k];
+      if (has_b) see -= SR_s[r * n + k] * GB[c * n + k];
+    }
+    See_s[el] = see;
+    a.SigD[(size_t)x * nn + el] = see;
+    if (level == 0) {                                  // tridiagonal blocks of the original chain
+      a.SigU[(size_t)xa * nn + c * n + r] = SL_s[el];  // Sig[a,e] = Sig[e,a]^T
+      if (has_b) a.SigU[(size_t)x * nn + el] = SR_s[el];
+    }
+  }
+  wave_lds_sync();
+}
+
+// Fold the pending updates of levels [prev0, level0) into node x's diagonal block / rhs (global reads).
+__device__ inline double seg_fold_D(const SegArgs& a, int x, int el) {
+  const int nn = a.n * a.n;
+  double v = (a.level0 == 0 ? a.D : a.w.Deff)[(size_t)x * nn + el];
+  for (int l = a.prev0; l < a.level0; ++l) {
+    const int h = 1 << l;
+    if (x - h >= 0) v -= a.w.CR[(size_t)(x - h) * nn + el];
+    if (x + h < a.T) v -= a.w.CL[(size_t)(x + h) * nn + el];
+  }
+  return v;
+}
+__device__ inline double seg_fold_y(const SegArgs& a, int x, int r) {
+  const int n = a.n;
+  double v = a.level0 == 0 ? a.rhs_scale * a.rhs[(size_t)x * n + r] : a.w.yeff[(size_t)x * n + r];
+  for (int l = a.prev0; l < a.level0; ++l) {
+    const int h = 1 << l;
+    if (x - h >= 0) v -= a.w.yR[(size_t)(x - h) * n + r];
+    if (x + h < a.T) v -= a.w.yL[(size_t)(x + h) * n + r];
+  }
+  return v;
+}
+
+// ---- pass A / B forward (+ pass B backward): one workgroup per segment ----
+template <bool PIVOT, int N>
+__global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
+  extern __shared__ double sm[];
+  constexpr int nn = N * N;
+  const int T = a.T, S = a.S, st = 1 << a.level0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const bool rhs = a.rhs != nullptr;
+  const int x0 = (int)blockIdx.x * S * st;
+  double* Dl = sm;                    // [S][nn] effective diagonal blocks
+  double* Cl = Dl + S * nn;           // [S][nn] coupling A[x_j, x_{j+1}] at this pass's spacing
+  double* NUl = Cl + S * nn;          // [S][nn] new couplings, indexed by the eliminated node
+  double* CLl = NUl + S * nn;         // [S][nn] pending update to the left neighbour
+  double* CRl = CLl + S * nn;         // [S][nn] pending update to the right neighbour
+  double* yl = CRl + S * nn;          // [S+1][N] (rhs only)
+  double* yLl = yl + (rhs ? (S + 1) * N : 0);
+  double* yRl = yLl + (rhs ? (S + 1) * N : 0);
+  double* xl = yRl + (rhs ? (S + 1) * N : 0);    // [S+1][N] solution (top pass backward)
+  double* scratch = xl + (rhs ? (S + 1) * N : 0);  // [waves][4 nn + N]: elimination tile / backward-step scratch
+  double* red = scratch + SEG_MAX_WAVES * (4 * nn + N);  // [1024] doubles + [1024] ints: log-det reduction
+  // number of local nodes that exist
+  int cnt = 0;
+  for (int j = 0; j < S; ++j) if (x0 + j * st < T) cnt = j + 1;
+  const bool ext_right = x0 + S * st < T;          // the next segment's first node exists
+  // ---- load + fold ----
+  for (int e = tid; e < cnt * nn; e += blockDim.x) {
+    const int j = e / nn, el = e % nn, x = x0 + j * st;
+    const double v = seg_fold_D(a, x, el);
+    Dl[e] = v;
+    if (j == 0 && !a.top) a.w.Deff[(size_t)x * nn + el] = v;      // the survivor's base for the next pass
+    if (x + st < T) Cl[e] = (a.level0 == 0 ? a.U + (size_t)x * nn : a.w.NU + (size_t)(x + st / 2) * nn)[el];
+  }
+  if (rhs) {
+    for (int e = tid; e < cnt * N; e += blockDim.x) {
+      const int j = e / N, r = e % N, x = x0 + j * st;
+      const double v = seg_fold_y(a, x, r);
+      yl[e] = v;
+      if (j == 0 && !a.top) a.w.yeff[(size_t)x * N + r] = v;
+    }
+  }
+  __syncthreads();
+  // ---- m local levels ----
+  for (int lam = 0; lam < a.m; ++lam) {
+    const int h2 = 1 << lam;
+    // eliminated local nodes: odd multiples of h2 that exist
+    int nel = 0;
+    for (int j = h2; j < cnt; j += 2 * h2) ++nel;
+    for (int u = wave; u < nel; u += nwaves) {
+      const int j = (2 * u + 1) * h2, x = x0 + j * st;
+      const int ja = j - h2, jb = j + h2;
+      const bool has_b = (jb < cnt) || (jb == S && ext_right && !a.top);
+      const double* Ua = lam == 0 ? Cl + ja * nn : NUl + (j - h2 / 2) * nn;
+      const double* Ub = !has_b ? nullptr : (lam == 0 ? Cl + j * nn : NUl + (j + h2 / 2) * nn);
+      seg_eliminate<PIVOT, N>(a, x, Dl + j * nn, Ua, Ub, yl + j * N, CLl + j * nn, CRl + j * nn, NUl + j * nn,
+                              yLl + j * N, yRl + j * N, scratch + wave * (4 * nn + N), lane);
+    }
+    lds_barrier();
+    // eager update of the local survivors of this level (node 0 only in the top pass: elsewhere its
+    // left-hand updates live in another segment, so it folds both sides from global in the next pass)
+    const int first = a.top ? 0 : 2 * h2;
+    for (int j = first + wave * 2 * h2; j < cnt; j += nwaves * 2 * h2) {
+      const bool lft = j - h2 >= 0, rgt = j + h2 < cnt;
+      for (int el = lane; el < nn; el += 64) {
+        double v = Dl[j * nn + el];
+        if (lft) v -= CRl[(j - h2) * nn + el];
+        if (rgt) v -= CLl[(j + h2) * nn + el];
+        Dl[j * nn + el] = v;
+      }
+      if (rhs && lane < N) {
+        double v = yl[j * N + lane];
+        if (lft) v -= yRl[(j - h2) * N + lane];
+        if (rgt) v -= yLl[(j + h2) * N + lane];
+        yl[j * N + lane] = v;
+      }
+    }
+    lds_barrier();
+  }
+  if (!a.top) return;
+  // ---- root (node 0), log-det ----
+  if (wave == 0)
+    seg_eliminate<PIVOT, N>(a, 0, Dl, nullptr, nullptr, yl, CLl, CRl, NUl, yLl, yRl, scratch, lane);
+  __syncthreads();                                   // factors of this pass are read back from global below
+  if (a.hld) {
+    int* redb = (int*)(red + 1024);
+    double s = 0.0;
+    int bflag = 0;
+    for (int t = tid; t < T; t += blockDim.x) { s += a.w.logp[t]; bflag |= a.w.bad[t]; }
+    red[tid] = s; redb[tid] = bflag;
+    lds_barrier();
+    for (int wdt = blockDim.x / 2; wdt > 0; wdt >>= 1) {
+      if (tid < wdt) { red[tid] += red[tid + wdt]; redb[tid] |= redb[tid + wdt]; }
+      lds_barrier();
+    }
+    if (tid == 0) a.hld[0] = redb[0] ? __builtin_nan("") : 0.5 * red[0];
+    lds_barrier();
+  }
+  // ---- backward recursion for the nodes of this pass ----
+  if (rhs) {                                          // solve: x_e = v - GA x_a - GB x_b
+    if (tid < N) { const double v = a.w.v[tid]; xl[tid] = v; a.x[tid] = v; }
+    lds_barrier();
+    for (int lam = a.m - 1; lam >= 0; --lam) {
+      const int h2 = 1 << lam;
+      int nel = 0;
+      for (int j = h2; j < cnt; j += 2 * h2) ++nel;
+      for (int e = tid; e < nel * N; e += blockDim.x) {
+        const int u = e / N, r = e % N, j = (2 * u + 1) * h2, x = x0 + j * st;
+        const int ja = j - h2, jb = j + h2;
+        double xe = a.w.v[(size_t)x * N + r];
+        const double* GA = a.w.GA + (size_t)x * nn + r * N;
+        for (int k = 0; k < N; ++k) xe -= GA[k] * xl[ja * N + k];
+        if (jb < cnt) {
+          const double* GB = a.w.GB + (size_t)x * nn + r * N;
+          for (int k = 0; k < N; ++k) xe -= GB[k] * xl[jb * N + k];
+        }
+        xl[j * N + r] = xe;
+        a.x[(size_t)x * N + r] = xe;
+      }
+      lds_barrier();
+    }
+  } else if (a.need_E) {                              // selected inverse
+    double* Sgl = Dl;                                 // [S][nn] Sig_jj
+    double* SLl = Cl;                                 // [S][nn] Sig[j, left neighbour at its level]
+    double* SRl = CLl;                                // [S][nn] Sig[j, right neighbour]
+    for (int el = tid; el < nn; el += blockDim.x) { const double v = a.w.E[el]; Sgl[el] = v; a.SigD[el] = v; }
+    lds_barrier();
+    for (int lam = a.m - 1; lam >= 0; --lam) {
+      const int h2 = 1 << lam;
+      int nel = 0;
+      for (int j = h2; j < cnt; j += 2 * h2) ++nel;
+      for (int u = wave; u < nel; u += nwaves) {
+        const int j = (2 * u + 1) * h2, x = x0 + j * st;
+        const int ja = j - h2, jb = j + h2;
+        const bool has_b = jb < cnt;
+        const bool a_odd = has_b && (((ja / (2 * h2)) & 1) != 0);   // which of a, b was eliminated at the next level
+        const double* Sab = a_odd ? SRl + ja * nn : SLl + (has_b ? jb : 0) * nn;
+        seg_marginal_node(a, x, x0 + ja * st, a.level0 + lam, has_b, Sgl + ja * nn, Sgl + (has_b ? jb : 0) * nn, Sab,
+                          !a_odd, Sgl + j * nn, SLl + j * nn, SRl + j * nn, scratch + wave * (4 * nn + N), lane);
+      }
+      lds_barrier();
+    }
+  }
+}
+
+// ---- pass C: backward recursion inside every segment of an earlier pass ----
+template <int N>
+__global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
+  extern __shared__ double sm[];
+  constexpr int nn = N * N;
+  const int T = a.T, S = a.S, st = 1 << a.level0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
+  const bool rhs = a.rhs != nullptr;
+  const int x0 = (int)blockIdx.x * S * st;
+  int cnt = 0;
+  for (int j = 0; j < S; ++j) if (x0 + j * st < T) cnt = j + 1;
+  const int xn = x0 + S * st;                         // the next segment's first node (slot S)
+  const bool ext_right = xn < T;
+  if (rhs) {
+    double* xl = sm;                                  // [S+1][N]
+    if (tid < N) xl[tid] = a.x[(size_t)x0 * N + tid];
+    if (ext_right && tid >= 64 && tid < 64 + N) xl[S * N + tid - 64] = a.x[(size_t)xn * N + tid - 64];
+    lds_barrier();
+    for (int lam = a.m - 1; lam >= 0; --lam) {
+      const int h2 = 1 << lam;
+      int nel = 0;
+      for (int j = h2; j < cnt; j += 2 * h2) ++nel;
+      for (int e = tid; e < nel * N; e += blockDim.x) {
+        const int u = e / N, r = e % N, j = (2 * u + 1) * h2, x = x0 + j * st;
+        const int ja = j - h2, jb = j + h2;
+        const bool has_b = (jb < cnt) || (jb == S && ext_right);
+        double xe = a.w.v[(size_t)x * N + r];
+        const double* GA = a.w.GA + (size_t)x * nn + r * N;
+        for (int k = 0; k < N; ++k) xe -= GA[k] * xl[ja * N + k];
+        if (has_b) {
+          const double* GB = a.w.GB + (size_t)x * nn + r * N;
+          for (int k = 0; k < N; ++k) xe -= GB[k] * xl[jb * N + k];
+        }
+        xl[j * N + r] = xe;
+        a.x[(size_t)x * N + r] = xe;
+      }
+      lds_barrier();
+    }
+    return;
+  }
+  double* Sgl = sm;                                   // [S+1][nn] Sig_jj (slot S = next segment's first node)
+  double* SLl = Sgl + (S + 1) * nn;                   // [S+1][nn]
+  double* SRl = SLl + (S + 1) * nn;                   // [S+1][nn]; SRl[0] is preloaded with Sig[x0, xn]
+  double* scratch = SRl + (S + 1) * nn;               // per wave [2][nn]
+  // Sig[x0, xn]: the two are adjacent at level level0 + m; the odd one was eliminated there
+  const int lvl_up = a.level0 + a.m;
+  const bool x0_odd = ext_right && (((x0 >> lvl_up) & 1) != 0);
+  for (int el = tid; el < nn; el += blockDim.x) {
+    const int r = el / N, c = el % N;
+    Sgl[el] = a.SigD[(size_t)x0 * nn + el];
+    if (ext_right) {
+      Sgl[S * nn + el] = a.SigD[(size_t)xn * nn + el];
+      SRl[el] = x0_odd ? a.w.SR[(size_t)x0 * nn + el] : a.w.SL[(size_t)xn * nn + c * N + r];
+    }
+  }
+  lds_barrier();
+  for (int lam = a.m - 1; lam >= 0; --lam) {
+    const int h2 = 1 << lam;
+    int nel = 0;
+    for (int j = h2; j < cnt; j += 2 * h2) ++nel;
+    for (int u = wave; u < nel; u += nwaves) {
+      const int j = (2 * u + 1) * h2, x = x0 + j * st;
+      const int ja = j - h2, jb = j + h2;
+      const bool has_b = (jb < cnt) || (jb == S && ext_right);
+      // Sig[a,b]: the segment boundary pair was preloaded into SRl[0]; otherwise the odd one of (a, b)
+      // at the next local level holds it (SRl[ja] = Sig[a, b] or SLl[jb] = Sig[b, a])
+      bool transposed = false;
+      const double* Sab = SRl;
+      if (has_b && !(ja == 0 && jb == S)) {
+        const bool a_odd = ((ja / (2 * h2)) & 1) != 0;
+        Sab = a_odd ? SRl + ja * nn : SLl + jb * nn;
+        transposed = !a_odd;
+      }
+      seg_marginal_node(a, x, x0 + ja * st, a.level0 + lam, has_b, Sgl + ja * nn, Sgl + (has_b ? jb : 0) * nn, Sab,
+                        transposed, Sgl + j * nn, SLl + j * nn, SRl + j * nn, scratch + wave * 2 * nn, lane);
+    }
+    lds_barrier();
+  }
+}
+
+}  // namespace gvi

@@ -276,6 +276,168 @@ __device__ inline void bcr_eliminate(const BcrArgs& a, int L, int e, bool root, 
   wave_lds_sync();
 }
 
+// ---- register-resident elimination for compile-time block size N (4N+1 <= 64) ----
+// Lane c holds column c of the augmented tile [D_e | I | Ua^T | Ub | y] in N registers.  A pivot step
+// broadcasts the pivot column with v_readlane (wave-uniform scalars), so Gauss-Jordan needs no LDS
+// round trips and no waits: ~2N readlanes + N FMAs per pivot.  Ua / Ub are parked in LDS only for the
+// three small products (CL, CR, NU) at the end.
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
+
+template <bool PIVOT, int N>
+__device__ inline void bcr_eliminate_reg(const BcrArgs& a, int L, int e, bool root, int lane, double* sm) {
+  constexpr int nn = N * N;
+  const int T = a.T;
+  const int s = root ? 0 : (1 << L);
+  const bool has_a = !root;
+  const int b = e + s;
+  const bool has_b = !root && b < T;
+  const bool rhs = a.rhs != nullptr;
+  const int cE = N, cA = a.need_E ? 2 * N : N, cB = cA + N, cY = cB + N;
+  double* Ua = sm;                 // [N][N]  A[a,e]
+  double* Ub = Ua + nn;            // [N][N]  A[e,b]
+  const int h = L > 0 ? (1 << (L - 1)) : 0;
+  const bool cl = L > 0 && e - h >= 0, cr = L > 0 && e + h < T;
+  const double* baseD = (L <= 1 ? a.D : a.w.Deff) + (size_t)e * nn;
+  const double* pUa = !has_a ? nullptr : (L == 0 ? a.U + (size_t)(e - s) * nn : a.w.NU + (size_t)(e - s / 2) * nn);
+  const double* pUb = !has_b ? nullptr : (L == 0 ? a.U + (size_t)e * nn : a.w.NU + (size_t)(e + s / 2) * nn);
+  // ---- load this lane's column ----
+  double col[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) col[r] = 0.0;
+  if (lane < N) {                                            // D_e (symmetric: read row `lane` = column `lane`)
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      double v = baseD[lane * N + r];
+      if (cl) v -= a.w.CR[(size_t)(e - h) * nn + lane * N + r];
+      if (cr) v -= a.w.CL[(size_t)(e + h) * nn + lane * N + r];
+      col[r] = v;
+    }
+  } else if (a.need_E && lane < 2 * N) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) col[r] = (r == lane - cE) ? 1.0 : 0.0;
+  } else if (lane >= cA && lane < cA + N) {                  // column j of Ua^T = row j of Ua
+    if (has_a) {
+      const int j = lane - cA;
+#pragma unroll
+      for (int r = 0; r < N; ++r) { col[r] = pUa[j * N + r]; Ua[j * N + r] = col[r]; }
+    }
+  } else if (lane >= cB && lane < cB + N) {                  // column j of Ub
+    if (has_b) {
+      const int j = lane - cB;
+#pragma unroll
+      for (int r = 0; r < N; ++r) { col[r] = pUb[r * N + j]; Ub[r * N + j] = col[r]; }
+    }
+  } else if (rhs && lane == cY) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      double y = L <= 1 ? a.rhs_scale * a.rhs[(size_t)e * N + r] : a.w.yeff[(size_t)e * N + r];
+      if (cl) y -= a.w.yR[(size_t)(e - h) * N + r];
+      if (cr) y -= a.w.yL[(size_t)(e + h) * N + r];
+      col[r] = y;
+    }
+  }
+  // ---- Gauss-Jordan, pivot column broadcast by readlane ----
+  double pivs[N];
+  int bad = 0;
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    double ap[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) ap[r] = readlane_f64(col[r], p);
+    if (PIVOT) {
+      int rs = p;
+      double best = fabs(ap[p]);
+#pragma unroll
+      for (int r = p + 1; r < N; ++r)
+        if (fabs(ap[r]) > best) { best = fabs(ap[r]); rs = r; }
+#pragma unroll
+      for (int r = p + 1; r < N; ++r) {                      // swap rows p <-> rs (rs is wave-uniform)
+        if (r == rs) {
+          const double t = col[p]; col[p] = col[r]; col[r] = t;
+          const double u = ap[p]; ap[p] = ap[r]; ap[r] = u;
+        }
+      }
+    }
+    const double piv = ap[p];
+    if (!(piv > 0.0)) bad = 1;
+    pivs[p] = piv;
+    const double f = col[p] * (1.0 / piv);
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      if (r != p) col[r] = fma(-ap[r], f, col[r]);
+    col[p] = f;
+  }
+  double lg = 0.0;
+#pragma unroll
+  for (int p = 0; p < N; ++p) lg = (lane == p) ? pivs[p] : lg;
+  lg = lane < N ? log(lg) : 0.0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+  if (lane == 0) { a.w.logp[e] = lg; a.w.bad[e] = bad; }
+  wave_lds_sync();                                           // Ua / Ub visible to every lane
+  // ---- store E, GA, GB, v and the pending updates (lane = output column) ----
+  if (a.need_E && lane >= cE && lane < cE + N) {
+    const int c = lane - cE;
+#pragma unroll
+    for (int r = 0; r < N; ++r) a.w.E[(size_t)e * nn + r * N + c] = col[r];
+  }
+  if (has_a && lane >= cA && lane < cA + N) {                // GA[:,c] and CL[:,c] = Ua GA[:,c]
+    const int c = lane - cA;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      a.w.GA[(size_t)e * nn + r * N + c] = col[r];
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) v = fma(Ua[r * N + k], col[k], v);
+      a.w.CL[(size_t)e * nn + r * N + c] = v;
+    }
+  }
+  if (has_b && lane >= cB && lane < cB + N) {                // GB[:,c], CR[:,c] = Ub^T GB[:,c], NU[:,c] = -Ua GB[:,c]
+    const int c = lane - cB;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      a.w.GB[(size_t)e * nn + r * N + c] = col[r];
+      double v = 0.0, u = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) { v = fma(Ub[k * N + r], col[k], v); u = fma(Ua[r * N + k], col[k], u); }
+      a.w.CR[(size_t)e * nn + r * N + c] = v;
+      a.w.NU[(size_t)e * nn + r * N + c] = -u;
+    }
+  }
+  if (rhs && lane == cY) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      a.w.v[(size_t)e * N + r] = col[r];
+      if (has_a) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v = fma(Ua[r * N + k], col[k], v);
+        a.w.yL[(size_t)e * N + r] = v;
+      }
+      if (has_b) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v = fma(Ub[k * N + r], col[k], v);
+        a.w.yR[(size_t)e * N + r] = v;
+      }
+    }
+  }
+  wave_lds_sync();
+}
+
+// NMAX >= 100 selects the register kernel with N = NMAX - 100 (exact block size)
+template <bool PIVOT, int NMAX>
+__device__ inline void bcr_eliminate_any(const BcrArgs& a, int L, int e, bool root, int lane, double* sm) {
+  if constexpr (NMAX >= 100) bcr_eliminate_reg<PIVOT, NMAX - 100>(a, L, e, root, lane, sm);
+  else bcr_eliminate<PIVOT, NMAX>(a, L, e, root, lane, sm);
+}
+
 // Surviving node x = 2 j s of level L >= 1: fold the pending updates of level L-1 into Deff / yeff.
 __device__ inline void bcr_update_survivor(const BcrArgs& a, int L, int x, int lane) {
   const int n = a.n, nn = n * n, T = a.T, h = 1 << (L - 1);
@@ -307,7 +469,7 @@ __global__ __launch_bounds__(64) void bcr_forward_kernel(BcrArgs a) {
   extern __shared__ double sm[];
   const int elim = bcr_count(a.T, a.level);
   if ((int)blockIdx.x < elim) {
-    bcr_eliminate<PIVOT, NMAX>(a, a.level, (2 * (int)blockIdx.x + 1) << a.level, false, threadIdx.x, sm);
+    bcr_eliminate_any<PIVOT, NMAX>(a, a.level, (2 * (int)blockIdx.x + 1) << a.level, false, threadIdx.x, sm);
   } else {
     bcr_update_survivor(a, a.level, (2 * ((int)blockIdx.x - elim)) << a.level, threadIdx.x);
   }
@@ -324,14 +486,14 @@ __global__ __launch_bounds__(1024) void bcr_forward_tail_kernel(BcrArgs a) {
   double* my = sm + (size_t)wave * bcr_unit_lds_doubles(a.n);
   for (int l = a.tail_from; l < a.nlevels; ++l) {
     const int elim = bcr_count(a.T, l);
-    if (wave < elim) bcr_eliminate<PIVOT, NMAX>(a, l, (2 * wave + 1) << l, false, lane, my);
+    if (wave < elim) bcr_eliminate_any<PIVOT, NMAX>(a, l, (2 * wave + 1) << l, false, lane, my);
     if (l > 0) {
       const int surv = bcr_survivors(a.T, l);
       for (int j = wave; j < surv; j += nwaves) bcr_update_survivor(a, l, (2 * j) << l, lane);
     }
     __syncthreads();
   }
-  if (wave == 0) bcr_eliminate<PIVOT, NMAX>(a, a.nlevels, 0, true, lane, my);
+  if (wave == 0) bcr_eliminate_any<PIVOT, NMAX>(a, a.nlevels, 0, true, lane, my);
 }
 
 // half_logdet = 1/2 sum_t logp[t]  (fixed-order tree), NaN if any node saw a non-positive pivot
@@ -462,6 +624,113 @@ __global__ __launch_bounds__(1024) void bcr_back_marginals_head_kernel(int T, in
     if (wave < bcr_count(T, l)) bcr_marginal_node(T, n, l, (2 * wave + 1) << l, w, SigD, SigU, lane, sm + (size_t)wave * 7 * nn);
     __syncthreads();
   }
+}
+
+// ---- fused glue of the resident NGD iteration (one launch each instead of one per set) ----
+constexpr int MAX_SETS = 8;
+struct SetDesc {
+  int K, d;
+  const int32_t* start;
+  const int32_t* ptr;        // CSR over states (scatter)
+  const int32_t* idx;
+  const double* Vdmu;        // [K][d]
+  const double* Vddmu;       // [K][d][d]
+  double* mu_k;              // [K][d]      (gather)
+  double* Sigma_k;           // [K][d][d]
+  const double* cost;        // [K]         (cost sum)
+};
+struct SetList { int nsets; SetDesc s[MAX_SETS]; };
+
+// assemble over ALL sets: every output element is written once (ordered: set after set, factor
+// index ascending), so no memset and no second launch
+__global__ __launch_bounds__(256) void bt_scatter_all_kernel(SetList L, int T, int n, double* __restrict__ g,
+                                                             double* __restrict__ D, double* __restrict__ U) {
+  const int nn = n * n, per = n + 2 * nn;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)T * per) return;
+  const int t = (int)(gid / per), e = (int)(gid % per);
+  double acc = 0.0;
+  for (int si = 0; si < L.nsets; ++si) {
+    const SetDesc& a = L.s[si];
+    const int d = a.d;
+    const bool two = d == 2 * n;
+    double s = 0.0;
+    if (e < n) {
+      for (int q = a.ptr[t]; q < a.ptr[t + 1]; ++q) s += a.Vdmu[(size_t)a.idx[q] * d + e];
+      if (two && t > 0)
+        for (int q = a.ptr[t - 1]; q < a.ptr[t]; ++q) s += a.Vdmu[(size_t)a.idx[q] * d + n + e];
+    } else if (e < n + nn) {
+      const int r = (e - n) / n, c = (e - n) % n;
+      for (int q = a.ptr[t]; q < a.ptr[t + 1]; ++q) s += a.Vddmu[(size_t)a.idx[q] * d * d + r * d + c];
+      if (two && t > 0)
+        for (int q = a.ptr[t - 1]; q < a.ptr[t]; ++q)
+          s += a.Vddmu[(size_t)a.idx[q] * d * d + (n + r) * d + n + c];
+    } else if (two && t < T - 1) {
+      const int r = (e - n - nn) / n, c = (e - n - nn) % n;
+      for (int q = a.ptr[t]; q < a.ptr[t + 1]; ++q) s += a.Vddmu[(size_t)a.idx[q] * d * d + r * d + n + c];
+    }
+    acc += s;                 // same association as memset + one "+=" per set
+  }
+  if (e < n) g[(size_t)t * n + e] = acc;
+  else if (e < n + nn) D[(size_t)t * nn + (e - n)] = acc;
+  else if (t < T - 1) U[(size_t)t * nn + (e - n - nn)] = acc;
+}
+
+// gather (mu_k, Sigma_k) for ALL sets: blockIdx.y = set
+__global__ __launch_bounds__(256) void gather_all_kernel(SetList L, int n, const double* __restrict__ mu,
+                                                         const double* __restrict__ SigD,
+                                                         const double* __restrict__ SigU) {
+  const SetDesc& a = L.s[blockIdx.y];
+  const int d = a.d, per = d + d * d, nn = n * n;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)a.K * per) return;
+  const int k = (int)(gid / per), e = (int)(gid % per), s = a.start[k];
+  if (e < d) { a.mu_k[(size_t)k * d + e] = mu[(size_t)s * n + e]; return; }
+  const int r = (e - d) / d, c = (e - d) % d;
+  double v;
+  if (r < n && c < n) v = SigD[(size_t)s * nn + r * n + c];
+  else if (r >= n && c >= n) v = SigD[(size_t)(s + 1) * nn + (r - n) * n + (c - n)];
+  else if (r < n) v = SigU[(size_t)s * nn + r * n + (c - n)];
+  else v = SigU[(size_t)s * nn + c * n + (r - n)];
+  a.Sigma_k[(size_t)k * d * d + r * d + c] = v;
+}
+
+// ordered sum of the factor costs of ALL sets -> acc[0]; one block, fixed tree per set
+__global__ __launch_bounds__(256) void cost_sum_all_kernel(SetList L, double* acc) {
+  __shared__ double sh[256];
+  double total = 0.0;
+  for (int si = 0; si < L.nsets; ++si) {
+    double s = 0.0;
+    for (int k = threadIdx.x; k < L.s[si].K; k += 256) s += L.s[si].cost[k];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    total += sh[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) acc[0] = total;
+}
+
+// trial point in one launch: mu_t = mu + step dmu ; Lam_t = Lam + step (V - Lam)
+__global__ __launch_bounds__(256) void trial_kernel(int64_t nmu, int64_t nlam, double step, const double* __restrict__ mu,
+                                                    const double* __restrict__ dmu, const double* __restrict__ lam,
+                                                    const double* __restrict__ V, double* __restrict__ mu_t,
+                                                    double* __restrict__ lam_t) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nmu) mu_t[i] = mu[i] + step * dmu[i];
+  else if (i < nmu + nlam) {
+    const int64_t j = i - nmu;
+    const double l = lam[j];
+    lam_t[j] = l + step * (V[j] - l);
+  }
+}
+
+// publish the (all-reduced) cost sum and the log-det into host-mapped memory: out = {cost_sum, hld}
+__global__ void publish_kernel(const double* cost_sum, const double* half_logdet, double* host_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { host_out[0] = cost_sum[0]; host_out[1] = half_logdet[0]; }
 }
 
 // ---- gather (mu_k, Sigma_k) of every factor from the joint mean / covariance blocks ----
