@@ -116,13 +116,16 @@ def main():
         torch.cuda.synchronize()
 
     evals_moments = sum(K * N for (K, d, p, N) in ctx.sets)       # local, per pass
+    # one process: the whole iteration (backtracking loop included) is one C-ABI call; sharded: the
+    # Python driver interleaves the two all-reduces between the *_local / *_finish halves
+    step_fn = (lambda: ctx.ngd_step(0.55, 10)) if (world == 1 and not ngd.group_forced) else (lambda: ngd.step(0.55, 10))
     for _ in range(args.warmup):
-        ngd.step(0.55, 10)
+        step_fn()
     barrier()
     t0 = time.perf_counter()
     passes, kern_ms, cost_ms, log = 0, [], [], []
     for _ in range(args.steps):
-        r = ngd.step(0.55, 10)
+        r = step_fn()
         log.append(r)
         passes += 1 + r["ntrials"]
         kern_ms.append(ctx.profile_last(ids[0], 0))

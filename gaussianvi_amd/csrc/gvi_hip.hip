@@ -110,7 +110,8 @@ struct gvi_ctx {
   bool profile = false;
   int target_waves = 2048;
   hipEvent_t fork = nullptr;
-  double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet}
+  double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
+  double seq = 0.0;
   double* host_slot_dev = nullptr;
 };
 
@@ -433,7 +434,7 @@ bool seg_supported(int n) { return n == 1 || n == 2 || n == 3 || n == 4 || n == 
 SegPlan seg_plan(const gvi_ctx* c) {
   const int n = c->n, T = c->T;
   const int m_seg = n <= 6 ? 5 : (n <= 8 ? 4 : 3);
-  const int cap = n <= 6 ? 64 : (n <= 8 ? 32 : 16);
+  const int cap = n <= 6 ? 48 : (n <= 8 ? 24 : 8);          // top-pass nodes: 8 LDS block arrays must fit
   SegPlan p;
   const int nlevels = bcr_levels(T);
   int level0 = 0, prev0 = 0;
@@ -444,7 +445,7 @@ SegPlan seg_plan(const gvi_ctx* c) {
     level0 += m_seg;
   }
   p.passes.push_back({level0, nlevels - level0, alive(level0), prev0, 1});
-  p.threads = 1024;
+  p.threads = n <= 8 ? 1024 : 512;
   return p;
 }
 
@@ -461,7 +462,7 @@ gvi_status launch_seg(gvi_ctx* c, SegArgs a, const SegPlan& pl) {
   const bool rhs = a.rhs != nullptr;
   for (const SegPass& ps : pl.passes) {
     a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.prev0 = ps.prev0; a.top = ps.top;
-    const size_t lds = seg_fwd_lds_doubles(N, ps.S, rhs) * 8;
+    const size_t lds = seg_fwd_lds_doubles(N, ps.S, rhs, ps.top != 0, pl.threads / 64) * 8;
     if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: LDS budget");
     const int stride = ps.S << ps.level0;
     const int blocks = ps.top ? 1 : (c->T + stride - 1) / stride;
@@ -609,6 +610,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
       hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
     return fail(nullptr, GVI_ERR_HIP, "event / host-mapped slot allocation failed");
+  c->host_slot[0] = c->host_slot[1] = c->host_slot[2] = 0.0;
   *out = c.release();
   return GVI_OK;
 }
@@ -1042,18 +1044,54 @@ static SetList make_set_list(gvi_ctx* ctx, int slot) {
   return L;
 }
 
-// fork: every set stream waits for what is queued on the main stream so far
-static gvi_status ngd_fork(gvi_ctx* ctx) {
-  HIPCK(ctx, hipEventRecord(ctx->fork, ctx->stream));
-  for (auto& s : ctx->sets) HIPCK(ctx, hipStreamWaitEvent(s->st, ctx->fork, 0));
+// prep of every set whose per-pass products are not those of NGD slot i -- one launch
+static gvi_status ngd_prep_all(gvi_ctx* ctx, int i) {
+  PrepList L;
+  L.nsets = 0;
+  L.koff[0] = 0;
+  int dmax = 0;
+  for (auto& s : ctx->sets) {
+    if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
+    if (s->prep_slot == i) continue;
+    s->prep_slot = i;
+    L.f[L.nsets] = s->dev();
+    L.mu[L.nsets] = s->mu_k[i].d();
+    L.Sigma[L.nsets] = s->Sigma_k[i].d();
+    L.koff[L.nsets + 1] = L.koff[L.nsets] + s->K;
+    dmax = std::max(dmax, s->d);
+    ++L.nsets;
+  }
+  if (L.nsets == 0) return GVI_OK;
+  const int dp = dmax + (dmax & 1);
+  const size_t lds = (size_t)(4 * dmax * dmax + 2 * dp + 3 * dmax) * 8 + (size_t)dp * 4 + 16;
+  const dim3 grid(L.koff[L.nsets]);
+  if (dmax <= 8) hipLaunchKernelGGL(prep_all_kernel<1>, grid, dim3(64), lds, ctx->stream, L);
+  else if (dmax <= 16) hipLaunchKernelGGL(prep_all_kernel<4>, grid, dim3(64), lds, ctx->stream, L);
+  else if (dmax <= 32) hipLaunchKernelGGL(prep_all_kernel<16>, grid, dim3(64), lds, ctx->stream, L);
+  else return fail(ctx, GVI_ERR_UNSUPPORTED, "factor dimension > 32");
+  HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
-// join: the main stream waits for every set stream
-static gvi_status ngd_join(gvi_ctx* ctx) {
-  for (auto& s : ctx->sets) {
-    HIPCK(ctx, hipEventRecord(s->done, s->st));
-    HIPCK(ctx, hipStreamWaitEvent(ctx->stream, s->done, 0));
+
+// epilogue of every set -- one launch (full: Vdmu / Vddmu / Ephi / cost; else cost only)
+static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full) {
+  EpiList L;
+  L.nsets = (int)ctx->sets.size();
+  L.koff[0] = 0;
+  int dmax = 0;
+  for (int si = 0; si < L.nsets; ++si) {
+    FactorSet& s = *ctx->sets[si];
+    EpiArgs& e = L.e[si];
+    e.f = s.dev(); e.partial = s.partial.d(); e.nchunk = s.nchunk; e.full = full;
+    e.Ephi = full ? s.Ephi.d() : nullptr; e.cost = s.cost.d();
+    e.Vdmu = full ? s.Vdmu.d() : nullptr; e.Vddmu = full ? s.Vddmu.d() : nullptr;
+    e.E_xmuphi = nullptr; e.E_xxphi = nullptr;
+    L.koff[si + 1] = L.koff[si] + s.K;
+    dmax = std::max(dmax, s.d);
   }
+  const size_t lds = (size_t)(npairs(dmax) + 2 * dmax * dmax) * 8;
+  hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L);
+  HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
 
@@ -1079,18 +1117,16 @@ static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
   return GVI_OK;
 }
 
-// sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0]; the sets run concurrently on their own streams
+// sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0].  Everything stays on ONE stream: side streams
+// share the hardware queue on this part and every cross-stream dependency costs a 6-30 us barrier
+// packet (profiles/r01_d_*); the small sets ride along inside the fused prep / epilogue launches.
 static gvi_status ngd_cost_local(gvi_ctx* ctx, int i) {
   NgdState& g = ctx->ngd;
   if (ctx->sets.empty()) { HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream)); return GVI_OK; }
-  GVICK(ngd_fork(ctx));
-  for (auto& s : ctx->sets) {
-    if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
-    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i, s->st));
-    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0, s->st));
-    GVICK(run_epilogue(ctx, *s, 0, nullptr, s->cost.d(), nullptr, nullptr, nullptr, nullptr, s->st));
-  }
-  GVICK(ngd_join(ctx));
+  if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
+  GVICK(ngd_prep_all(ctx, i));
+  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0));
+  GVICK(ngd_epilogue_all(ctx, 0));
   hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, i), g.exch1.d());
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
@@ -1098,9 +1134,22 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i) {
 
 static gvi_status ngd_cost_finish(gvi_ctx* ctx, int i, double* out) {
   NgdState& g = ctx->ngd;
-  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev);
+  ctx->seq += 1.0;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev,
+                     ctx->seq);
   HIPCK(ctx, hipGetLastError());
-  GVICK(sync(ctx));
+  // spin on the host-mapped sequence word (a blocking stream sync costs tens of us of wake-up latency);
+  // bounded: fall back to the stream sync after ~50 ms
+  {
+    volatile double* slot = ctx->host_slot;
+    bool seen = false;
+    for (long spins = 0; spins < 20000000L; ++spins) {
+      if (slot[2] == ctx->seq) { seen = true; break; }
+      __builtin_ia32_pause();
+    }
+    if (!seen) GVICK(sync(ctx));
+  }
+  __sync_synchronize();
   const double v = ctx->host_slot[0] + ctx->host_slot[1];     // cost_value = sum of factor costs + 1/2 log det
   g.cost[i] = v;
   g.cost_valid[i] = true;
@@ -1184,14 +1233,9 @@ gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx) {
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
-  GVICK(ngd_fork(ctx));
-  for (auto& s : ctx->sets) {
-    if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
-    GVICK(run_prep(ctx, *s, s->mu_k[i].d(), s->Sigma_k[i].d(), i, s->st));
-    GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 1, s->st));
-    GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), s->cost.d(), s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr, s->st));
-  }
-  GVICK(ngd_join(ctx));
+  GVICK(ngd_prep_all(ctx, i));
+  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 1));
+  GVICK(ngd_epilogue_all(ctx, 1));
   const int64_t total = (int64_t)T * (n + 2 * nn);
   hipLaunchKernelGGL(bt_scatter_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                      make_set_list(ctx, i), ctx->T, ctx->n, eg, eD, eU);

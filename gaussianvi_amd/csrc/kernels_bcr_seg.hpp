@@ -51,13 +51,14 @@ struct SegArgs {
   double* hld;       // [1]
 };
 
-constexpr int SEG_MAX_WAVES = 16;
-// forward / top kernel: 5 block arrays, 4 rhs vectors, per-wave backward scratch, reduction area
-__host__ __device__ inline size_t seg_fwd_lds_doubles(int n, int S, bool rhs) {
-  return (size_t)5 * S * n * n + (rhs ? (size_t)4 * (S + 1) * n : 0) + (size_t)SEG_MAX_WAVES * (4 * n * n + n) + 1600;
+// forward kernel LDS: 5 block arrays (+3 factor arrays in the top pass), rhs vectors, one elimination tile
+// per wave, reduction area
+__host__ __device__ inline size_t seg_fwd_lds_doubles(int n, int S, bool rhs, bool top, int nwaves) {
+  return (size_t)(top ? 8 : 5) * S * n * n + (rhs ? (size_t)5 * (S + 1) * n : 0) + (size_t)nwaves * (4 * n * n + n) + 1600;
 }
 __host__ __device__ inline size_t seg_bwd_lds_doubles(int n, int S, bool rhs) {
-  return rhs ? (size_t)(S + 1) * n + 16 : (size_t)3 * (S + 1) * n * n + (size_t)SEG_MAX_WAVES * 2 * n * n;
+  return rhs ? (size_t)(S + 1) * n + (size_t)S * (2 * n * n + n) + 16
+             : (size_t)3 * (S + 1) * n * n + (size_t)3 * S * n * n;
 }
 
 // ---- forward elimination of one node from LDS-resident operands (register Gauss-Jordan) ----
@@ -66,7 +67,8 @@ __host__ __device__ inline size_t seg_bwd_lds_doubles(int n, int S, bool rhs) {
 template <bool PIVOT, int N>
 __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e, const double* Ua, const double* Ub,
                                      const double* y_e, double* CLs, double* CRs, double* NUs, double* yLs,
-                                     double* yRs, double* Tl, int lane) {
+                                     double* yRs, double* Tl, double* Es, double* GAs, double* GBs, double* vs,
+                                     int lane) {
   constexpr int nn = N * N, NC = 4 * N + 1;
   const bool has_a = Ua != nullptr, has_b = Ub != nullptr, rhs = a.rhs != nullptr;
   const int cE = N, cA = a.need_E ? 2 * N : N, cB = cA + N, cY = cB + N;
@@ -141,9 +143,9 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
   wave_lds_sync();
   for (int el = lane; el < nn; el += 64) {
     const int r = el / N, c = el % N;
-    if (a.need_E) a.w.E[(size_t)x * nn + el] = Tl[r * NC + cE + c];
+    if (a.need_E) { const double ev = Tl[r * NC + cE + c]; a.w.E[(size_t)x * nn + el] = ev; if (Es) Es[el] = ev; }
     if (has_a) {
-      a.w.GA[(size_t)x * nn + el] = Tl[r * NC + cA + c];
+      { const double gv = Tl[r * NC + cA + c]; a.w.GA[(size_t)x * nn + el] = gv; if (GAs) GAs[el] = gv; }
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) v = fma(Ua[r * N + k], Tl[k * NC + cA + c], v);
@@ -151,7 +153,7 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
       a.w.CL[(size_t)x * nn + el] = v;
     }
     if (has_b) {
-      a.w.GB[(size_t)x * nn + el] = Tl[r * NC + cB + c];
+      { const double gv = Tl[r * NC + cB + c]; a.w.GB[(size_t)x * nn + el] = gv; if (GBs) GBs[el] = gv; }
       double v = 0.0, u = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -166,7 +168,7 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
   }
   if (rhs && lane < N) {
     const int r = lane;
-    a.w.v[(size_t)x * N + r] = Tl[r * NC + cY];
+    { const double vv = Tl[r * NC + cY]; a.w.v[(size_t)x * N + r] = vv; if (vs) vs[r] = vv; }
     if (has_a) {
       double v = 0.0;
 #pragma unroll
@@ -186,29 +188,26 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
 }
 
 // ---- backward step of one node: selected inverse (marginals) ----
-// Saa / Sbb / Sab: LDS blocks of its neighbours' covariance; writes Sig_ee, Sig[e,a], Sig[e,b] to the
-// LDS slots and to global.
-__device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int level, bool has_b, const double* Saa,
-                                         const double* Sbb, const double* Sab, bool sab_transposed, double* See_s,
-                                         double* SL_s, double* SR_s, double* scratch, int lane) {
-  const int n = a.n, nn = n * n;
-  double* GA = scratch;          // [n][n]
-  double* GB = GA + nn;
+// E / GA / GB: the node's factors (LDS); Saa / Sbb / Sab: LDS blocks of its neighbours' covariance.
+// Writes Sig_ee, Sig[e,a], Sig[e,b] to the LDS slots and to global.
+template <int N>
+__device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int level, bool has_b, const double* E,
+                                         const double* GA, const double* GB, const double* Saa, const double* Sbb,
+                                         const double* Sab, bool sab_transposed, double* See_s, double* SL_s,
+                                         double* SR_s, int lane) {
+  constexpr int nn = N * N;
   for (int el = lane; el < nn; el += 64) {
-    GA[el] = a.w.GA[(size_t)x * nn + el];
-    if (has_b) GB[el] = a.w.GB[(size_t)x * nn + el];
-  }
-  wave_lds_sync();
-  for (int el = lane; el < nn; el += 64) {
-    const int r = el / n, c = el % n;
+    const int r = el / N, c = el % N;
     double sl = 0.0, sr = 0.0;
-    for (int k = 0; k < n; ++k) {
-      sl += GA[r * n + k] * Saa[k * n + c];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      sl = fma(GA[r * N + k], Saa[k * N + c], sl);
       if (has_b) {
-        const double sab_kc = sab_transposed ? Sab[c * n + k] : Sab[k * n + c];   // Sig_ab[k][c]
-        const double sba_kc = sab_transposed ? Sab[k * n + c] : Sab[c * n + k];   // Sig_ba[k][c] = Sig_ab[c][k]
-        sl += GB[r * n + k] * sba_kc;
-        sr += GA[r * n + k] * sab_kc + GB[r * n + k] * Sbb[k * n + c];
+        const double sab_kc = sab_transposed ? Sab[c * N + k] : Sab[k * N + c];   // Sig_ab[k][c]
+        const double sba_kc = sab_transposed ? Sab[k * N + c] : Sab[c * N + k];   // Sig_ba[k][c] = Sig_ab[c][k]
+        sl = fma(GB[r * N + k], sba_kc, sl);
+        sr = fma(GA[r * N + k], sab_kc, sr);
+        sr = fma(GB[r * N + k], Sbb[k * N + c], sr);
       }
     }
     SL_s[el] = -sl;
@@ -218,16 +217,17 @@ __device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int le
   }
   wave_lds_sync();
   for (int el = lane; el < nn; el += 64) {
-    const int r = el / n, c = el % n;
-    double see = a.w.E[(size_t)x * nn + el];
-    for (int k = 0; k < n; ++k) {
-      see -= SL_s[r * n + k] * GA[c * n + k];
-      if (has_b) see -= SR_s[r * n + k] * GB[c * n + k];
+    const int r = el / N, c = el % N;
+    double see = E[el];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      see = fma(-SL_s[r * N + k], GA[c * N + k], see);
+      if (has_b) see = fma(-SR_s[r * N + k], GB[c * N + k], see);
     }
     See_s[el] = see;
     a.SigD[(size_t)x * nn + el] = see;
     if (level == 0) {                                  // tridiagonal blocks of the original chain
-      a.SigU[(size_t)xa * nn + c * n + r] = SL_s[el];  // Sig[a,e] = Sig[e,a]^T
+      a.SigU[(size_t)xa * nn + c * N + r] = SL_s[el];  // Sig[a,e] = Sig[e,a]^T
       if (has_b) a.SigU[(size_t)x * nn + el] = SR_s[el];
     }
   }
@@ -270,12 +270,16 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
   double* NUl = Cl + S * nn;          // [S][nn] new couplings, indexed by the eliminated node
   double* CLl = NUl + S * nn;         // [S][nn] pending update to the left neighbour
   double* CRl = CLl + S * nn;         // [S][nn] pending update to the right neighbour
-  double* yl = CRl + S * nn;          // [S+1][N] (rhs only)
+  double* El = CRl + S * nn;          // top pass only: [S][nn] x3 factors kept for the backward recursion
+  double* GAl = El + (a.top ? S * nn : 0);
+  double* GBl = GAl + (a.top ? S * nn : 0);
+  double* yl = GBl + (a.top ? S * nn : 0);        // [S+1][N] (rhs only)
   double* yLl = yl + (rhs ? (S + 1) * N : 0);
   double* yRl = yLl + (rhs ? (S + 1) * N : 0);
   double* xl = yRl + (rhs ? (S + 1) * N : 0);    // [S+1][N] solution (top pass backward)
-  double* scratch = xl + (rhs ? (S + 1) * N : 0);  // [waves][4 nn + N]: elimination tile / backward-step scratch
-  double* red = scratch + SEG_MAX_WAVES * (4 * nn + N);  // [1024] doubles + [1024] ints: log-det reduction
+  double* vl = xl + (rhs ? (S + 1) * N : 0);     // [S+1][N] v (top pass)
+  double* scratch = vl + (rhs ? (S + 1) * N : 0);   // [waves][4 nn + N]: elimination tiles
+  double* red = scratch + nwaves * (4 * nn + N);  // [1024] doubles + [1024] ints: log-det reduction
   // number of local nodes that exist
   int cnt = 0;
   for (int j = 0; j < S; ++j) if (x0 + j * st < T) cnt = j + 1;
@@ -310,7 +314,9 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
       const double* Ua = lam == 0 ? Cl + ja * nn : NUl + (j - h2 / 2) * nn;
       const double* Ub = !has_b ? nullptr : (lam == 0 ? Cl + j * nn : NUl + (j + h2 / 2) * nn);
       seg_eliminate<PIVOT, N>(a, x, Dl + j * nn, Ua, Ub, yl + j * N, CLl + j * nn, CRl + j * nn, NUl + j * nn,
-                              yLl + j * N, yRl + j * N, scratch + wave * (4 * nn + N), lane);
+                              yLl + j * N, yRl + j * N, scratch + wave * (4 * nn + N),
+                              a.top ? El + j * nn : nullptr, a.top ? GAl + j * nn : nullptr,
+                              a.top ? GBl + j * nn : nullptr, (a.top && rhs) ? vl + j * N : nullptr, lane);
     }
     lds_barrier();
     // eager update of the local survivors of this level (node 0 only in the top pass: elsewhere its
@@ -336,8 +342,9 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
   if (!a.top) return;
   // ---- root (node 0), log-det ----
   if (wave == 0)
-    seg_eliminate<PIVOT, N>(a, 0, Dl, nullptr, nullptr, yl, CLl, CRl, NUl, yLl, yRl, scratch, lane);
-  __syncthreads();                                   // factors of this pass are read back from global below
+    seg_eliminate<PIVOT, N>(a, 0, Dl, nullptr, nullptr, yl, CLl, CRl, NUl, yLl, yRl, scratch, El, GAl, GBl,
+                            rhs ? vl : nullptr, lane);
+  lds_barrier();                                     // the factors of these nodes live in LDS (El, GAl, GBl, vl)
   if (a.hld) {
     int* redb = (int*)(red + 1024);
     double s = 0.0;
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
   }
   // ---- backward recursion for the nodes of this pass ----
   if (rhs) {                                          // solve: x_e = v - GA x_a - GB x_b
-    if (tid < N) { const double v = a.w.v[tid]; xl[tid] = v; a.x[tid] = v; }
+    if (tid < N) { const double v = vl[tid]; xl[tid] = v; a.x[tid] = v; }
     lds_barrier();
     for (int lam = a.m - 1; lam >= 0; --lam) {
       const int h2 = 1 << lam;
@@ -363,12 +370,12 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
       for (int e = tid; e < nel * N; e += blockDim.x) {
         const int u = e / N, r = e % N, j = (2 * u + 1) * h2, x = x0 + j * st;
         const int ja = j - h2, jb = j + h2;
-        double xe = a.w.v[(size_t)x * N + r];
-        const double* GA = a.w.GA + (size_t)x * nn + r * N;
-        for (int k = 0; k < N; ++k) xe -= GA[k] * xl[ja * N + k];
+        double xe = vl[j * N + r];
+#pragma unroll
+        for (int k = 0; k < N; ++k) xe = fma(-GAl[j * nn + r * N + k], xl[ja * N + k], xe);
         if (jb < cnt) {
-          const double* GB = a.w.GB + (size_t)x * nn + r * N;
-          for (int k = 0; k < N; ++k) xe -= GB[k] * xl[jb * N + k];
+#pragma unroll
+          for (int k = 0; k < N; ++k) xe = fma(-GBl[j * nn + r * N + k], xl[jb * N + k], xe);
         }
         xl[j * N + r] = xe;
         a.x[(size_t)x * N + r] = xe;
@@ -376,10 +383,10 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
       lds_barrier();
     }
   } else if (a.need_E) {                              // selected inverse
-    double* Sgl = Dl;                                 // [S][nn] Sig_jj
+    double* Sgl = Dl;                                 // [S][nn] Sig_jj          (forward arrays are dead)
     double* SLl = Cl;                                 // [S][nn] Sig[j, left neighbour at its level]
     double* SRl = CLl;                                // [S][nn] Sig[j, right neighbour]
-    for (int el = tid; el < nn; el += blockDim.x) { const double v = a.w.E[el]; Sgl[el] = v; a.SigD[el] = v; }
+    for (int el = tid; el < nn; el += blockDim.x) { const double v = El[el]; Sgl[el] = v; a.SigD[el] = v; }
     lds_barrier();
     for (int lam = a.m - 1; lam >= 0; --lam) {
       const int h2 = 1 << lam;
@@ -391,8 +398,9 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
         const bool has_b = jb < cnt;
         const bool a_odd = has_b && (((ja / (2 * h2)) & 1) != 0);   // which of a, b was eliminated at the next level
         const double* Sab = a_odd ? SRl + ja * nn : SLl + (has_b ? jb : 0) * nn;
-        seg_marginal_node(a, x, x0 + ja * st, a.level0 + lam, has_b, Sgl + ja * nn, Sgl + (has_b ? jb : 0) * nn, Sab,
-                          !a_odd, Sgl + j * nn, SLl + j * nn, SRl + j * nn, scratch + wave * (4 * nn + N), lane);
+        seg_marginal_node<N>(a, x, x0 + ja * st, a.level0 + lam, has_b, El + j * nn, GAl + j * nn, GBl + j * nn,
+                             Sgl + ja * nn, Sgl + (has_b ? jb : 0) * nn, Sab, !a_odd, Sgl + j * nn, SLl + j * nn,
+                             SRl + j * nn, lane);
       }
       lds_barrier();
     }
@@ -400,6 +408,8 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
 }
 
 // ---- pass C: backward recursion inside every segment of an earlier pass ----
+// The segment's factors (E, GA, GB / v) are fetched from global ONCE into LDS, then the m levels run
+// on LDS only.
 template <int N>
 __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
   extern __shared__ double sm[];
@@ -414,9 +424,20 @@ __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
   const bool ext_right = xn < T;
   if (rhs) {
     double* xl = sm;                                  // [S+1][N]
+    double* vl = xl + (S + 1) * N;                    // [S][N]
+    double* GAl = vl + S * N;                         // [S][nn]
+    double* GBl = GAl + S * nn;                       // [S][nn]
+    for (int e = tid; e < cnt * nn; e += blockDim.x) {
+      const int j = e / nn, el = e % nn, x = x0 + j * st;
+      if (j > 0) { GAl[e] = a.w.GA[(size_t)x * nn + el]; GBl[e] = a.w.GB[(size_t)x * nn + el]; }
+    }
+    for (int e = tid; e < cnt * N; e += blockDim.x) {
+      const int j = e / N, r = e % N, x = x0 + j * st;
+      if (j > 0) vl[e] = a.w.v[(size_t)x * N + r];
+    }
     if (tid < N) xl[tid] = a.x[(size_t)x0 * N + tid];
     if (ext_right && tid >= 64 && tid < 64 + N) xl[S * N + tid - 64] = a.x[(size_t)xn * N + tid - 64];
-    lds_barrier();
+    __syncthreads();
     for (int lam = a.m - 1; lam >= 0; --lam) {
       const int h2 = 1 << lam;
       int nel = 0;
@@ -425,12 +446,12 @@ __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
         const int u = e / N, r = e % N, j = (2 * u + 1) * h2, x = x0 + j * st;
         const int ja = j - h2, jb = j + h2;
         const bool has_b = (jb < cnt) || (jb == S && ext_right);
-        double xe = a.w.v[(size_t)x * N + r];
-        const double* GA = a.w.GA + (size_t)x * nn + r * N;
-        for (int k = 0; k < N; ++k) xe -= GA[k] * xl[ja * N + k];
+        double xe = vl[j * N + r];
+#pragma unroll
+        for (int k = 0; k < N; ++k) xe = fma(-GAl[j * nn + r * N + k], xl[ja * N + k], xe);
         if (has_b) {
-          const double* GB = a.w.GB + (size_t)x * nn + r * N;
-          for (int k = 0; k < N; ++k) xe -= GB[k] * xl[jb * N + k];
+#pragma unroll
+          for (int k = 0; k < N; ++k) xe = fma(-GBl[j * nn + r * N + k], xl[jb * N + k], xe);
         }
         xl[j * N + r] = xe;
         a.x[(size_t)x * N + r] = xe;
@@ -442,10 +463,20 @@ __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
   double* Sgl = sm;                                   // [S+1][nn] Sig_jj (slot S = next segment's first node)
   double* SLl = Sgl + (S + 1) * nn;                   // [S+1][nn]
   double* SRl = SLl + (S + 1) * nn;                   // [S+1][nn]; SRl[0] is preloaded with Sig[x0, xn]
-  double* scratch = SRl + (S + 1) * nn;               // per wave [2][nn]
+  double* El = SRl + (S + 1) * nn;                    // [S][nn] factors of the segment's nodes
+  double* GAl = El + S * nn;
+  double* GBl = GAl + S * nn;
   // Sig[x0, xn]: the two are adjacent at level level0 + m; the odd one was eliminated there
   const int lvl_up = a.level0 + a.m;
   const bool x0_odd = ext_right && (((x0 >> lvl_up) & 1) != 0);
+  for (int e = tid; e < cnt * nn; e += blockDim.x) {
+    const int j = e / nn, el = e % nn, x = x0 + j * st;
+    if (j > 0) {
+      El[e] = a.w.E[(size_t)x * nn + el];
+      GAl[e] = a.w.GA[(size_t)x * nn + el];
+      GBl[e] = a.w.GB[(size_t)x * nn + el];      // unused garbage when the node had no right neighbour
+    }
+  }
   for (int el = tid; el < nn; el += blockDim.x) {
     const int r = el / N, c = el % N;
     Sgl[el] = a.SigD[(size_t)x0 * nn + el];
@@ -454,7 +485,7 @@ __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
       SRl[el] = x0_odd ? a.w.SR[(size_t)x0 * nn + el] : a.w.SL[(size_t)xn * nn + c * N + r];
     }
   }
-  lds_barrier();
+  __syncthreads();
   for (int lam = a.m - 1; lam >= 0; --lam) {
     const int h2 = 1 << lam;
     int nel = 0;
@@ -472,8 +503,9 @@ __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
         Sab = a_odd ? SRl + ja * nn : SLl + jb * nn;
         transposed = !a_odd;
       }
-      seg_marginal_node(a, x, x0 + ja * st, a.level0 + lam, has_b, Sgl + ja * nn, Sgl + (has_b ? jb : 0) * nn, Sab,
-                        transposed, Sgl + j * nn, SLl + j * nn, SRl + j * nn, scratch + wave * 2 * nn, lane);
+      seg_marginal_node<N>(a, x, x0 + ja * st, a.level0 + lam, has_b, El + j * nn, GAl + j * nn, GBl + j * nn,
+                           Sgl + ja * nn, Sgl + (has_b ? jb : 0) * nn, Sab, transposed, Sgl + j * nn, SLl + j * nn,
+                           SRl + j * nn, lane);
     }
     lds_barrier();
   }

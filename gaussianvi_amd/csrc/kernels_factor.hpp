@@ -60,6 +60,16 @@ struct FactorDev {
 //   A'_ij = al_i al_j A_ij + al_i be_j A_i,pj + be_i al_j A_pi,j + be_i be_j A_pi,pj ,
 //   V'_ij = al_j V_ij + be_j V_i,pj           (p. = rotation partner, (al, be) = (c, -/+s)).
 // ---------------------------------------------------------------------------------------------
+// reciprocal / reciprocal square root: hardware seed + one Newton-Raphson step (~1e-16 relative)
+__device__ __forceinline__ double rcp_nr(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rsq_nr(double x) {
+  const double r = __builtin_amdgcn_rsq(x);
+  return r * fma(-0.5 * x * r, r, 1.5);
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -67,10 +77,9 @@ __device__ inline double wave_sum(double v) {
 }
 
 template <int EPLP>   // elements of the d x d block per lane: 1 (d <= 8), 4 (d <= 16), 16 (d <= 32)
-__global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __restrict__ mu,
-                                                  const double* __restrict__ Sigma) {
-  extern __shared__ double sm[];
-  const int d = f.d, dd = d * d, k = blockIdx.x, lane = threadIdx.x;
+__device__ inline void prep_body(const FactorDev& f, const double* __restrict__ mu, const double* __restrict__ Sigma,
+                                 int k, double* sm) {
+  const int d = f.d, dd = d * d, lane = threadIdx.x;
   const int dp = d + (d & 1);
   double* A0 = sm;
   double* A1 = A0 + dd;
@@ -124,10 +133,21 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
         if (valid) {
           const double apq = A[p * d + q];
           if (apq != 0.0) {
-            const double theta = (A[q * d + q] - A[p * d + p]) / (2.0 * apq);
-            const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            c = 1.0 / sqrt(t * t + 1.0);
-            s = t * c;
+            // fp64 div / sqrt sequences cost ~1 400 cycles per rotation on the critical path; hardware
+            // rcp / rsq + Newton steps give the same rotation.  Only (c, s) must be orthonormal to
+            // working precision (c gets two Newton steps); errors in theta / t merely perturb the
+            // convergence rate.
+            const double theta = (A[q * d + q] - A[p * d + p]) * rcp_nr(2.0 * apq);
+            if (fabs(theta) < 1e150) {               // else the rotation is the identity to fp64
+              const double w1 = fma(theta, theta, 1.0);
+              const double sq = w1 * rsq_nr(w1);
+              const double t = copysign(rcp_nr(fabs(theta) + sq), theta);
+              const double w2 = fma(t, t, 1.0);
+              double rc = rsq_nr(w2);
+              rc = rc * fma(fma(-0.5 * w2, rc, 0.0), rc, 1.5);   // second Newton step
+              c = rc;
+              s = t * c;
+            }
           }
         }
         al[p] = c; be[p] = -s; pa[p] = valid ? q : p;
@@ -188,6 +208,31 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
       f.u0[(size_t)k * m + lane] = u;
     }
   }
+}
+
+template <int EPLP>
+__global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __restrict__ mu,
+                                                  const double* __restrict__ Sigma) {
+  extern __shared__ double sm[];
+  prep_body<EPLP>(f, mu, Sigma, blockIdx.x, sm);
+}
+
+// every factor set of the problem in ONE launch: block -> (set, factor) through the offsets
+constexpr int MAX_FSETS = 8;
+struct PrepList {
+  int nsets;
+  int koff[MAX_FSETS + 1];
+  FactorDev f[MAX_FSETS];
+  const double* mu[MAX_FSETS];
+  const double* Sigma[MAX_FSETS];
+};
+
+template <int EPLP>
+__global__ __launch_bounds__(64) void prep_all_kernel(PrepList L) {
+  extern __shared__ double sm[];
+  int si = 0;
+  while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
+  prep_body<EPLP>(L.f[si], L.mu[si], L.Sigma[si], (int)blockIdx.x - L.koff[si], sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -522,10 +567,9 @@ struct EpiArgs {
   double* E_xxphi;         // [K][d][d] or null
 };
 
-__global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
-  extern __shared__ double sm[];
+__device__ inline void epilogue_body(const EpiArgs& a, int k, double* sm) {
   const FactorDev& f = a.f;
-  const int d = f.d, dd = d * d, k = blockIdx.x, lane = threadIdx.x;
+  const int d = f.d, dd = d * d, lane = threadIdx.x;
   const int npo = a.full ? npairs(d) : 1;
   double* Ms = sm;              // [npo]
   double* M2 = Ms + npairs(d);  // [d][d]
@@ -601,6 +645,24 @@ __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
       a.E_xxphi[(size_t)k * dd + e] = s;
     }
   }
+}
+
+__global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
+  extern __shared__ double sm[];
+  epilogue_body(a, blockIdx.x, sm);
+}
+
+struct EpiList {
+  int nsets;
+  int koff[MAX_FSETS + 1];
+  EpiArgs e[MAX_FSETS];
+};
+
+__global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L) {
+  extern __shared__ double sm[];
+  int si = 0;
+  while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
+  epilogue_body(L.e[si], (int)blockIdx.x - L.koff[si], sm);
 }
 
 // X[k][a][i] = mu_a + sum_b S_ab z_b[i]  (reference CUDA-path layout [factor][dim][point])
