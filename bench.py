@@ -123,13 +123,12 @@ def main():
         step_fn()
     barrier()
     t0 = time.perf_counter()
-    passes, kern_ms, cost_ms, log = 0, [], [], []
+    passes, kern_ms, log = 0, [], []
     for _ in range(args.steps):
         r = step_fn()
         log.append(r)
         passes += 1 + r["ntrials"]
         kern_ms.append(ctx.profile_last(ids[0], 0))
-        cost_ms.append(ctx.profile_last(ids[0], 1))
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -171,8 +170,7 @@ def main():
             "accepted_steps": int(sum(r["accepted"] for r in log)),
             "trials_per_step": float(np.mean([r["ntrials"] for r in log])),
             "final_cost": log[-1]["new_cost"],
-            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": K0 * N0 / km,
-                               "cost_kernel_ms": float(np.mean(cost_ms))},
+            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": K0 * N0 / km},
             # The dominant kernel streams only the (d,p) table, which is L2-resident (profiles/r01_traffic.json:
             # HBM traffic ~0.5 % of the algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.
             # The schema's compute label is "mfma"; fp64 MFMA and fp64 VALU share one pipe on MI355X and the

@@ -86,7 +86,11 @@ struct NgdState {
   bool ready = false;
   int cur = 0;
   DevMem mu[2], Lam[2], Sig[2], hld[2];   // Lam = [D | U], Sig = [SigD | SigU]
-  DevMem exch0, exch1;                    // [g | VD | VU], [cost partial sum]
+  DevMem exch0[2], exch1;                 // gradient buffers [g | VD | VU] (double-buffered for speculation), [cost partial sum]
+  DevMem dmu2[2];
+  int gcur = 0;                           // gradient buffer holding the gradients of `grad_slot`
+  bool grad_valid = false;
+  int grad_slot = -1;
   DevMem dmu, dLam, total;
   bool cost_valid[2] = {false, false};
   double cost[2] = {0, 0};
@@ -106,8 +110,10 @@ struct gvi_ctx {
   DevMem Wbuf, Ibuf, vbuf, scratch, hldtmp;
   std::string err;
   int variant = 0;
+  bool speculate = true;              // gvi_ngd_step: queue the next gradients behind the first trial
   int bcr_variant = 0;                // 0 auto (segmented where instantiated), 1 per-level kernels
   bool profile = false;
+  bool profile_all = false;           // events around every moments / cost launch (else: set 0, full pass only)
   int target_waves = 2048;
   hipEvent_t fork = nullptr;
   double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
@@ -284,7 +290,8 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   a.f = s.dev(); a.mu = mu; a.psi_ext = psi_ext; a.partial = s.partial.d();
   a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full;
   const int which = full ? 0 : 1;
-  if (c->profile) {
+  const bool prof = c->profile && (c->profile_all || (full && &s == c->sets[0].get()));
+  if (prof) {
     for (int e = 0; e < 2; ++e)
       if (!s.ev[which][e]) HIPCK(c, hipEventCreate(&s.ev[which][e]));
     HIPCK(c, hipEventRecord(s.ev[which][0], st));
@@ -310,7 +317,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     hipLaunchKernelGGL(moments_generic_kernel, dim3(s.K, s.nchunk), dim3(GEN_BS), lds, st, a);
   }
   HIPCK(c, hipGetLastError());
-  if (c->profile) {
+  if (prof) {
     HIPCK(c, hipEventRecord(s.ev[which][1], st));
     s.ev_set[which] = true;
   }
@@ -606,6 +613,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
+  if (const char* w = getenv("GVI_SPECULATE")) c->speculate = atoi(w) != 0;
   if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
@@ -805,6 +813,7 @@ gvi_status gvi_factors_set_temperature(gvi_ctx* ctx, int set_id, const double* t
   GVICK(sync(ctx));
   HIPCK(ctx, hipMemcpy(s->temperature.p, temperature, (size_t)s->K * 8, hipMemcpyHostToDevice));
   ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
   return GVI_OK;
 }
 
@@ -1132,14 +1141,19 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i) {
   return GVI_OK;
 }
 
-static gvi_status ngd_cost_finish(gvi_ctx* ctx, int i, double* out) {
+static gvi_status ngd_cost_publish(gvi_ctx* ctx, int i) {
   NgdState& g = ctx->ngd;
   ctx->seq += 1.0;
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev,
                      ctx->seq);
   HIPCK(ctx, hipGetLastError());
-  // spin on the host-mapped sequence word (a blocking stream sync costs tens of us of wake-up latency);
-  // bounded: fall back to the stream sync after ~50 ms
+  return GVI_OK;
+}
+
+static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
+  NgdState& g = ctx->ngd;
+  // spin on the host-mapped sequence word (a blocking stream sync costs tens of us of wake-up latency and
+  // would also wait for speculative work queued behind the publish); bounded: falls back to the stream sync
   {
     volatile double* slot = ctx->host_slot;
     bool seen = false;
@@ -1157,6 +1171,11 @@ static gvi_status ngd_cost_finish(gvi_ctx* ctx, int i, double* out) {
   return GVI_OK;
 }
 
+static gvi_status ngd_cost_finish(gvi_ctx* ctx, int i, double* out) {
+  GVICK(ngd_cost_publish(ctx, i));
+  return ngd_cost_wait(ctx, i, out);
+}
+
 gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const double* U) {
   if (!ctx) return GVI_ERR_ARG;
   if (ctx->T < 1) return fail(ctx, GVI_ERR_STATE, "call gvi_chain_set first");
@@ -1170,7 +1189,11 @@ gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const d
     HIPCK(ctx, g.Sig[i].ensure(bt * 8));
     HIPCK(ctx, g.hld[i].ensure(8));
   }
-  HIPCK(ctx, g.exch0.ensure((T * n + bt) * 8));
+  for (int i = 0; i < 2; ++i) {
+    HIPCK(ctx, g.exch0[i].ensure((T * n + bt) * 8));
+    HIPCK(ctx, g.dmu2[i].ensure(T * n * 8));
+  }
+  g.gcur = 0; g.grad_valid = false; g.grad_slot = -1;
   HIPCK(ctx, g.exch1.ensure(8));
   HIPCK(ctx, g.dmu.ensure(T * n * 8));
   HIPCK(ctx, g.dLam.ensure(bt * 8));
@@ -1223,35 +1246,48 @@ gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs) {
   return sync(ctx);
 }
 
-gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx) {
-  GVICK(ngd_check(ctx));
-  HIPCK(ctx, hipSetDevice(ctx->device));
+// moments of every set at NGD slot `slot`, ordered assemble into gradient buffer `gb`
+static gvi_status ngd_grad_local(gvi_ctx* ctx, int slot, int gb) {
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, n = ctx->n, nn = n * n;
-  const int i = g.cur;
-  double* eg = g.exch0.d();
+  double* eg = g.exch0[gb].d();
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
-  GVICK(ngd_prep_all(ctx, i));
-  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 1));
+  GVICK(ngd_prep_all(ctx, slot));
+  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[slot].d(), nullptr, 1));
   GVICK(ngd_epilogue_all(ctx, 1));
   const int64_t total = (int64_t)T * (n + 2 * nn);
   hipLaunchKernelGGL(bt_scatter_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     make_set_list(ctx, i), ctx->T, ctx->n, eg, eD, eU);
+                     make_set_list(ctx, slot), ctx->T, ctx->n, eg, eD, eU);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
+}
+
+// dmu = Vddmu^-1 (-Vdmu) from gradient buffer `gb` (dprecision = V - Lambda is formed inside the trial)
+static gvi_status ngd_grad_finish(gvi_ctx* ctx, int gb) {
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n;
+  double* eg = g.exch0[gb].d();
+  double* eD = eg + T * n;
+  double* eU = eD + T * nn;
+  return run_bt_solve(ctx, eD, eU, eg, -1.0, g.dmu2[gb].d());
+}
+
+gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  ctx->ngd.grad_valid = false;
+  return ngd_grad_local(ctx, ctx->ngd.cur, ctx->ngd.gcur);
 }
 
 gvi_status gvi_ngd_gradients_finish(gvi_ctx* ctx) {
   GVICK(ngd_check(ctx));
   HIPCK(ctx, hipSetDevice(ctx->device));
-  NgdState& g = ctx->ngd;
-  const size_t T = ctx->T, n = ctx->n, nn = n * n;
-  double* eg = g.exch0.d();
-  double* eD = eg + T * n;
-  double* eU = eD + T * nn;
-  return run_bt_solve(ctx, eD, eU, eg, -1.0, g.dmu.d());     // dprecision = V - Lambda is formed inside the trial
+  GVICK(ngd_grad_finish(ctx, ctx->ngd.gcur));
+  ctx->ngd.grad_valid = true;
+  ctx->ngd.grad_slot = ctx->ngd.cur;
+  return GVI_OK;
 }
 
 gvi_status gvi_ngd_gradients(gvi_ctx* ctx) {
@@ -1263,10 +1299,12 @@ gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step) {
   GVICK(ngd_check(ctx));
   HIPCK(ctx, hipSetDevice(ctx->device));
   NgdState& g = ctx->ngd;
+  if (!(g.grad_valid && g.grad_slot == g.cur)) return fail(ctx, GVI_ERR_STATE, "call gvi_ngd_gradients first");
   const size_t Tn = (size_t)ctx->T * ctx->n, bt = bt_count(ctx);
   const int c = g.cur, t = 1 - c;
   hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn,
-                     (int64_t)bt, step, g.mu[c].d(), g.dmu.d(), g.Lam[c].d(), g.exch0.d() + Tn, g.mu[t].d(), g.Lam[t].d());
+                     (int64_t)bt, step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn,
+                     g.mu[t].d(), g.Lam[t].d());
   HIPCK(ctx, hipGetLastError());
   g.cost_valid[t] = false;
   GVICK(ngd_refresh(ctx, t));
@@ -1292,23 +1330,43 @@ gvi_status gvi_ngd_accept(gvi_ctx* ctx) {
   if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
   ctx->ngd.cur = 1 - ctx->ngd.cur;
   ctx->ngd.have_trial = false;
+  ctx->ngd.grad_valid = false;
   return GVI_OK;
 }
 
 gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter, int* accepted,
                         double* new_cost, int* ntrials) {
   GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
   double c0 = 0.0;
   GVICK(gvi_ngd_cost(ctx, &c0));
   if (cost_iter) *cost_iter = c0;
-  GVICK(gvi_ngd_gradients(ctx));
+  if (!(g.grad_valid && g.grad_slot == g.cur)) GVICK(gvi_ngd_gradients(ctx));   // else: computed speculatively
   double step = step_size_base, c1 = c0;
   int cnt = 0, ok = 0;
   while (true) {
     step *= 0.75;                                  // gvibase/GVI-GH-impl.h:83
-    GVICK(gvi_ngd_trial(ctx, step, &c1));
-    if (c1 < c0) { GVICK(gvi_ngd_accept(ctx)); ok = 1; ++cnt; break; }   // NaN compares false -> rejected
+    GVICK(gvi_ngd_trial_local(ctx, step));
+    const int t = 1 - g.cur;
+    GVICK(ngd_cost_publish(ctx, t));
+    // Speculation: the first trial is accepted in the common case, and then the next iteration starts
+    // with the gradients at exactly this trial state.  Queue them BEHIND the publish, into the other
+    // gradient buffer, so the device never idles while the host reads the cost and decides.  A rejected
+    // trial just leaves that buffer unused (same numbers either way).
+    const bool spec = cnt == 0 && ctx->speculate;
+    if (spec) {
+      GVICK(ngd_grad_local(ctx, t, 1 - g.gcur));
+      GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
+    }
+    GVICK(ngd_cost_wait(ctx, t, &c1));
     ++cnt;
+    if (c1 < c0) {                                 // NaN compares false -> rejected
+      GVICK(gvi_ngd_accept(ctx));
+      if (spec) { g.gcur = 1 - g.gcur; g.grad_valid = true; g.grad_slot = g.cur; }
+      ok = 1;
+      break;
+    }
     if (cnt > max_backtrack) break;
   }
   if (accepted) *accepted = ok;
@@ -1320,7 +1378,7 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
 gvi_status gvi_ngd_exchange(gvi_ctx* ctx, int which, void** dev_ptr, int64_t* count) {
   GVICK(ngd_check(ctx));
   if (!dev_ptr || !count) return fail(ctx, GVI_ERR_ARG, "NULL argument");
-  if (which == 0) { *dev_ptr = ctx->ngd.exch0.p; *count = (int64_t)((size_t)ctx->T * ctx->n + bt_count(ctx)); }
+  if (which == 0) { *dev_ptr = ctx->ngd.exch0[ctx->ngd.gcur].p; *count = (int64_t)((size_t)ctx->T * ctx->n + bt_count(ctx)); }
   else if (which == 1) { *dev_ptr = ctx->ngd.exch1.p; *count = 1; }
   else return fail(ctx, GVI_ERR_ARG, "which must be 0 or 1");
   return GVI_OK;
@@ -1345,12 +1403,13 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
   HIPCK(ctx, hipSetDevice(ctx->device));
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, n = ctx->n, nn = n * n, bt = bt_count(ctx);
-  if (dmu) GVICK(d2h(ctx, dmu, g.dmu.p, T * n * 8));
-  if (gq) GVICK(d2h(ctx, gq, g.exch0.p, T * n * 8));
+  if (!(g.grad_valid)) return fail(ctx, GVI_ERR_STATE, "no gradients computed for the current proposal");
+  if (dmu) GVICK(d2h(ctx, dmu, g.dmu2[g.gcur].p, T * n * 8));
+  if (gq) GVICK(d2h(ctx, gq, g.exch0[g.gcur].p, T * n * 8));
   std::vector<double> V, L;
   if (dD || dU || VD || VU) {
     V.resize(bt);
-    GVICK(d2h(ctx, V.data(), g.exch0.d() + T * n, bt * 8));
+    GVICK(d2h(ctx, V.data(), g.exch0[g.gcur].d() + T * n, bt * 8));
   }
   if (dD || dU) {
     L.resize(bt);
@@ -1367,6 +1426,7 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on) {
   if (!ctx) return GVI_ERR_ARG;
   ctx->profile = on != 0;
+  ctx->profile_all = on > 1;
   for (auto& s : ctx->sets) s->ev_set[0] = s->ev_set[1] = false;
   return GVI_OK;
 }

@@ -71,10 +71,10 @@ class HipEngine:
             dist.all_reduce(self.exchange_tensor(which), op=dist.ReduceOp.SUM, group=group)
 
     def exchange_tensor(self, which: int):
-        if which not in self._ex:
-            ptr, cnt = self.ctx.ngd_exchange(which)
-            self._ex[which] = self.torch.as_tensor(_DevArray(ptr, cnt), device=self.device)
-        return self._ex[which]
+        ptr, cnt = self.ctx.ngd_exchange(which)          # the gradient buffer can flip (gvi_ngd_step speculation)
+        if self._ex.get(which, (None,))[0] != ptr:
+            self._ex[which] = (ptr, self.torch.as_tensor(_DevArray(ptr, cnt), device=self.device))
+        return self._ex[which][1]
 
     def gradients_local(self): self.ctx.ngd_gradients_local()
     def gradients_finish(self): self.ctx.ngd_gradients_finish()

@@ -171,7 +171,9 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
                                  double* VD, double* VU);
 
 /* ---- measurement hooks (bench.py): HIP-event time of the last moments / cost kernel launch of a
- *      set, in milliseconds, measured on the context stream; enable before the launches. ---- */
+ *      set, in milliseconds, measured on the context stream; enable before the launches.
+ *      on = 1: only the dominant launch (set 0, full moments pass) is bracketed -- an event pair costs
+ *      ~10 us of queue gaps; on = 2: every moments / cost launch of every set. ---- */
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on);
 gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kernel, 1 cost kernel*/, float* ms);
 /* Launch geometry of the set's last moments/cost launch: variant (1 generic, 2 register), chunks. */
