@@ -53,6 +53,8 @@ struct FactorSet {
   std::shared_ptr<Table> table;
   DevMem dstart, dptr, didx, A, b, sgn, raw, temperature;
   DevMem S, Sinv, Lam, H, u0;         // per-pass products
+  DevMem Vws;                         // eigenvectors of the last resident-NGD prep (Jacobi warm start)
+  int warm_count = 0;                 // preps since the last cold start
   DevMem partial;
   int nchunk = 1;
   int64_t chunk = 0;
@@ -78,6 +80,7 @@ struct FactorSet {
     f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
     f.temperature = temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.u0 = u0.d();
+    f.Vws = nullptr; f.warm = 0;
     return f;
   }
 };
@@ -110,6 +113,7 @@ struct gvi_ctx {
   DevMem Wbuf, Ibuf, vbuf, scratch, hldtmp;
   std::string err;
   int variant = 0;
+  bool warm_start = true;             // resident NGD: Jacobi warm start from the previous eigenvectors
   bool speculate = true;              // gvi_ngd_step: queue the next gradients behind the first trial
   int bcr_variant = 0;                // 0 auto (segmented where instantiated), 1 per-level kernels
   bool profile = false;
@@ -614,6 +618,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
   if (const char* w = getenv("GVI_SPECULATE")) c->speculate = atoi(w) != 0;
+  if (const char* w = getenv("GVI_WARM_START")) c->warm_start = atoi(w) != 0;
   if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
@@ -1064,6 +1069,12 @@ static gvi_status ngd_prep_all(gvi_ctx* ctx, int i) {
     if (s->prep_slot == i) continue;
     s->prep_slot = i;
     L.f[L.nsets] = s->dev();
+    if (ctx->warm_start) {                 // warm-started Jacobi; a cold start every 32nd prep bounds the drift
+      if (s->Vws.bytes == 0) { HIPCK(ctx, s->Vws.ensure((size_t)s->K * s->d * s->d * 8)); s->warm_count = 0; }
+      L.f[L.nsets].Vws = s->Vws.d();
+      L.f[L.nsets].warm = (s->warm_count % 32) != 0;
+      s->warm_count++;
+    }
     L.mu[L.nsets] = s->mu_k[i].d();
     L.Sigma[L.nsets] = s->Sigma_k[i].d();
     L.koff[L.nsets + 1] = L.koff[L.nsets] + s->K;
@@ -1200,7 +1211,7 @@ gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const d
   HIPCK(ctx, g.total.ensure(8));
   for (auto& s : ctx->sets) GVICK(ensure_set_buffers(ctx, *s));
   g.cur = 0; g.have_trial = false;
-  for (auto& s : ctx->sets) s->prep_slot = -1;
+  for (auto& s : ctx->sets) { s->prep_slot = -1; s->warm_count = 0; }
   g.cost_valid[0] = g.cost_valid[1] = false;
   GVICK(h2d(ctx, g.mu[0].p, mu, T * n * 8));
   GVICK(h2d(ctx, g.Lam[0].p, D, T * nn * 8));

@@ -52,6 +52,8 @@ struct FactorDev {
   double* Lam;              // [K][d][d]
   double* H;                // [K][d][m]  H = A S, stored column by column
   double* u0;               // [K][m]
+  double* Vws;              // [K][d][d] eigenvectors of the previous prep (warm start) or null
+  int warm;                 // 1: start the Jacobi sweeps from Vws (resident NGD iteration only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -97,12 +99,55 @@ __device__ inline void prep_body(const FactorDev& f, const double* __restrict__ 
     ej[q] = e < dd ? e % d : 0;
   }
   const double* Sg = Sigma + (size_t)k * dd;
+  // Warm start (device-resident NGD iteration): consecutive proposals differ little, so the previous
+  // eigenvectors W almost diagonalise the new block; sweeping A0 = W^T Sigma W from V0 = W needs 2-4
+  // sweeps instead of 7-8.  Any orthogonal start gives the same decomposition up to rounding; a NaN
+  // in W (left by a rejected non-PSD trial) falls back to the cold start.
+  bool warm = f.warm != 0 && f.Vws != nullptr;
+  if (warm) {
+    int bad = 0;
 #pragma unroll
-  for (int q = 0; q < EPLP; ++q) {
-    if (ei[q] >= 0) {
-      const int i = ei[q], j = ej[q], e = lane + q * 64;
-      A0[e] = i >= j ? Sg[i * d + j] : Sg[j * d + i];   // lower triangle, like SelfAdjointEigenSolver
-      V0[e] = i == j ? 1.0 : 0.0;
+    for (int q = 0; q < EPLP; ++q) {
+      if (ei[q] >= 0) {
+        const int i = ei[q], j = ej[q], e = lane + q * 64;
+        const double v = f.Vws[(size_t)k * dd + e];
+        bad |= !(fabs(v) <= 2.0);
+        V0[e] = v;
+        A1[e] = i >= j ? Sg[i * d + j] : Sg[j * d + i];
+      }
+    }
+    warm = __ballot(bad) == 0;
+    wave_lds_sync();
+    if (warm) {
+#pragma unroll
+      for (int q = 0; q < EPLP; ++q) {              // T = Sigma W  -> V1
+        if (ei[q] >= 0) {
+          const int i = ei[q], j = ej[q];
+          double t = 0.0;
+          for (int c = 0; c < d; ++c) t += A1[i * d + c] * V0[c * d + j];
+          V1[lane + q * 64] = t;
+        }
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < EPLP; ++q) {              // A0 = W^T T, upper triangle mirrored (exactly symmetric)
+        if (ei[q] >= 0) {
+          const int i = ei[q] <= ej[q] ? ei[q] : ej[q], j = ei[q] <= ej[q] ? ej[q] : ei[q];
+          double t = 0.0;
+          for (int c = 0; c < d; ++c) t += V0[c * d + i] * V1[c * d + j];
+          A0[lane + q * 64] = t;
+        }
+      }
+    }
+  }
+  if (!warm) {
+#pragma unroll
+    for (int q = 0; q < EPLP; ++q) {
+      if (ei[q] >= 0) {
+        const int i = ei[q], j = ej[q], e = lane + q * 64;
+        A0[e] = i >= j ? Sg[i * d + j] : Sg[j * d + i];   // lower triangle, like SelfAdjointEigenSolver
+        V0[e] = i == j ? 1.0 : 0.0;
+      }
     }
   }
   wave_lds_sync();
@@ -187,6 +232,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* __restrict__ 
         s0 += vv * lam[c]; s1 += vv * lam[d + c]; s2 += vv * lam[2 * d + c];
       }
       An[e] = s0;
+      if (f.Vws) f.Vws[(size_t)k * dd + e] = V[e];
       f.S[(size_t)k * dd + e] = s0;
       f.Sinv[(size_t)k * dd + e] = s1;
       f.Lam[(size_t)k * dd + e] = s2;
