@@ -132,6 +132,24 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # extra (not part of `value`): the fused single-pass scheduling of the same iteration
+    fused = None
+    if world == 1 and not ngd.group_forced:
+        ctx.ngd_set_mode(True, True)
+        ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
+        for _ in range(args.warmup):
+            ctx.ngd_step(0.55, 10)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        flog = [ctx.ngd_step(0.55, 10) for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf0
+        fused = {"ms_per_step": 1e3 * tf / args.steps, "ngd_iters_per_s": args.steps / tf,
+                 "final_cost": flog[-1]["new_cost"],
+                 "note": "gvi_ngd_set_mode(fuse_trial=1): one psi pass per accepted iteration (trial cost = m0 of the "
+                         "full moments pass that is also the next gradient pass); identical iterates"}
+        ctx.ngd_set_mode(True, False)
+
     stats = torch.tensor([elapsed, float(passes * evals_moments)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = stats.clone()
@@ -170,6 +188,7 @@ def main():
             "accepted_steps": int(sum(r["accepted"] for r in log)),
             "trials_per_step": float(np.mean([r["ntrials"] for r in log])),
             "final_cost": log[-1]["new_cost"],
+            "fused_trial_mode": fused,
             "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": K0 * N0 / km},
             # The dominant kernel streams only the (d,p) table, which is L2-resident (profiles/r01_traffic.json:
             # HBM traffic ~0.5 % of the algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.

@@ -235,6 +235,9 @@ class Context:
                                        C.byref(c1), C.byref(ntr)))
         return dict(cost_iter=c0.value, accepted=bool(ok.value), new_cost=c1.value, ntrials=ntr.value)
 
+    def ngd_set_mode(self, speculate=True, fuse_trial=False):
+        self._ck(self.lib.gvi_ngd_set_mode(self.h, int(speculate), int(fuse_trial)))
+
     def ngd_exchange(self, which):
         ptr, cnt = C.c_void_p(), C.c_int64()
         self._ck(self.lib.gvi_ngd_exchange(self.h, which, C.byref(ptr), C.byref(cnt)))

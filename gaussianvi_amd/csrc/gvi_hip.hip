@@ -114,6 +114,7 @@ struct gvi_ctx {
   std::string err;
   int variant = 0;
   bool warm_start = true;             // resident NGD: Jacobi warm start from the previous eigenvectors
+  bool fuse_trial = false;            // gvi_ngd_step: trial cost from the full moments pass (one psi pass per iteration)
   bool speculate = true;              // gvi_ngd_step: queue the next gradients behind the first trial
   int bcr_variant = 0;                // 0 auto (segmented where instantiated), 1 per-level kernels
   bool profile = false;
@@ -619,6 +620,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
   if (const char* w = getenv("GVI_SPECULATE")) c->speculate = atoi(w) != 0;
   if (const char* w = getenv("GVI_WARM_START")) c->warm_start = atoi(w) != 0;
+  if (const char* w = getenv("GVI_FUSE_TRIAL")) c->fuse_trial = atoi(w) != 0;
   if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
       hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
@@ -1257,22 +1259,31 @@ gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs) {
   return sync(ctx);
 }
 
-// moments of every set at NGD slot `slot`, ordered assemble into gradient buffer `gb`
-static gvi_status ngd_grad_local(gvi_ctx* ctx, int slot, int gb) {
+// full moments pass of every set at NGD slot `slot` (per-factor Vdmu / Vddmu / E[psi] / cost)
+static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot) {
+  if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
+  GVICK(ngd_prep_all(ctx, slot));
+  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[slot].d(), nullptr, 1));
+  return ngd_epilogue_all(ctx, 1);
+}
+
+// ordered assemble of the per-factor results into gradient buffer `gb`
+static gvi_status ngd_scatter(gvi_ctx* ctx, int slot, int gb) {
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, n = ctx->n, nn = n * n;
   double* eg = g.exch0[gb].d();
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
-  if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
-  GVICK(ngd_prep_all(ctx, slot));
-  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[slot].d(), nullptr, 1));
-  GVICK(ngd_epilogue_all(ctx, 1));
   const int64_t total = (int64_t)T * (n + 2 * nn);
   hipLaunchKernelGGL(bt_scatter_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                      make_set_list(ctx, slot), ctx->T, ctx->n, eg, eD, eU);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
+}
+
+static gvi_status ngd_grad_local(gvi_ctx* ctx, int slot, int gb) {
+  GVICK(ngd_moments_full(ctx, slot));
+  return ngd_scatter(ctx, slot, gb);
 }
 
 // dmu = Vddmu^-1 (-Vdmu) from gradient buffer `gb` (dprecision = V - Lambda is formed inside the trial)
@@ -1306,9 +1317,8 @@ gvi_status gvi_ngd_gradients(gvi_ctx* ctx) {
   return gvi_ngd_gradients_finish(ctx);
 }
 
-gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step) {
-  GVICK(ngd_check(ctx));
-  HIPCK(ctx, hipSetDevice(ctx->device));
+// trial proposal into the other slot: state, chain factorisation (log-det + marginals), gather
+static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
   NgdState& g = ctx->ngd;
   if (!(g.grad_valid && g.grad_slot == g.cur)) return fail(ctx, GVI_ERR_STATE, "call gvi_ngd_gradients first");
   const size_t Tn = (size_t)ctx->T * ctx->n, bt = bt_count(ctx);
@@ -1319,9 +1329,15 @@ gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step) {
   HIPCK(ctx, hipGetLastError());
   g.cost_valid[t] = false;
   GVICK(ngd_refresh(ctx, t));
-  GVICK(ngd_cost_local(ctx, t));
   g.have_trial = true;
   return GVI_OK;
+}
+
+gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step) {
+  GVICK(ngd_check(ctx));
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(ngd_trial_state(ctx, step));
+  return ngd_cost_local(ctx, 1 - ctx->ngd.cur);
 }
 
 gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost) {
@@ -1358,17 +1374,30 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
   int cnt = 0, ok = 0;
   while (true) {
     step *= 0.75;                                  // gvibase/GVI-GH-impl.h:83
-    GVICK(gvi_ngd_trial_local(ctx, step));
     const int t = 1 - g.cur;
-    GVICK(ngd_cost_publish(ctx, t));
-    // Speculation: the first trial is accepted in the common case, and then the next iteration starts
-    // with the gradients at exactly this trial state.  Queue them BEHIND the publish, into the other
-    // gradient buffer, so the device never idles while the host reads the cost and decides.  A rejected
-    // trial just leaves that buffer unused (same numbers either way).
     const bool spec = cnt == 0 && ctx->speculate;
-    if (spec) {
-      GVICK(ngd_grad_local(ctx, t, 1 - g.gcur));
+    GVICK(ngd_trial_state(ctx, step));
+    if (spec && ctx->fuse_trial) {
+      // Fused form: ONE full moments pass at the trial point serves both the trial cost (its m0 column)
+      // and -- if the trial is accepted -- the next iteration's gradients.  Same numbers, one psi pass
+      // less per accepted iteration; a rejected first trial wasted the moment accumulation.
+      GVICK(ngd_moments_full(ctx, t));
+      hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, t), g.exch1.d());
+      HIPCK(ctx, hipGetLastError());
+      GVICK(ngd_cost_publish(ctx, t));
+      GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
       GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
+    } else {
+      GVICK(ngd_cost_local(ctx, t));
+      GVICK(ngd_cost_publish(ctx, t));
+      // Speculation: the first trial is accepted in the common case, and then the next iteration starts
+      // with the gradients at exactly this trial state.  Queue them BEHIND the publish, into the other
+      // gradient buffer, so the device never idles while the host reads the cost and decides.  A rejected
+      // trial just leaves that buffer unused (same numbers either way).
+      if (spec) {
+        GVICK(ngd_grad_local(ctx, t, 1 - g.gcur));
+        GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
+      }
     }
     GVICK(ngd_cost_wait(ctx, t, &c1));
     ++cnt;
@@ -1383,6 +1412,13 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
   if (accepted) *accepted = ok;
   if (new_cost) *new_cost = ok ? c1 : c0;
   if (ntrials) *ntrials = cnt;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_set_mode(gvi_ctx* ctx, int speculate, int fuse_trial) {
+  if (!ctx) return GVI_ERR_ARG;
+  ctx->speculate = speculate != 0;
+  ctx->fuse_trial = fuse_trial != 0;
   return GVI_OK;
 }
 

@@ -238,21 +238,33 @@ __device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int le
 __device__ inline double seg_fold_D(const SegArgs& a, int x, int el) {
   const int nn = a.n * a.n;
   double v = (a.level0 == 0 ? a.D : a.w.Deff)[(size_t)x * nn + el];
-  for (int l = a.prev0; l < a.level0; ++l) {
-    const int h = 1 << l;
-    if (x - h >= 0) v -= a.w.CR[(size_t)(x - h) * nn + el];
-    if (x + h < a.T) v -= a.w.CL[(size_t)(x + h) * nn + el];
+  // at most 5 levels per pass (seg_plan): a fixed-trip, fully unrolled loop keeps the (independent)
+  // loads in flight together instead of one global round trip per level
+  double cr[5], cl[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int l = a.prev0 + q, h = 1 << l;
+    const bool on = l < a.level0;
+    cr[q] = (on && x - h >= 0) ? a.w.CR[(size_t)(x - h) * nn + el] : 0.0;
+    cl[q] = (on && x + h < a.T) ? a.w.CL[(size_t)(x + h) * nn + el] : 0.0;
   }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { v -= cr[q]; v -= cl[q]; }
   return v;
 }
 __device__ inline double seg_fold_y(const SegArgs& a, int x, int r) {
   const int n = a.n;
   double v = a.level0 == 0 ? a.rhs_scale * a.rhs[(size_t)x * n + r] : a.w.yeff[(size_t)x * n + r];
-  for (int l = a.prev0; l < a.level0; ++l) {
-    const int h = 1 << l;
-    if (x - h >= 0) v -= a.w.yR[(size_t)(x - h) * n + r];
-    if (x + h < a.T) v -= a.w.yL[(size_t)(x + h) * n + r];
+  double yr[5], yl[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int l = a.prev0 + q, h = 1 << l;
+    const bool on = l < a.level0;
+    yr[q] = (on && x - h >= 0) ? a.w.yR[(size_t)(x - h) * n + r] : 0.0;
+    yl[q] = (on && x + h < a.T) ? a.w.yL[(size_t)(x + h) * n + r] : 0.0;
   }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { v -= yr[q]; v -= yl[q]; }
   return v;
 }
 
@@ -345,18 +357,21 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
     seg_eliminate<PIVOT, N>(a, 0, Dl, nullptr, nullptr, yl, CLl, CRl, NUl, yLl, yRl, scratch, El, GAl, GBl,
                             rhs ? vl : nullptr, lane);
   lds_barrier();                                     // the factors of these nodes live in LDS (El, GAl, GBl, vl)
-  if (a.hld) {
-    int* redb = (int*)(red + 1024);
+  if (a.hld) {                                       // 1/2 sum of the log-pivots of ALL nodes (every pass)
+    int* redb = (int*)(red + 64);
     double s = 0.0;
     int bflag = 0;
     for (int t = tid; t < T; t += blockDim.x) { s += a.w.logp[t]; bflag |= a.w.bad[t]; }
-    red[tid] = s; redb[tid] = bflag;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); bflag |= __shfl_xor(bflag, o); }
+    if (lane == 0) { red[wave] = s; redb[wave] = bflag; }
     lds_barrier();
-    for (int wdt = blockDim.x / 2; wdt > 0; wdt >>= 1) {
-      if (tid < wdt) { red[tid] += red[tid + wdt]; redb[tid] |= redb[tid + wdt]; }
-      lds_barrier();
+    if (tid == 0) {
+      double tot = 0.0;
+      int bb = 0;
+      for (int wv = 0; wv < nwaves; ++wv) { tot += red[wv]; bb |= redb[wv]; }   // fixed order
+      a.hld[0] = bb ? __builtin_nan("") : 0.5 * tot;
     }
-    if (tid == 0) a.hld[0] = redb[0] ? __builtin_nan("") : 0.5 * red[0];
     lds_barrier();
   }
   // ---- backward recursion for the nodes of this pass ----

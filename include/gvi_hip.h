@@ -152,6 +152,13 @@ gvi_status gvi_ngd_accept(gvi_ctx* ctx);
  * cost at entry; accepted/new_cost/ntrials report the outcome. */
 gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter,
                         int* accepted, double* new_cost, int* ntrials);
+/* Scheduling of gvi_ngd_step (results are identical in every mode):
+ *   speculate  1 (default): the next iteration's gradients are queued behind the first trial, so the
+ *              device does not idle while the host reads the cost; 0: strictly trial-then-decide;
+ *   fuse_trial 1: the first trial's cost is taken from a FULL moments pass at the trial point, which is
+ *              also the next iteration's gradient pass (one psi pass per accepted iteration instead of
+ *              the reference's cost pass + gradient pass); 0 (default): separate passes as the reference. */
+gvi_status gvi_ngd_set_mode(gvi_ctx* ctx, int speculate, int fuse_trial);
 /* Split forms for sharded factors (one process per GPU): *_local does the rank's factors and leaves
  * the partial sums in the exchange buffer; the caller all-reduces gvi_ngd_exchange() over the ranks
  * (RCCL); *_finish does the replicated chain work.  Single GPU: local; finish. */

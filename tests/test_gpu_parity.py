@@ -352,6 +352,27 @@ def test_ngd_iterations_vs_oracle(name, iters):
     ctx.close()
 
 
+@pytest.mark.parametrize("speculate,fuse", [(0, 0), (1, 0), (1, 1)])
+def test_step_scheduling_modes_give_identical_iterates(speculate, fuse):
+    """gvi_ngd_set_mode only changes what is queued when: plain trial-then-decide, speculative next
+    gradients, and the fused single-pass form all produce the same costs and (to rounding) iterates."""
+    ch = make_chain("c2")
+    ref = None
+    out = []
+    for mode in [(0, 0), (speculate, fuse)]:
+        ctx, ids = api.context_for_chain(ch)
+        ctx.ngd_set_mode(*mode)
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        log = [ctx.ngd_step(0.55, 10) for _ in range(6)]
+        out.append((log, ctx.ngd_get_state()))
+        ctx.close()
+    (l0, s0), (l1, s1) = out
+    for a, b in zip(l0, l1):
+        assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"]
+        assert np.isclose(a["new_cost"], b["new_cost"], rtol=1e-12)
+    assert rel(s1["mu"], s0["mu"]) < 1e-10 and rel(s1["D"], s0["D"]) < 1e-10
+
+
 def test_linesearch_rejects_nan_and_backtracks():
     """A huge base step makes the trial precision indefinite: log-det NaN -> rejected -> backtrack
     (gvibase/GVI-GH-impl.h:92-117 with the NaN rule of section 3.1)."""
