@@ -196,7 +196,7 @@ def main():
             # VALU form is the faster one (profiles/r01_fp64_pipes.txt), so the kernel uses v_fma_f64.
             "roofline": {"bound": "mfma", "achieved": f_alg * K0 * N0 / km / 1e12, "peak": FP64_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": f_alg * K0 * N0 / km / FP64_PEAK, "traffic": traffic,
-                         "kernel": "moments_reg_kernel<12, PsiQuad<12,6>, full>" if geo["variant"] == 2 else "moments_generic_kernel",
+                         "kernel": "moments_tile_kernel<12, PsiQuad<12,6>, full>" if geo["variant"] == 2 else "moments_generic_kernel",
                          "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": 188,
                          "executed_tflops": 2 * 188 * K0 * N0 / km / 1e12,
                          "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "

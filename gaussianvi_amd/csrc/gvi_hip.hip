@@ -164,7 +164,7 @@ gvi_status sync(gvi_ctx* c) {
 }
 
 gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const double* Z, const double* w) {
-  t.d = d; t.p = p; t.N = N; t.Np = (N + 63) / 64 * 64;
+  t.d = d; t.p = p; t.N = N; t.Np = (N + 255) / 256 * 256;   // tile kernels walk 256-point tiles
   std::vector<double> zt((size_t)d * t.Np, 0.0), wp(t.Np, 0.0);
   for (int64_t i = 0; i < N; ++i) {
     wp[i] = w[i];
@@ -194,11 +194,11 @@ bool reg_supported(int kind, int d, int m) {
 void plan_chunks(gvi_ctx* c, FactorSet& s, bool reg) {
   const int64_t Np = s.table->Np;
   if (reg) {
-    const int64_t iters = Np / 64;
+    const int64_t iters = Np / 256;                       // 256-point tiles (the tile kernel needs whole tiles)
     int64_t nch = std::max<int64_t>(1, (c->target_waves + s.K - 1) / s.K);
-    nch = std::min<int64_t>(nch, std::max<int64_t>(1, iters / 4));
+    nch = std::min<int64_t>(nch, std::max<int64_t>(1, iters));
     const int64_t per = (iters + nch - 1) / nch;
-    s.chunk = per * 64;
+    s.chunk = per * 256;
     s.nchunk = (int)((Np + s.chunk - 1) / s.chunk);
   } else {
     const int64_t blocks = (Np + 255) / 256;
@@ -220,6 +220,19 @@ template <int D, typename Psi>
 void launch_wide(const MomArgs& a, dim3 grid, hipStream_t st) {
   if (a.full) hipLaunchKernelGGL((moments_wide_kernel<D, Psi, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((moments_wide_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
+}
+
+template <int D, typename Psi>
+void launch_tile(const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (a.full) hipLaunchKernelGGL((moments_tile_kernel<D, Psi, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((moments_tile_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
+}
+
+// LDS-staged-table kernel (variant 4): instantiated for the headline shape
+bool dispatch_tile(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (s.kind == KIND_QUAD_PRIOR && s.d == 12) { launch_tile<12, PsiQuad<12, 6>>(a, grid, st); return true; }
+  if (s.kind == KIND_FIXED_PRIOR && s.d == 6) { launch_tile<6, PsiQuad<6, 6>>(a, grid, st); return true; }
+  return false;
 }
 
 // operand-resident kernel: instantiated for the shapes of the BASELINE configs
@@ -306,7 +319,8 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     bool done = false;
     // auto: the operand-resident kernel wins for the cost pass (operands hoisted into VGPRs, 2 waves/SIMD),
     // the LDS-operand kernel for the full pass (the 91 accumulators own the register file)
-    if (c->variant == 3 || (c->variant == 0 && !full)) done = dispatch_wide(s, a, grid, st);
+    if (c->variant == 4) done = dispatch_tile(s, a, grid, st);       // LDS-staged table (experimental)
+    if (!done && (c->variant == 3 || (c->variant == 0 && !full))) done = dispatch_wide(s, a, grid, st);
     if (!done && !dispatch_reg(s, a, grid, st)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
     if (s.d > 32) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel supports d <= 32");
@@ -1497,7 +1511,7 @@ gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nch
 }
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 3) return GVI_ERR_ARG;
+  if (!ctx || variant < 0 || variant > 4) return GVI_ERR_ARG;
   ctx->variant = variant;
   return GVI_OK;
 }

@@ -45,7 +45,7 @@ def quad_params(rng, K, n):
 # ------------------------------------------------------------------------------------------
 # a4-a9: moments / costs, every psi kind, both kernel variants
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("n,p,K", [(1, 3, 5), (2, 3, 7), (3, 4, 4), (4, 3, 3), (6, 5, 6)])
 def test_moments_quad_prior_vs_oracle(n, p, K, variant):
     rng = np.random.default_rng(100 + n)
@@ -71,7 +71,7 @@ def test_moments_quad_prior_vs_oracle(n, p, K, variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("d,p", [(1, 5), (2, 3), (3, 3), (6, 5)])
 def test_moments_fixed_prior_vs_oracle(d, p, variant):
     rng = np.random.default_rng(200 + d)
@@ -419,8 +419,14 @@ def test_c3_full_size_closed_form_and_variants(c3):
     K, d, n = len(spec["start"]), spec["d"], ch["n"]
     SD, SU = o.inverse_gbp(ch["D0"], ch["U0"])
     mk, Sk = o.gather_marginals(ch["mu0"], SD, SU, spec["start"], d)
-    ctx.set_variant(3)
-    Ephi3, Vdmu3, Vddmu3 = ctx.moments(ids[0], mk, Sk)
+    for v in (3, 4):
+        ctx.set_variant(v)
+        Ephi3, Vdmu3, Vddmu3 = ctx.moments(ids[0], mk, Sk)
+        ctx.set_variant(2)
+        Ephi, Vdmu, Vddmu = ctx.moments(ids[0], mk, Sk)
+        assert rel(Ephi3, Ephi) < 1e-12 and rel(Vdmu3, Vdmu) < 1e-11 and rel(Vddmu3, Vddmu) < 1e-10
+        c3 = ctx.costs(ids[0], mk, Sk)
+        assert rel(c3, Ephi) < 1e-12
     ctx.set_variant(2)
     Ephi, Vdmu, Vddmu = ctx.moments(ids[0], mk, Sk)
     assert rel(Ephi3, Ephi) < 1e-12 and rel(Vdmu3, Vdmu) < 1e-11 and rel(Vddmu3, Vddmu) < 1e-10

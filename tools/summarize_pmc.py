@@ -10,7 +10,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         for row in csv.DictReader(fh):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in acc.items():
-        if "moments_reg_kernel<12" not in k and "prep_kernel<4>" not in k:
+        if "kernel<12" not in k:
             continue
         d = out.setdefault(k, {})
         for c, v in cs.items():
