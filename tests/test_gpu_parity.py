@@ -211,7 +211,8 @@ def _spd_chain(T, n, rng):
     return D, U
 
 
-@pytest.mark.parametrize("T,n", [(1, 1), (1, 4), (2, 2), (9, 3), (33, 6), (65, 2), (17, 12), (5, 16)])
+@pytest.mark.parametrize("T,n", [(1, 1), (1, 4), (2, 2), (3, 1), (9, 3), (33, 6), (65, 2), (17, 12), (5, 16),
+                                 (31, 4), (32, 6), (34, 8), (100, 2), (257, 3), (1000, 1), (129, 12), (70, 5), (40, 7)])
 def test_bt_ops_vs_oracle(T, n):
     rng = np.random.default_rng(T * 31 + n)
     D, U = _spd_chain(T, n, rng)
@@ -228,6 +229,42 @@ def test_bt_ops_vs_oracle(T, n):
         assert rel(ctx.bt_solve(D, U, rhs).reshape(-1), o.cg_eigen(A, rhs.reshape(-1))) < 1e-7
         tD, tU = o.dense_to_bt(o.inv_sparse_takahashi(A, n), n)
         assert rel(SD, tD) < TIGHT
+    ctx.close()
+
+
+def test_mixed_factor_sets_general_chain():
+    """Three sets on one chain (binary priors with two different GH degrees covering disjoint ranges + unary
+    factors), T not of the form 2^k + 1, n = 3: several NGD iterations against the oracle."""
+    rng = np.random.default_rng(77)
+    T, n = 21, 3
+    d = 2 * n
+    def pri(K):
+        Phi = np.stack([np.eye(n) + 0.05 * rng.normal(size=(n, n)) for _ in range(K)])
+        Qh = rng.normal(size=(K, n, n))
+        return Phi, Qh @ np.transpose(Qh, (0, 2, 1)) + 2.0 * np.eye(n)
+    PhiA, QA = pri(12)
+    PhiB, QB = pri(8)
+    startA, startB = np.arange(12, dtype=np.int32), np.arange(12, 20, dtype=np.int32)
+    mu_u = rng.normal(size=(T, n)); Kinv = np.stack([np.eye(n) * 1.5] * T)
+    ctx = api.Context(0)
+    ctx.chain_set(T, n)
+    ids = [ctx.factors_add(d, 3, startA, api.PSI_QUAD_PRIOR, np.concatenate([PhiA.reshape(12, -1), QA.reshape(12, -1)], 1), np.full(12, 2.0)),
+           ctx.factors_add(d, 4, startB, api.PSI_QUAD_PRIOR, np.concatenate([PhiB.reshape(8, -1), QB.reshape(8, -1)], 1)),
+           ctx.factors_add(n, 3, np.arange(T, dtype=np.int32), api.PSI_FIXED_PRIOR, np.concatenate([mu_u, Kinv.reshape(T, -1)], 1))]
+    sets = []
+    for start, dd, p, pb, temp in [(startA, d, 3, o.psi_batch_quad_prior(PhiA, QA), 2.0), (startB, d, 4, o.psi_batch_quad_prior(PhiB, QB), 1.0),
+                                   (np.arange(T), n, 3, o.psi_batch_fixed_prior(mu_u, Kinv), 1.0)]:
+        sets.append(o.FactorSet(start, dd, p, pb, temp))
+    D0 = np.stack([np.eye(n) * 4.0] * T); U0 = np.stack([np.eye(n) * -0.5] * (T - 1))
+    mu0 = rng.normal(size=(T, n))
+    chain = o.ChainNGD(T, n, sets, mu0, D0, U0)
+    ctx.ngd_init(mu0, D0, U0)
+    for it in range(3):
+        r = ctx.ngd_step(0.55, 10)
+        ok, cost, ntr = chain.step()
+        assert r["accepted"] == ok and r["ntrials"] == ntr and np.isclose(r["new_cost"], cost, rtol=1e-9)
+    st = ctx.ngd_get_state()
+    assert rel(st["mu"], chain.mu) < RTOL / 10 and rel(st["D"], chain.D) < RTOL / 10 and rel(st["SigU"], chain.SigU) < RTOL / 10
     ctx.close()
 
 
