@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib
 
-PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK = 0, 1, 2, 3
+PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK, PSI_HINGE_SDF_2D = 0, 1, 2, 3, 4
 GVI_F64, GVI_F32 = 0, 1
 
 
@@ -102,6 +102,12 @@ class Context:
         self._ck(self.lib.gvi_factors_set_table(self.h, sid, len(w), _p(Z), _p(w)))
         K, d, p, _ = self.sets[sid]
         self.sets[sid] = (K, d, p, len(w))
+
+    def factors_set_sdf2d(self, sid, origin, cell_size, field):
+        """field[r, c]: signed distance at (x = origin[0] + c cell, y = origin[1] + r cell)."""
+        f = np.asfortranarray(field, dtype=np.float64)                 # column-major like Eigen's MatrixXd
+        self._ck(self.lib.gvi_factors_set_sdf2d(self.h, sid, float(origin[0]), float(origin[1]), float(cell_size),
+                                                f.shape[0], f.shape[1], f.ctypes.data_as(C.c_void_p)))
 
     def factors_set_temperature(self, sid, temperature):
         self._ck(self.lib.gvi_factors_set_temperature(self.h, sid, _p(_f64(temperature))))
@@ -284,4 +290,6 @@ def context_for_chain(chain, device=0, specs=None):
     for spec in (chain["specs"] if specs is None else specs):
         ids.append(ctx.factors_add(spec["d"], spec["p"], spec["start"], spec["kind"], spec["params"],
                                    spec["temperature"]))
+        if spec["kind"] == PSI_HINGE_SDF_2D:
+            ctx.factors_set_sdf2d(ids[-1], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
     return ctx, ids

@@ -53,6 +53,9 @@ struct FactorSet {
   std::shared_ptr<Table> table;
   DevMem dstart, dptr, didx, A, b, sgn, raw, temperature;
   DevMem S, Sinv, Lam, H, u0;         // per-pass products
+  DevMem sdf;                         // HINGE_SDF_2D grid
+  int sdf_rows = 0, sdf_cols = 0;
+  double sdf_ox = 0, sdf_oy = 0, sdf_cell = 1;
   DevMem Vws;                         // eigenvectors of the last resident-NGD prep (Jacobi warm start)
   int warm_count = 0;                 // preps since the last cold start
   DevMem partial;
@@ -81,6 +84,7 @@ struct FactorSet {
     f.temperature = temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.u0 = u0.d();
     f.Vws = nullptr; f.warm = 0;
+    f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell;
     return f;
   }
 };
@@ -185,6 +189,7 @@ FactorSet* get_set(gvi_ctx* c, int id) {
 // which (d, m) pairs have a register-kernel instantiation
 bool reg_supported(int kind, int d, int m) {
   if (kind == KIND_RANGE_1D) return d == 1;
+  if (kind == KIND_HINGE_SDF_2D) return d == 2 || d == 4 || d == 6;
   if (kind == KIND_QUAD_PRIOR) return (d == 2 && m == 1) || (d == 4 && m == 2) || (d == 6 && m == 3) ||
                                       (d == 8 && m == 4) || (d == 12 && m == 6);
   if (kind == KIND_FIXED_PRIOR) return d == m && (d == 1 || d == 2 || d == 3 || d == 4 || d == 6 || d == 8);
@@ -255,6 +260,13 @@ bool dispatch_wide(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t 
 bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
   const int d = s.d;
   if (s.kind == KIND_RANGE_1D && d == 1) { launch_reg<1, PsiRange1D>(a, grid, st); return true; }
+  if (s.kind == KIND_HINGE_SDF_2D) {
+    switch (d) {
+      case 2: launch_reg<2, PsiHingeSdf2D<2>>(a, grid, st); return true;
+      case 4: launch_reg<4, PsiHingeSdf2D<4>>(a, grid, st); return true;
+      case 6: launch_reg<6, PsiHingeSdf2D<6>>(a, grid, st); return true;
+    }
+  }
   if (s.kind == KIND_QUAD_PRIOR) {
     switch (d) {
       case 2: launch_reg<2, PsiQuad<2, 1>>(a, grid, st); return true;
@@ -297,6 +309,8 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
 gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full,
                        hipStream_t st = nullptr) {
   if (!st) st = c->stream;
+  if (s.kind == KIND_HINGE_SDF_2D && !psi_ext && s.sdf_rows == 0)
+    return fail(c, GVI_ERR_STATE, "HINGE_SDF_2D set without a grid: call gvi_factors_set_sdf2d");
   bool reg = reg_supported(s.kind, s.d, s.m) && !psi_ext && c->variant != 1;
   if (c->variant == 2 && !reg && !psi_ext)
     return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
@@ -720,6 +734,7 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
     case GVI_PSI_QUAD_PRIOR: if (d % 2) return fail(ctx, GVI_ERR_ARG, "QUAD_PRIOR needs even d"); m = d / 2; need = 2 * (int64_t)m * m; break;
     case GVI_PSI_FIXED_PRIOR: m = d; need = d + (int64_t)d * d; break;
     case GVI_PSI_HOST_CALLBACK: need = 0; break;
+    case GVI_PSI_HINGE_SDF_2D: if (d < 2) return fail(ctx, GVI_ERR_ARG, "HINGE_SDF_2D needs d >= 2"); need = 3; break;
     default: return fail(ctx, GVI_ERR_ARG, "unknown psi kind");
   }
   if (need > 0 && (!psi_params || params_per_factor < need))
@@ -779,10 +794,11 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   GVICK(up(s->A, A.data(), A.size() * 8));
   GVICK(up(s->b, b.data(), b.size() * 8));
   GVICK(up(s->sgn, sg.data(), sg.size() * 8));
-  if (psi_kind == GVI_PSI_RANGE_1D) {
-    std::vector<double> raw((size_t)K * 5);
-    for (int k = 0; k < K; ++k) memcpy(&raw[(size_t)k * 5], psi_params + (size_t)k * params_per_factor, 40);
-    s->raw_stride = 5;
+  if (psi_kind == GVI_PSI_RANGE_1D || psi_kind == GVI_PSI_HINGE_SDF_2D) {
+    const int np = psi_kind == GVI_PSI_RANGE_1D ? 5 : 3;
+    std::vector<double> raw((size_t)K * np);
+    for (int k = 0; k < K; ++k) memcpy(&raw[(size_t)k * np], psi_params + (size_t)k * params_per_factor, (size_t)np * 8);
+    s->raw_stride = np;
     GVICK(up(s->raw, raw.data(), raw.size() * 8));
   } else {
     GVICK(up(s->raw, nullptr, 0));
@@ -824,6 +840,22 @@ gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const doub
   auto t = std::make_shared<Table>();
   GVICK(upload_table(ctx, *t, s->d, -1, N, Z, w));
   s->table = t;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_set_sdf2d(gvi_ctx* ctx, int set_id, double origin_x, double origin_y, double cell_size, int rows,
+                                 int cols, const double* data) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
+  if (s->kind != KIND_HINGE_SDF_2D) return fail(ctx, GVI_ERR_ARG, "set is not GVI_PSI_HINGE_SDF_2D");
+  if (rows < 2 || cols < 2 || !(cell_size > 0) || !data) return fail(ctx, GVI_ERR_ARG, "bad grid");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  HIPCK(ctx, s->sdf.ensure((size_t)rows * cols * 8));
+  HIPCK(ctx, hipMemcpy(s->sdf.p, data, (size_t)rows * cols * 8, hipMemcpyHostToDevice));
+  s->sdf_rows = rows; s->sdf_cols = cols; s->sdf_ox = origin_x; s->sdf_oy = origin_y; s->sdf_cell = cell_size;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
   return GVI_OK;
 }
 

@@ -26,7 +26,7 @@
 
 namespace gvi {
 
-enum { KIND_RANGE_1D = 0, KIND_QUAD_PRIOR = 1, KIND_FIXED_PRIOR = 2, KIND_HOST_CALLBACK = 3 };
+enum { KIND_RANGE_1D = 0, KIND_QUAD_PRIOR = 1, KIND_FIXED_PRIOR = 2, KIND_HOST_CALLBACK = 3, KIND_HINGE_SDF_2D = 4 };
 
 __host__ __device__ inline int npairs(int d) { return (d + 1) * (d + 2) / 2; }
 
@@ -52,6 +52,9 @@ struct FactorDev {
   double* Lam;              // [K][d][d]
   double* H;                // [K][d][m]  H = A S, stored column by column
   double* u0;               // [K][m]
+  const double* sdf;        // HINGE_SDF_2D: column-major rows x cols signed-distance grid
+  int sdf_rows, sdf_cols;
+  double sdf_ox, sdf_oy, sdf_cell;
   double* Vws;              // [K][d][d] eigenvectors of the previous prep (warm start) or null
   int warm;                 // 1: start the Jacobi sweeps from Vws (resident NGD iteration only)
 };
@@ -290,6 +293,25 @@ __device__ inline double psi_range_1d(const double* p, double x) {
   return e * e / p[4] / 2 + r * r / p[3] / 2;
 }
 
+// planar point-robot obstacle cost (helpers/CudaOperation.h:491-523): sigma * hinge(eps + r - sdf(x, y))^2,
+// sdf = PlanarSDF bilinear interpolation with the query clamped to the grid (:61-103).  p = [sigma, eps, r].
+__device__ inline double psi_hinge_sdf2d(const FactorDev& f, const double* p, double px, double py) {
+  const double xmax = f.sdf_ox + (f.sdf_cols - 1.0) * f.sdf_cell, ymax = f.sdf_oy + (f.sdf_rows - 1.0) * f.sdf_cell;
+  const double xin = px < f.sdf_ox ? f.sdf_ox : (px > xmax ? xmax : px);
+  const double yin = py < f.sdf_oy ? f.sdf_oy : (py > ymax ? ymax : py);
+  const double col = (xin - f.sdf_ox) / f.sdf_cell, row = (yin - f.sdf_oy) / f.sdf_cell;
+  const double lr = floor(row), lc = floor(col), hr = lr + 1.0, hc = lc + 1.0;
+  const int lri = (int)lr, lci = (int)lc;
+  const int hri = lri + 1 < f.sdf_rows ? lri + 1 : f.sdf_rows - 1;    // weight is 0 there; keeps the read in bounds
+  const int hci = lci + 1 < f.sdf_cols ? lci + 1 : f.sdf_cols - 1;
+  const int R = f.sdf_rows;
+  const double sd = (hr - row) * (hc - col) * f.sdf[lri + lci * R] + (row - lr) * (hc - col) * f.sdf[hri + lci * R] +
+                    (hr - row) * (col - lc) * f.sdf[lri + hci * R] + (row - lr) * (col - lc) * f.sdf[hri + hci * R];
+  const double thr = p[1] + p[2];
+  const double err = sd > thr ? 0.0 : thr - sd;
+  return err * err * p[0];
+}
+
 // ---------------------------------------------------------------------------------------------
 // moments_generic_kernel: any d (<= 32), any psi kind.  Block = 256 threads handles one factor and a
 // range of points in sub-chunks of 256: stage 1 (thread = point) expands x = mu + S z, evaluates
@@ -368,6 +390,7 @@ __global__ __launch_bounds__(GEN_BS) void moments_generic_kernel(MomArgs a) {
       }
       if (a.psi_ext) psi = a.psi_ext[(size_t)k * f.N + i];
       else if (f.kind == KIND_RANGE_1D) psi = psi_range_1d(f.raw + (size_t)k * f.raw_stride, xr[0]);
+      else if (f.kind == KIND_HINGE_SDF_2D) psi = psi_hinge_sdf2d(f, f.raw + (size_t)k * f.raw_stride, xr[0], xr[1]);
       else {
         for (int r = 0; r < m; ++r) {
           double u = bsh[r];
@@ -429,7 +452,7 @@ struct PsiQuad {
       hs[M * D + M + lane] = a.f.sgn[(size_t)k * M + lane];
     }
   }
-  __device__ static double eval(const double (&z)[D], const double* hs) {
+  __device__ static double eval(const double (&z)[D], const double* hs, const MomArgs&) {
     double u[M];                      // M independent FMA chains (column-outer order)
 #pragma unroll
     for (int r = 0; r < M; ++r) u[r] = hs[M * D + r];
@@ -452,8 +475,26 @@ struct PsiRange1D {
     if (lane == 0) { hs[0] = a.mu[k]; hs[1] = a.f.S[k]; }
     if (lane < 5) hs[2 + lane] = a.f.raw[(size_t)k * a.f.raw_stride + lane];
   }
-  __device__ static double eval(const double (&z)[1], const double* hs) {
+  __device__ static double eval(const double (&z)[1], const double* hs, const MomArgs&) {
     return psi_range_1d(hs + 2, fma(hs[1], z[0], hs[0]));
+  }
+};
+
+// nonlinear obstacle cost: pose = (mu + S z)[0:2] (two rows of S in LDS), SDF lookups straight from L2
+template <int D>
+struct PsiHingeSdf2D {
+  static constexpr int LDS = 2 * D + 2 + 3;
+  static constexpr bool GUARD = false;
+  __device__ static void load(const MomArgs& a, int k, double* hs, int lane) {
+    if (lane < 2 * D) hs[lane] = a.f.S[(size_t)k * D * D + lane];          // rows 0 and 1 of S
+    if (lane < 2) hs[2 * D + lane] = a.mu[(size_t)k * D + lane];
+    if (lane < 3) hs[2 * D + 2 + lane] = a.f.raw[(size_t)k * a.f.raw_stride + lane];
+  }
+  __device__ static double eval(const double (&z)[D], const double* hs, const MomArgs& a) {
+    double px = hs[2 * D], py = hs[2 * D + 1];
+#pragma unroll
+    for (int c = 0; c < D; ++c) { px = fma(hs[c], z[c], px); py = fma(hs[D + c], z[c], py); }
+    return psi_hinge_sdf2d(a.f, hs + 2 * D + 2, px, py);
   }
 };
 
@@ -482,7 +523,7 @@ __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
 #pragma unroll
       for (int c = 0; c < D; ++c) z[c] = Zt[(size_t)c * Np + i];
       // padded tail (i >= N) carries w = 0, z = 0; the select keeps a non-finite psi(mu) out
-      const double cw = i < a.f.N ? w[i] * Psi::eval(z, hs[wave]) : 0.0;
+      const double cw = i < a.f.N ? w[i] * Psi::eval(z, hs[wave], a) : 0.0;
       acc[0] += cw;
       if (FULL) {
         int q = 1 + D;
@@ -565,7 +606,7 @@ __global__ __launch_bounds__(256, FULL ? 1 : 2) void moments_wide_kernel(MomArgs
       for (int c = 0; c < D; ++c) zn[c] = *(const double*)(Zb + c * rowb + (size_t)nxt * 8u);
       wn = *(const double*)(wb + (size_t)nxt * 8u);
     }
-    const double psi = Psi::eval(z, hs[wave]);
+    const double psi = Psi::eval(z, hs[wave], a);
     // GUARD kinds may be non-finite at the padded z = 0 (x = mu): keep 0 * inf out of the sums
     const double cw = Psi::GUARD ? (idx < nvalid ? wi * psi : 0.0) : wi * psi;
     acc[0] += cw;
@@ -667,7 +708,7 @@ __global__ __launch_bounds__(256, 2) void moments_tile_kernel(MomArgs a) {
       const double wi = zt[D * TP + it * 64 + lane];
       int woff = wave * Psi::LDS;                          // FULL: keep the psi operands in LDS (see moments_reg_kernel)
       if (FULL) asm volatile("" : "+s"(woff));
-      const double psi = Psi::eval(z, &hs[0][0] + woff);
+      const double psi = Psi::eval(z, &hs[0][0] + woff, a);
       const unsigned idx = (unsigned)(i0 + (int64_t)t * TP + it * 64 + lane);
       const double cw = Psi::GUARD ? (idx < nvalid ? wi * psi : 0.0) : wi * psi;
       acc[0] += cw;

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK = 0, 1, 2, 3
+PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK, PSI_HINGE_SDF_2D = 0, 1, 2, 3, 4
 
 CONFIGS = {
     # name: (cfg#, T, n, p, prior kind)
@@ -109,6 +109,55 @@ def make_chain(name: str):
              temperature=np.ones(T), mu0=meas, Kinv=Kinv),
     ]
     return dict(name=name, T=T, n=n, specs=specs, mu0=mu0, D0=D0, U0=U0)
+
+
+def circle_sdf(origin, cell, rows, cols, centers, radii):
+    """Signed distance to a union of discs on a grid: field[r, c] at (origin + (c, r) * cell)."""
+    xs = origin[0] + np.arange(cols) * cell
+    ys = origin[1] + np.arange(rows) * cell
+    X, Y = np.meshgrid(xs, ys)
+    f = np.full((rows, cols), np.inf)
+    for (cx, cy), r in zip(centers, radii):
+        f = np.minimum(f, np.hypot(X - cx, Y - cy) - r)
+    return f
+
+
+def make_planar_chain(T=17, p=3, seed=0x5EED + 40):
+    """Planar point-robot planning graph of the reference's own GPU workload: states
+    [x, y, vx, vy] (n = 4), T-1 minimum-acceleration priors (d = 8), T hinge-on-SDF obstacle factors on
+    every state (d = 4, helpers/CudaOperation.h:491-523) and two fixed-prior end anchors."""
+    rng = np.random.default_rng(seed)
+    n, nd, K = 4, 2, T - 1
+    dt = 0.25
+    Phi1, Qinv1 = _minacc(nd, QC, dt)
+    Phi, Qinv = np.stack([Phi1] * K), np.stack([Qinv1] * K)
+    start_xy, goal_xy = np.array([-3.0, -0.4]), np.array([3.0, 0.4])
+    horizon = (T - 1) * dt
+    vel = (goal_xy - start_xy) / horizon
+    t = np.arange(T)[:, None] * dt
+    nominal = np.hstack([start_xy[None] + vel[None] * t, np.tile(vel, (T, 1))])
+    mu0 = nominal + 0.02 * rng.normal(size=nominal.shape)
+    origin, cell, rows, cols = (-5.0, -4.0), 0.1, 81, 101
+    field = circle_sdf(origin, cell, rows, cols, [(0.0, 1.6), (-1.0, -2.2)], [1.2, 0.9])
+    anchors = np.stack([nominal[0], nominal[-1]])
+    Kinv = np.stack([np.eye(n) / 1e-2] * 2)
+    D0 = np.zeros((T, n, n)); U0 = np.zeros((T - 1, n, n))
+    for k in range(K):
+        Lam = np.hstack([-Phi[k], np.eye(n)])
+        M = Lam.T @ Qinv[k] @ Lam
+        D0[k] += M[:n, :n]; D0[k + 1] += M[n:, n:]; U0[k] += M[:n, n:]
+    D0[0] += 2 * Kinv[0]; D0[-1] += 2 * Kinv[1]
+    D0 += 0.5 * np.eye(n)
+    specs = [
+        dict(kind=PSI_QUAD_PRIOR, d=2 * n, p=p, start=np.arange(K, dtype=np.int32),
+             params=np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1), temperature=np.ones(K), Phi=Phi, Qinv=Qinv),
+        dict(kind=PSI_HINGE_SDF_2D, d=n, p=p + 1, start=np.arange(T, dtype=np.int32),
+             params=np.tile(np.array([[15.5, 0.5, 0.3]]), (T, 1)), temperature=np.ones(T),
+             sdf_origin=origin, sdf_cell=cell, sdf_field=field),
+        dict(kind=PSI_FIXED_PRIOR, d=n, p=p, start=np.array([0, T - 1], dtype=np.int32),
+             params=np.concatenate([anchors, Kinv.reshape(2, -1)], axis=1), temperature=np.ones(2), mu0=anchors, Kinv=Kinv),
+    ]
+    return dict(name="planar", T=T, n=n, specs=specs, mu0=mu0, D0=D0, U0=U0)
 
 
 def random_marginals(rng, K, d, scale=1.0):

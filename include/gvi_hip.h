@@ -48,9 +48,14 @@ enum { GVI_F64 = 0, GVI_F32 = 1 };
  *       psi(x) = 1/2 (Phi x1 - x2)^T Qinv (Phi x1 - x2)   gp/minimum_acc_prior.h:103-106, gp/LTV_prior.h:223-226
  *   GVI_PSI_FIXED_PRIOR   [mu0 (d) | Kinv (d x d)]                          d = n
  *       psi(x) = (x-mu0)^T Kinv (x-mu0)                                     gp/fixed_prior.h:28-30
+ *   GVI_PSI_HINGE_SDF_2D  [sigma, epsilon, radius]                          d >= 2 (pose = x[0:2])
+ *       psi(x) = sigma * max(0, epsilon + radius - sdf(x0, x1))^2, sdf = bilinear interpolation of a 2-D
+ *       signed-distance grid shared by the set (gvi_factors_set_sdf2d): the reference's planar point-robot
+ *       obstacle cost (helpers/CudaOperation.h:491-523 with PlanarSDF :21-131) -- SURVEY 8(f)1
  *   GVI_PSI_HOST_CALLBACK no parameters: psi is an opaque host function (the reference's
  *       std::function, ngd/NGDFactorizedBaseGH.h:30,46-48); use gvi_expand + gvi_moments_from_psi. */
-enum { GVI_PSI_RANGE_1D = 0, GVI_PSI_QUAD_PRIOR = 1, GVI_PSI_FIXED_PRIOR = 2, GVI_PSI_HOST_CALLBACK = 3 };
+enum { GVI_PSI_RANGE_1D = 0, GVI_PSI_QUAD_PRIOR = 1, GVI_PSI_FIXED_PRIOR = 2, GVI_PSI_HOST_CALLBACK = 3,
+       GVI_PSI_HINGE_SDF_2D = 4 };
 
 const char* gvi_version(void);
 /* Message of the last failing call on this context (never NULL). */
@@ -85,6 +90,11 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
 /* Replace the set's quadrature table by a caller-supplied one (e.g. read from the reference's
  * cereal file quadrature/SparseGHQuadratureWeights_cereal.bin): Z [N][d], w [N], host. */
 gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const double* Z, const double* w);
+/* Signed-distance grid of a GVI_PSI_HINGE_SDF_2D set: PlanarSDF(origin, cell_size, data)
+ * (helpers/CudaOperation.h:39-43); data is COLUMN-major rows x cols like Eigen's MatrixXd
+ * (data[r + c * rows], :130), row = y cell, col = x cell; queries are clamped to the grid (:61-80). */
+gvi_status gvi_factors_set_sdf2d(gvi_ctx* ctx, int set_id, double origin_x, double origin_y, double cell_size,
+                                 int rows, int cols, const double* data);
 /* factor_switch_to_high_temperature (gvibase/GVIFactorizedBase.h:212-214), batched. */
 gvi_status gvi_factors_set_temperature(gvi_ctx* ctx, int set_id, const double* temperature);
 gvi_status gvi_factors_info(const gvi_ctx* ctx, int set_id, int* K, int* d, int* p, int64_t* N);

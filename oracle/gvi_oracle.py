@@ -236,6 +236,35 @@ def psi_fixed_prior(x, mu0, Kinv):
     return float(e @ Kinv @ e)
 
 
+def planar_sdf_lookup(px, py, origin, cell, field):
+    """PlanarSDF::convertPoint2toCell + signed_distance (helpers/CudaOperation.h:61-103): clamp the query
+    to the grid, bilinear interpolation; field[r, c] (Eigen column-major data_array_[r + c rows], :130).
+    The reference reads one row/column past the edge with weight 0 there; the index is clamped instead."""
+    rows, cols = field.shape
+    xin = np.clip(px, origin[0], origin[0] + (cols - 1.0) * cell)
+    yin = np.clip(py, origin[1], origin[1] + (rows - 1.0) * cell)
+    col, row = (xin - origin[0]) / cell, (yin - origin[1]) / cell
+    lr, lc = np.floor(row), np.floor(col)
+    hr, hc = lr + 1.0, lc + 1.0
+    lri = np.nan_to_num(lr, nan=0.0).astype(int)                      # NaN queries (rejected trials) stay NaN via the weights
+    lci = np.nan_to_num(lc, nan=0.0).astype(int)
+    hri, hci = np.minimum(lri + 1, rows - 1), np.minimum(lci + 1, cols - 1)
+    return ((hr - row) * (hc - col) * field[lri, lci] + (row - lr) * (hc - col) * field[hri, lci] +
+            (hr - row) * (col - lc) * field[lri, hci] + (row - lr) * (col - lc) * field[hri, hci])
+
+
+def psi_batch_hinge_sdf2d(params, origin, cell, field):
+    """cost_obstacle_planar of the planar point robot (helpers/CudaOperation.h:491-508, one ball, slope 1):
+    sigma * max(0, eps + r - sdf(x0, x1))^2; params [K,3] = (sigma, eps, r)."""
+    def f(X, sel=slice(None)):
+        P = params[sel]
+        sd = planar_sdf_lookup(X[:, :, 0], X[:, :, 1], origin, cell, field)
+        thr = (P[:, 1] + P[:, 2])[:, None]
+        err = np.where(sd > thr, 0.0, thr - sd)
+        return err * err * P[:, 0][:, None]
+    return f
+
+
 def ltv_phi_q(A_list, B_list, delta_t: float):
     """(Phi, Q) of LTV_GP (gp/LTV_prior.h:123-197): Phi' = A(t) Phi, Q' = A Q + Q A^T + B B^T over
     [0, dt] with A, B piece-wise constant on 4 sub-intervals.  The reference integrates with GSL

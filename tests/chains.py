@@ -10,6 +10,8 @@ def oracle_psi_batch(spec):
         return o.psi_batch_quad_prior(spec["Phi"], spec["Qinv"])
     if spec["kind"] == syn.PSI_FIXED_PRIOR:
         return o.psi_batch_fixed_prior(spec["mu0"], spec["Kinv"])
+    if spec["kind"] == syn.PSI_HINGE_SDF_2D:
+        return o.psi_batch_hinge_sdf2d(spec["params"], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
     if spec["kind"] == syn.PSI_RANGE_1D:
         y, mu_p, fb, srs, sps = spec["params"][0]
         return o.psi_batch_range_1d(y, mu_p, fb, srs, sps)
@@ -27,10 +29,11 @@ def oracle_psi_point(spec):
 
 
 def make_chain(name):
-    ch = syn.make_chain(name)
+    ch = syn.make_planar_chain() if name == "planar" else syn.make_chain(name)
     for spec in ch["specs"]:
         spec["psi_batch"] = oracle_psi_batch(spec)
-        spec["psi_point"] = oracle_psi_point(spec)
+        if spec["kind"] != syn.PSI_HINGE_SDF_2D:
+            spec["psi_point"] = oracle_psi_point(spec)
 
     def oracle_sets():
         out = []

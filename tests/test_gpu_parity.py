@@ -122,6 +122,53 @@ def test_moments_range_1d_nonlinear(variant):
     ctx.close()
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("d,p", [(2, 4), (4, 4), (6, 3), (8, 3)])
+def test_moments_hinge_sdf2d_vs_oracle(d, p, variant):
+    """Hinge-on-signed-distance psi of the planar point robot (helpers/CudaOperation.h:61-103,491-508):
+    means inside, on the rim of and far from the obstacles, one of them outside the grid (clamped)."""
+    rng = np.random.default_rng(300 + d)
+    origin, cell = (-5.0, -4.0), 0.1
+    field = syn.circle_sdf(origin, cell, 81, 101, [(0.0, 1.6), (-1.0, -2.2)], [1.2, 0.9])
+    K = 6
+    params = np.column_stack([rng.uniform(5, 20, K), rng.uniform(0.2, 0.8, K), rng.uniform(0.1, 0.5, K)])
+    ctx, sid = single_set_ctx(api.PSI_HINGE_SDF_2D, d, d, p, K, params)
+    with pytest.raises(RuntimeError):
+        ctx.moments(sid, np.zeros((K, d)), np.stack([np.eye(d)] * K))        # no grid yet
+    ctx.factors_set_sdf2d(sid, origin, cell, field)
+    ctx.set_variant(variant if d <= 6 else 0)              # d = 8 has no register instantiation: generic kernel
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.2)
+    mu[:, :2] = [(0.0, 1.5), (0.1, 0.2), (-1.0, -1.2), (3.0, 3.0), (6.5, 0.0), (-0.3, 2.9)]
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == (variant if d <= 6 else 1)
+    Z, w = o.nwspgr(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_hinge_sdf2d(params, origin, cell, field), np.ones(K))
+    assert np.abs(r["E_phi"]).max() > 0.05              # Smolyak weights are signed: no positivity on a kinked psi
+    assert rel(Ephi, r["E_phi"]) < TIGHT and rel(Vdmu, r["Vdmu"]) < TIGHT and rel(Vddmu, r["Vddmu"]) < TIGHT * 10
+    assert rel(ctx.costs(sid, mu, Sigma), r["cost"]) < TIGHT
+    ctx.close()
+
+
+def test_planar_obstacle_chain_vs_oracle():
+    """The reference's own GPU workload shape: planar point robot, minimum-acceleration
+    priors + hinge-SDF obstacle factors + end anchors; NGD iterations against the CPU oracle."""
+    ch = make_chain("planar")
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    chain = o.ChainNGD(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"])
+    for it in range(5):
+        r = ctx.ngd_step(0.55, 10)
+        ok, cost, ntr = chain.step()
+        assert r["accepted"] == ok and r["ntrials"] == ntr
+        assert np.isclose(r["new_cost"], cost, rtol=1e-9)
+        st = ctx.ngd_get_state()
+        assert rel(st["mu"], chain.mu) < RTOL / 10
+        assert rel(st["D"], chain.D) < RTOL / 10 and rel(st["SigD"], chain.SigD) < RTOL / 10
+    fc = ctx.ngd_factor_costs(ids[1])
+    assert fc.max() > 0                                   # the obstacle factors are active on this path
+    ctx.close()
+
+
 def test_k9_golden_fixture(golden_dir):
     """Committed K9 vectors: device GH moments == oracle GH == closed form (ngd/NGDFactorizedLinear.h:93-129)."""
     g = np.load(os.path.join(golden_dir, "k9_moments.npz"))
