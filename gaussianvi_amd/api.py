@@ -109,6 +109,9 @@ class Context:
         self._ck(self.lib.gvi_factors_set_sdf2d(self.h, sid, float(origin[0]), float(origin[1]), float(cell_size),
                                                 f.shape[0], f.shape[1], f.ctypes.data_as(C.c_void_p)))
 
+    def factors_set_closed_form(self, sid, on=True):
+        self._ck(self.lib.gvi_factors_set_closed_form(self.h, sid, int(on)))
+
     def factors_set_temperature(self, sid, temperature):
         self._ck(self.lib.gvi_factors_set_temperature(self.h, sid, _p(_f64(temperature))))
 

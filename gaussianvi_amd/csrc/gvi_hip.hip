@@ -62,6 +62,7 @@ struct FactorSet {
   int nchunk = 1;
   int64_t chunk = 0;
   bool use_reg = false;
+  bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
   hipEvent_t done = nullptr;
@@ -314,7 +315,9 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   bool reg = reg_supported(s.kind, s.d, s.m) && !psi_ext && c->variant != 1;
   if (c->variant == 2 && !reg && !psi_ext)
     return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
-  plan_chunks(c, s, reg);
+  const bool closed = s.closed_form && !psi_ext;
+  if (closed) { reg = false; s.chunk = s.table->Np; s.nchunk = 1; }
+  else plan_chunks(c, s, reg);
   s.use_reg = reg;
   const size_t need = (size_t)s.K * s.nchunk * npairs(s.d) * 8;
   HIPCK(c, s.partial.ensure(need));
@@ -328,7 +331,9 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
       if (!s.ev[which][e]) HIPCK(c, hipEventCreate(&s.ev[which][e]));
     HIPCK(c, hipEventRecord(s.ev[which][0], st));
   }
-  if (reg) {
+  if (closed) {
+    hipLaunchKernelGGL(moments_closed_kernel, dim3(s.K), dim3(64), 0, st, a);
+  } else if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
     // auto: the operand-resident kernel wins for the cost pass (operands hoisted into VGPRs, 2 waves/SIMD),
@@ -854,6 +859,18 @@ gvi_status gvi_factors_set_sdf2d(gvi_ctx* ctx, int set_id, double origin_x, doub
   HIPCK(ctx, s->sdf.ensure((size_t)rows * cols * 8));
   HIPCK(ctx, hipMemcpy(s->sdf.p, data, (size_t)rows * cols * 8, hipMemcpyHostToDevice));
   s->sdf_rows = rows; s->sdf_cols = cols; s->sdf_ox = origin_x; s->sdf_oy = origin_y; s->sdf_cell = cell_size;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_set_closed_form(gvi_ctx* ctx, int set_id, int on) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
+  if (on && s->kind != KIND_QUAD_PRIOR && s->kind != KIND_FIXED_PRIOR)
+    return fail(ctx, GVI_ERR_ARG, "closed form exists for QUAD_PRIOR / FIXED_PRIOR sets only");
+  GVICK(sync(ctx));
+  s->closed_form = on != 0;
   ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
   ctx->ngd.grad_valid = false;
   return GVI_OK;
@@ -1536,7 +1553,7 @@ gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what, float* ms) {
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk) {
   FactorSet* s = get_set(ctx, set_id);
   if (!s) return GVI_ERR_ARG;
-  if (variant) *variant = s->use_reg ? 2 : 1;
+  if (variant) *variant = s->closed_form ? 0 : (s->use_reg ? 2 : 1);
   if (nchunk) *nchunk = s->nchunk;
   if (chunk) *chunk = s->chunk;
   return GVI_OK;

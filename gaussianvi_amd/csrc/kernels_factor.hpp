@@ -329,6 +329,46 @@ struct MomArgs {
   int full;                // 1: all moments, 0: m0 only (cost pass)
 };
 
+// ---------------------------------------------------------------------------------------------
+// moments_closed_kernel: quadrature-free moments of a sum-of-squares psi = sum_r s_r (u0 + H z)_r^2,
+// z ~ N(0, I)  [NGDFactorizedLinear::calculate_partial_V, ngd/NGDFactorizedLinear.h:93-129].  Isserlis in
+// the whitened space:  E[psi] = sum_r s_r (u0_r^2 + |h_r|^2),  E[z psi] = 2 sum_r s_r u0_r h_r,
+// E[z z^T psi] = E[psi] I + 2 sum_r s_r h_r h_r^T.  Writes the same packed layout as one chunk of the
+// sigma-point kernels, so the epilogue (back-transform, Lambda, temperature) is shared.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void moments_closed_kernel(MomArgs a) {
+  const FactorDev& f = a.f;
+  const int d = f.d, m = f.m, k = blockIdx.x;
+  const double* H = f.H + (size_t)k * d * m;      // [d][m]
+  const double* u0 = f.u0 + (size_t)k * m;
+  const double* sg = f.sgn + (size_t)k * m;
+  double m0 = 0.0;
+  for (int r = 0; r < m; ++r) {
+    double q = u0[r] * u0[r];
+    for (int c = 0; c < d; ++c) q = fma(H[c * m + r], H[c * m + r], q);
+    m0 = fma(sg[r], q, m0);
+  }
+  const int npo = a.full ? npairs(d) : 1;
+  double* out = a.partial + (size_t)k * a.nchunk * npo;
+  if (threadIdx.x == 0) out[0] = m0;
+  if (!a.full) return;
+  for (int j = 1 + threadIdx.x; j < npo; j += 64) {
+    double v = 0.0;
+    if (j <= d) {
+      const int c = j - 1;
+      for (int r = 0; r < m; ++r) v = fma(sg[r] * u0[r], H[c * m + r], v);
+      v *= 2.0;
+    } else {
+      int rem = j - 1 - d, row = 0;
+      while (rem >= d - row) { rem -= d - row; ++row; }
+      const int col = row + rem;
+      for (int r = 0; r < m; ++r) v = fma(sg[r] * H[row * m + r], H[col * m + r], v);
+      v = 2.0 * v + (row == col ? m0 : 0.0);
+    }
+    out[j] = v;
+  }
+}
+
 constexpr int GEN_BS = 256;
 constexpr int GEN_MAX_OUT = 3;   // outputs per thread: npairs(d) <= 768 -> d <= 37
 

@@ -95,6 +95,12 @@ gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const doub
  * (data[r + c * rows], :130), row = y cell, col = x cell; queries are clamped to the grid (:61-80). */
 gvi_status gvi_factors_set_sdf2d(gvi_ctx* ctx, int set_id, double origin_x, double origin_y, double cell_size,
                                  int rows, int cols, const double* data);
+/* Closed-form route for a QUAD_PRIOR / FIXED_PRIOR set: NGDFactorizedLinear::calculate_partial_V and
+ * fact_cost_value (ngd/NGDFactorizedLinear.h:93-129) instead of quadrature -- the factors the reference's
+ * classify_factors sends to its linear branch (gvibase/GVI-GH-Cuda-impl.h:31-38).  No sigma points are
+ * evaluated; the Gaussian 4th-moment contraction (its O(d^4) loop, :108-118) is done in the whitened
+ * space where it collapses to (u0^2 + |h|^2) I + 2 h h^T per residual row.  on = 0 returns to quadrature. */
+gvi_status gvi_factors_set_closed_form(gvi_ctx* ctx, int set_id, int on);
 /* factor_switch_to_high_temperature (gvibase/GVIFactorizedBase.h:212-214), batched. */
 gvi_status gvi_factors_set_temperature(gvi_ctx* ctx, int set_id, const double* temperature);
 gvi_status gvi_factors_info(const gvi_ctx* ctx, int set_id, int* K, int* d, int* p, int64_t* N);
@@ -193,7 +199,7 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
  *      ~10 us of queue gaps; on = 2: every moments / cost launch of every set. ---- */
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on);
 gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kernel, 1 cost kernel*/, float* ms);
-/* Launch geometry of the set's last moments/cost launch: variant (1 generic, 2 register), chunks. */
+/* Launch geometry of the set's last moments/cost launch: variant (0 closed form, 1 generic, 2 register), chunks. */
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk);
 /* Kernel variant override for A/B runs: 0 = auto, 1 = generic LDS kernel, 2 = register kernel. */
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);

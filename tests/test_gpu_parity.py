@@ -169,6 +169,64 @@ def test_planar_obstacle_chain_vs_oracle():
     ctx.close()
 
 
+@pytest.mark.parametrize("n,p", [(2, 3), (6, 5)])
+def test_closed_form_linear_factors_vs_reference_formula(n, p):
+    """a19 on the device (gvi_factors_set_closed_form): the reference's O(d^4) Isserlis loop
+    (ngd/NGDFactorizedLinear.h:93-129) restated by the oracle, and the quadrature route, which is
+    exact for a quadratic psi when p >= 3."""
+    rng = np.random.default_rng(900 + n)
+    K, d = 5, 2 * n
+    Phi, Qinv = quad_params(rng, K, n)
+    params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+    temp = rng.uniform(0.5, 5.0, K)
+    ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params, temperature=temp)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.3)
+    gh = ctx.moments(sid, mu, Sigma)
+    gh_cost = ctx.costs(sid, mu, Sigma)
+    ctx.factors_set_closed_form(sid, True)
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    cost = ctx.costs(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == 0
+    for k in range(K):
+        Lam = np.hstack([-Phi[k], np.eye(n)])
+        c, vd, vdd = o.linear_factor_closed_form(mu[k], Sigma[k], np.linalg.inv(Sigma[k]), Lam, Qinv[k], np.zeros(n), 0.5, temp[k])
+        assert rel(cost[k], c) < TIGHT and rel(Vdmu[k], vd) < TIGHT and rel(Vddmu[k], vdd) < TIGHT * 10
+    assert rel(Ephi, gh[0]) < TIGHT and rel(Vdmu, gh[1]) < TIGHT and rel(Vddmu, gh[2]) < TIGHT * 10
+    assert rel(cost, gh_cost) < TIGHT
+    ctx.factors_set_closed_form(sid, False)
+    assert np.array_equal(ctx.costs(sid, mu, Sigma), gh_cost)
+    # fixed prior: Lambda = I, constant 1
+    mu0 = rng.normal(size=(K, d)); Kinv = Qinv if d == n else np.stack([np.eye(d) * (1 + k) for k in range(K)])
+    ctx2, sid2 = single_set_ctx(api.PSI_FIXED_PRIOR, d, d, p, K, np.concatenate([mu0, Kinv.reshape(K, -1)], axis=1))
+    ctx2.factors_set_closed_form(sid2, True)
+    E2, V1, V2 = ctx2.moments(sid2, mu, Sigma)
+    for k in range(K):
+        c, vd, vdd = o.linear_factor_closed_form(mu[k], Sigma[k], np.linalg.inv(Sigma[k]), np.eye(d), Kinv[k], mu0[k], 1.0, 1.0)
+        assert rel(E2[k], c) < TIGHT and rel(V1[k], vd) < TIGHT and rel(V2[k], vdd) < TIGHT * 10
+    with pytest.raises(api.GviError):
+        c3, s3 = single_set_ctx(api.PSI_RANGE_1D, 1, 1, 4, 1, np.array([[1.2, 20.0, 40.0, 0.09, 9.0]]))
+        c3.factors_set_closed_form(s3, True)
+    ctx.close(); ctx2.close()
+
+
+def test_mixed_linear_nonlinear_graph_without_quadrature_for_priors():
+    """classify_factors split (gvibase/GVI-GH-Cuda-impl.h:31-38): priors and anchors closed-form, obstacle
+    factors by quadrature, in one resident NGD iteration; same iterates as the all-quadrature oracle."""
+    ch = make_chain("planar")
+    ctx, ids = api.context_for_chain(ch)
+    ctx.factors_set_closed_form(ids[0], True)
+    ctx.factors_set_closed_form(ids[2], True)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    chain = o.ChainNGD(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"])
+    for it in range(4):
+        r = ctx.ngd_step(0.55, 10)
+        ok, cost, ntr = chain.step()
+        assert r["accepted"] == ok and r["ntrials"] == ntr and np.isclose(r["new_cost"], cost, rtol=1e-9)
+    st = ctx.ngd_get_state()
+    assert rel(st["mu"], chain.mu) < RTOL / 10 and rel(st["D"], chain.D) < RTOL / 10
+    ctx.close()
+
+
 def test_k9_golden_fixture(golden_dir):
     """Committed K9 vectors: device GH moments == oracle GH == closed form (ngd/NGDFactorizedLinear.h:93-129)."""
     g = np.load(os.path.join(golden_dir, "k9_moments.npz"))
