@@ -47,6 +47,36 @@ def spgh_nodes(d: int, p: int):
     return Z, w, idx
 
 
+def _ck_global(lib, st):
+    if st:
+        raise GviError(st, lib.gvi_last_error(None).decode())
+
+
+def table_file_list(path: str):
+    """[(dim, deg, rows)] of the reference-format (cereal binary) quadrature-table file, in file order."""
+    lib = _lib.load()
+    n = C.c_int64()
+    _ck_global(lib, lib.gvi_table_file_list(path.encode(), 0, C.byref(n), None, None, None))
+    dims = np.empty(n.value); degs = np.empty(n.value); rows = np.empty(n.value, dtype=np.int64)
+    _ck_global(lib, lib.gvi_table_file_list(path.encode(), n.value, C.byref(n), _p(dims), _p(degs), _p(rows)))
+    return [(float(a), float(b), int(c)) for a, b, c in zip(dims, degs, rows)]
+
+
+def table_file_read(path: str, d: int, p: int):
+    lib = _lib.load()
+    N = C.c_int64(0)
+    _ck_global(lib, lib.gvi_table_file_read(path.encode(), d, p, C.byref(N), None, None))
+    Z = np.empty((N.value, d)); w = np.empty(N.value)
+    _ck_global(lib, lib.gvi_table_file_read(path.encode(), d, p, C.byref(N), _p(Z), _p(w)))
+    return Z, w
+
+
+def table_file_write(path: str, keys):
+    lib = _lib.load()
+    dims = np.array([k[0] for k in keys], dtype=np.int32); degs = np.array([k[1] for k in keys], dtype=np.int32)
+    _ck_global(lib, lib.gvi_table_file_write(path.encode(), len(keys), _p(dims), _p(degs)))
+
+
 class Context:
     def __init__(self, device: int = 0, dtype: int = GVI_F64):
         self.lib = _lib.load()

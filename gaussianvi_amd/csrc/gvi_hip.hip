@@ -709,6 +709,29 @@ gvi_status gvi_spgh_nodes(int d, int p, int64_t N, double* Z, double* w, int8_t*
   return GVI_OK;
 }
 
+gvi_status gvi_table_file_list(const char* path, int64_t cap, int64_t* count, double* dims, double* degs, int64_t* rows) {
+  if (!path || !count) return GVI_ERR_ARG;
+  return table_file_list(path, cap, count, dims, degs, rows) ? fail(nullptr, GVI_ERR_ARG, "cannot read table file") : GVI_OK;
+}
+
+gvi_status gvi_table_file_read(const char* path, int d, int p, int64_t* N, double* Z, double* w) {
+  if (!path || !N) return GVI_ERR_ARG;
+  int64_t found = 0;
+  const int rc = table_file_read(path, d, p, *N, Z, w, &found);
+  if (rc == 2) return fail(nullptr, GVI_ERR_NOTABLE, "key (d, p) not in the table file");
+  if (rc == 3) { *N = found; return fail(nullptr, GVI_ERR_ARG, "N does not match the entry"); }
+  if (rc) return fail(nullptr, GVI_ERR_ARG, "cannot read table file");
+  *N = found;
+  return GVI_OK;
+}
+
+gvi_status gvi_table_file_write(const char* path, int n_entries, const int32_t* dims, const int32_t* degs) {
+  if (!path || n_entries < 0 || (n_entries && (!dims || !degs))) return GVI_ERR_ARG;
+  const int rc = table_file_write(path, n_entries, dims, degs);
+  if (rc == 2) return fail(nullptr, GVI_ERR_NOTABLE, "(d, p) outside the tabulated rules");
+  return rc ? fail(nullptr, GVI_ERR_ARG, "cannot write table file") : GVI_OK;
+}
+
 gvi_status gvi_chain_set(gvi_ctx* ctx, int T, int n) {
   if (!ctx) return GVI_ERR_ARG;
   if (T < 1 || n < 1) return fail(ctx, GVI_ERR_ARG, "T and n must be >= 1");

@@ -76,6 +76,18 @@ gvi_status gvi_ctx_sync(gvi_ctx* ctx);
 gvi_status gvi_spgh_count(int d, int p, int64_t* N);
 gvi_status gvi_spgh_nodes(int d, int p, int64_t N, double* Z, double* w, int8_t* idx);
 
+/* ---- the reference's table FILE (QuadratureWeightsMap through cereal::BinaryOutputArchive:
+ *      quadrature/saveSparseGHWeightMap.h:14-51, helpers/SerializeEigenMaps.h:195-224; loaded at
+ *      quadrature/SparseGaussHermite.h:80-117).  Host only, no GPU.
+ * _list : number of entries; the (dim, deg, rows) of the first `cap` entries in file order (arrays may be NULL).
+ * _read : the entry with key (d, p) -> Z [N][d] row-major, w [N]; with Z = w = NULL only *N is returned.
+ *         GVI_ERR_NOTABLE when the key is absent (the reference only prints, SparseGaussHermite.h:150-160).
+ * _write: generate every (dims[e], degs[e]) with the in-tree nwspgr restatement and write them in that order
+ *         (save_pointweightmaps, saveSparseGHWeightMap.h:14-51). */
+gvi_status gvi_table_file_list(const char* path, int64_t cap, int64_t* count, double* dims, double* degs, int64_t* rows);
+gvi_status gvi_table_file_read(const char* path, int d, int p, int64_t* N, double* Z, double* w);
+gvi_status gvi_table_file_write(const char* path, int n_entries, const int32_t* dims, const int32_t* degs);
+
 /* ---- problem definition ---- */
 /* Chain of T states of size n (joint dimension T n): GVIGH(vec_factors, dim_state, num_states, ...)
  * gvibase/GVI-GH.h:41-64.  Drops previously added factor sets. */

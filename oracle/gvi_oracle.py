@@ -236,6 +236,35 @@ def psi_fixed_prior(x, mu0, Kinv):
     return float(e @ Kinv @ e)
 
 
+def cereal_table_bytes(entries):
+    """Byte image of a QuadratureWeightsMap written by cereal::BinaryOutputArchive
+    (quadrature/saveSparseGHWeightMap.h:44-50; helpers/SerializeEigenMaps.h:195-224): u64 count, then per
+    entry the key tuple (f64 dim, f64 deg), MatrixXd (i32 rows, i32 cols, elements row by row) and
+    VectorXd (i32 len, elements).  entries: [(dim, deg, Z[N,d], w[N])] in the order to write."""
+    import struct
+    out = [struct.pack("<Q", len(entries))]
+    for dim, deg, Z, w in entries:
+        Z = np.ascontiguousarray(Z, dtype="<f8"); w = np.ascontiguousarray(w, dtype="<f8")
+        out += [struct.pack("<dd", float(dim), float(deg)), struct.pack("<ii", Z.shape[0], Z.shape[1]), Z.tobytes(),
+                struct.pack("<i", w.shape[0]), w.tobytes()]
+    return b"".join(out)
+
+
+def cereal_table_parse(buf):
+    """Inverse of cereal_table_bytes -> {(dim, deg): (Z, w)} (the load side, quadrature/SparseGaussHermite.h:80-117)."""
+    import struct
+    (n,), off, res = struct.unpack_from("<Q", buf, 0), 8, {}
+    for _ in range(n):
+        dim, deg = struct.unpack_from("<dd", buf, off); off += 16
+        r, c = struct.unpack_from("<ii", buf, off); off += 8
+        Z = np.frombuffer(buf, dtype="<f8", count=r * c, offset=off).reshape(r, c); off += 8 * r * c
+        (ln,) = struct.unpack_from("<i", buf, off); off += 4
+        w = np.frombuffer(buf, dtype="<f8", count=ln, offset=off); off += 8 * ln
+        res[(dim, deg)] = (Z, w)
+    assert off == len(buf)
+    return res
+
+
 def planar_sdf_lookup(px, py, origin, cell, field):
     """PlanarSDF::convertPoint2toCell + signed_distance (helpers/CudaOperation.h:61-103): clamp the query
     to the grid, bilinear interpolation; field[r, c] (Eigen column-major data_array_[r + c rows], :130).

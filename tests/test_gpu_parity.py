@@ -291,6 +291,26 @@ def test_user_table_override_and_empty_edge_cases():
     ctx.close()
 
 
+def test_table_file_round_trip_feeds_a_factor_set(tmp_path):
+    """Reference-format table file -> gvi_table_file_read -> gvi_factors_set_table gives the same moments
+    as the built-in generator."""
+    path = str(tmp_path / "table.bin")
+    api.table_file_write(path, [(4, 3), (2, 4)])
+    Z, w = api.table_file_read(path, 4, 3)
+    rng = np.random.default_rng(77)
+    K, n = 3, 2
+    Phi, Qinv = quad_params(rng, K, n)
+    params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+    ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, 4, n, 3, K, params)
+    mu, Sigma = syn.random_marginals(rng, K, 4, 0.3)
+    a = ctx.moments(sid, mu, Sigma)
+    ctx.factors_set_table(sid, Z, w)
+    b = ctx.moments(sid, mu, Sigma)
+    for x, y in zip(a, b):
+        assert rel(y, x) < 1e-13
+    ctx.close()
+
+
 def test_non_psd_covariance_gives_nan_like_reference():
     """sqrt of a negative eigenvalue is NaN in the reference (quadrature/SparseGaussHermite.h:232-240)."""
     K, n, p = 1, 1, 3
