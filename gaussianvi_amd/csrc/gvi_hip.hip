@@ -45,6 +45,8 @@ struct Table {
   int d = 0, p = 0;
   int64_t N = 0, Np = 0;
   DevMem Zt, w;
+  DevMem codes, lut;       // 8-bit node codes [d/4][Np] + value look-up (moments_split_kernel); empty when not coded
+  bool coded = false;
 };
 
 struct FactorSet {
@@ -62,6 +64,7 @@ struct FactorSet {
   int nchunk = 1;
   int64_t chunk = 0;
   bool use_reg = false;
+  bool use_split = false;
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
@@ -81,6 +84,7 @@ struct FactorSet {
     f.K = K; f.d = d; f.m = m; f.kind = kind;
     f.N = table->N; f.Np = table->Np;
     f.Zt = table->Zt.d(); f.w = table->w.d();
+    f.codes = table->coded ? (const uint32_t*)table->codes.p : nullptr; f.lut = table->coded ? table->lut.d() : nullptr;
     f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
     f.temperature = temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.u0 = u0.d();
@@ -179,6 +183,42 @@ gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const dou
   HIPCK(c, t.w.ensure(wp.size() * 8));
   HIPCK(c, hipMemcpy(t.Zt.p, zt.data(), zt.size() * 8, hipMemcpyHostToDevice));
   HIPCK(c, hipMemcpy(t.w.p, wp.data(), wp.size() * 8, hipMemcpyHostToDevice));
+  // 8-bit node codes for the split kernel: a Smolyak table has a few dozen distinct node values
+  t.coded = false;
+  if (d >= 16 && d % 4 == 0) {
+    std::vector<double> vals{0.0};                                  // sorted distinct values
+    bool ok = true;
+    std::vector<uint32_t> packed((size_t)(d / 4) * t.Np, 0u);
+    // pass 1: distinct values
+    double last = 0.0;
+    for (size_t e = 0; e < (size_t)N * d && ok; ++e) {
+      const double v = Z[e];
+      if (v == last) continue;
+      last = v;
+      auto it = std::lower_bound(vals.begin(), vals.end(), v);
+      if (it == vals.end() || *it != v) {
+        if (vals.size() >= 256) ok = false;
+        else vals.insert(it, v);
+      }
+    }
+    if (ok) {
+      const uint32_t zero_code = (uint32_t)(std::lower_bound(vals.begin(), vals.end(), 0.0) - vals.begin());
+      uint32_t zero_word = zero_code | zero_code << 8 | zero_code << 16 | zero_code << 24;
+      std::fill(packed.begin(), packed.end(), zero_word);          // pad points decode to z = 0
+      for (int64_t i = 0; i < N; ++i)
+        for (int a = 0; a < d; ++a) {
+          const uint32_t code = (uint32_t)(std::lower_bound(vals.begin(), vals.end(), Z[(size_t)i * d + a]) - vals.begin());
+          uint32_t& word = packed[(size_t)(a / 4) * t.Np + i];
+          word = (word & ~(255u << (8 * (a % 4)))) | code << (8 * (a % 4));
+        }
+      vals.resize(256, 0.0);
+      HIPCK(c, t.codes.ensure(packed.size() * 4));
+      HIPCK(c, t.lut.ensure(256 * 8));
+      HIPCK(c, hipMemcpy(t.codes.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
+      HIPCK(c, hipMemcpy(t.lut.p, vals.data(), 256 * 8, hipMemcpyHostToDevice));
+      t.coded = true;
+    }
+  }
   return GVI_OK;
 }
 
@@ -195,6 +235,26 @@ bool reg_supported(int kind, int d, int m) {
                                       (d == 8 && m == 4) || (d == 12 && m == 6);
   if (kind == KIND_FIXED_PRIOR) return d == m && (d == 1 || d == 2 || d == 3 || d == 4 || d == 6 || d == 8);
   return false;
+}
+
+// split kernel (one block per factor and chunk): sum-of-squares kinds on a coded table
+bool split_supported(const FactorSet& s) {
+  return (s.kind == KIND_QUAD_PRIOR || s.kind == KIND_FIXED_PRIOR) && s.table->coded &&
+         (s.d == 16 || s.d == 20 || s.d == 24) && s.m <= s.d;
+}
+
+template <int D>
+gvi_status launch_split(gvi_ctx* c, const MomArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = (size_t)SPLIT_LDS_DOUBLES(D) * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (a.full) hipLaunchKernelGGL((moments_split_kernel<D, true>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((moments_split_kernel<D, false>), grid, dim3(256), lds, st, a);
+  return GVI_OK;
 }
 
 void plan_chunks(gvi_ctx* c, FactorSet& s, bool reg) {
@@ -316,9 +376,16 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   if (c->variant == 2 && !reg && !psi_ext)
     return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
   const bool closed = s.closed_form && !psi_ext;
+  const bool split = !closed && !reg && !psi_ext && c->variant != 1 && split_supported(s);
   if (closed) { reg = false; s.chunk = s.table->Np; s.nchunk = 1; }
-  else plan_chunks(c, s, reg);
+  else if (split) {
+    const int64_t tiles = s.table->Np / 64;                          // ~2 blocks per CU: K * nchunk >= 1024
+    int64_t nch = std::min<int64_t>(std::max<int64_t>(1, (1024 + s.K - 1) / s.K), tiles);
+    s.chunk = (tiles + nch - 1) / nch * 64;
+    s.nchunk = (int)((s.table->Np + s.chunk - 1) / s.chunk);
+  } else plan_chunks(c, s, reg);
   s.use_reg = reg;
+  s.use_split = split;
   const size_t need = (size_t)s.K * s.nchunk * npairs(s.d) * 8;
   HIPCK(c, s.partial.ensure(need));
   MomArgs a;
@@ -333,6 +400,11 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   }
   if (closed) {
     hipLaunchKernelGGL(moments_closed_kernel, dim3(s.K), dim3(64), 0, st, a);
+  } else if (split) {
+    const dim3 grid(s.K, s.nchunk);
+    if (s.d == 16) GVICK(launch_split<16>(c, a, grid, st));
+    else if (s.d == 20) GVICK(launch_split<20>(c, a, grid, st));
+    else GVICK(launch_split<24>(c, a, grid, st));
   } else if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
@@ -1576,7 +1648,7 @@ gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what, float* ms) {
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk) {
   FactorSet* s = get_set(ctx, set_id);
   if (!s) return GVI_ERR_ARG;
-  if (variant) *variant = s->closed_form ? 0 : (s->use_reg ? 2 : 1);
+  if (variant) *variant = s->closed_form ? 0 : (s->use_reg ? 2 : (s->use_split ? 3 : 1));
   if (nchunk) *nchunk = s->nchunk;
   if (chunk) *chunk = s->chunk;
   return GVI_OK;

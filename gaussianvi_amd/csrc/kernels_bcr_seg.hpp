@@ -28,9 +28,6 @@
 
 namespace gvi {
 
-// LDS-only workgroup barrier: unlike __syncthreads() it does not drain outstanding global stores
-// (vmcnt); everything the phases exchange goes through LDS.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct SegArgs {
   int T, n;

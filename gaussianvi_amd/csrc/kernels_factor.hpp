@@ -40,6 +40,8 @@ struct FactorDev {
   int64_t N, Np;            // points, padded to a multiple of 64 (pad: z = 0, w = 0)
   const double* Zt;         // [d][Np] dimension-major: lane-over-points loads are coalesced
   const double* w;          // [Np]
+  const uint32_t* codes;    // [d/4][Np] four 8-bit node codes per word (tables with <= 256 distinct values) or null
+  const double* lut;        // [256] code -> node value
   const double* A;          // [K][m][d]   sum-of-squares kinds
   const double* b;          // [K][m]
   const double* sgn;        // [K][m]
@@ -676,6 +678,145 @@ __global__ __launch_bounds__(256, FULL ? 1 : 2) void moments_wide_kernel(MomArgs
     s += __shfl_xor(s, 32);
     if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// moments_split_kernel<D, FULL>: factor dimensions whose (D+1)(D+2)/2 accumulators do not fit one
+// lane (D = 16, 20, 24; BASELINE configs[4]).  Block = 4 waves on ONE factor and the SAME 64 points per
+// step:  (1) every wave decodes z from the table's 8-bit node codes through a 256-entry LDS look-up
+// (D/4 coalesced dword loads per point instead of D doubles: 32 B/point at D = 24, nodes stay exact
+// fp64);  (2) wave v evaluates residual rows r = v, v+4, ... of the sum-of-squares psi and the four
+// partial sums meet in a double-buffered LDS tile (one LDS-only barrier per step);  (3) wave v owns
+// rows [split_row(v), split_row(v+1)) of the packed upper triangle (+ m1 of those rows, wave 0 also m0)
+// and accumulates them in registers.  Row boundaries balance the (D - a + 1) entries per row.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__host__ __device__ constexpr int split_row(int j) {
+  int total = 0;
+  for (int a = 0; a < D; ++a) total += D - a + 1;
+  int acc = 0, a = 0;
+  for (int q = 0; q < j && q < 3; ++q) {
+    const int target = total * (q + 1) / 4;
+    while (a < D && acc + (D - a + 1) / 2 <= target) { acc += D - a + 1; ++a; }
+  }
+  return j >= 4 ? D : a;
+}
+template <int D>
+__host__ __device__ constexpr int split_count(int r0, int r1) {
+  int n = 0;
+  for (int a = r0; a < r1; ++a) n += D - a + 1;
+  return n;
+}
+
+constexpr int SPLIT_LDS_DOUBLES(int D) { return 256 + D * D + 2 * D + 2 * 4 * 64 + 4 * 16 * 65; }
+
+template <int D, int R0, int R1, bool FULL>
+__device__ __forceinline__ void split_body(const MomArgs& a, const int k, const int wave, const int lane, const double* lut,
+                                           const double* hs, double* px, double* red) {
+  constexpr int NA = FULL ? split_count<D>(R0, R1) : 0;         // my rows: m1[a], M2[a][a..D)
+  constexpr int NT = NA + (R0 == 0 ? 1 : 0);                     // wave 0 also carries m0
+  const int m = a.f.m;
+  double acc[NT > 0 ? NT : 1];
+#pragma unroll
+  for (int j = 0; j < (NT > 0 ? NT : 1); ++j) acc[j] = 0.0;
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const uint32_t* __restrict__ codes = a.f.codes;
+  const double* __restrict__ w = a.f.w;
+  int buf = 0;
+  for (int64_t base = i0; base < i1; base += 64) {               // uniform trip count: barrier inside
+    const int64_t i = base + lane;
+    uint32_t cd[D / 4];
+#pragma unroll
+    for (int g = 0; g < D / 4; ++g) cd[g] = codes[(size_t)g * Np + i];
+    const double wi = w[i];
+    double z[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) z[c] = lut[(cd[c / 4] >> (8 * (c % 4))) & 255u];
+    double part = 0.0;
+    for (int r = wave; r < m; r += 4) {
+      const double* h = hs + r * D;
+      double u0 = hs[D * D + r], u1 = 0.0;                       // two chains per row
+#pragma unroll
+      for (int c = 0; c < D; c += 2) { u0 = fma(h[c], z[c], u0); u1 = fma(h[c + 1], z[c + 1], u1); }
+      const double u = u0 + u1;
+      part = fma(hs[D * D + D + r] * u, u, part);
+    }
+    px[(buf * 4 + wave) * 64 + lane] = part;
+    lds_barrier();
+    const double* pb = px + buf * 4 * 64 + lane;
+    const double psi = (pb[0] + pb[64]) + (pb[128] + pb[192]);
+    buf ^= 1;
+    const double cw = i < a.f.N ? wi * psi : 0.0;               // pad rows: w = 0 and a non-finite psi kept out
+    if (R0 == 0) acc[NT - 1] += cw;
+    if (FULL) {
+      int q = 0;
+#pragma unroll
+      for (int c = R0; c < R1; ++c) {
+        const double t = cw * z[c];
+        acc[q++] += t;
+#pragma unroll
+        for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
+      }
+    }
+  }
+  // cross-lane sums, 16 accumulators at a time through this wave's LDS tile (wave-private: no block barrier)
+  constexpr int NPK = (D + 1) * (D + 2) / 2;
+  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * (FULL ? NPK : 1);
+  double* rw = red + wave * 16 * 65;
+  constexpr int NB = (NT + 15) / 16;
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (bb * 16 + j < NT) rw[j * 65 + lane] = acc[bb * 16 + j];
+    wave_lds_sync();
+    const int j = lane & 15, part16 = lane >> 4;
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += rw[j * 65 + part16 * 16 + t];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const int loc = bb * 16 + lane;
+    if (lane < 16 && loc < NT) {
+      int dst = 0;                                                // m0
+      if (loc < NA) {
+        int row = R0, rem = loc;
+        while (rem >= D - row + 1) { rem -= D - row + 1; ++row; }
+        dst = rem == 0 ? 1 + row : pair_index(D, row, row + rem - 1);
+      }
+      out[dst] = s;
+    }
+    wave_lds_sync();
+  }
+}
+
+template <int D, bool FULL>
+__global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
+  extern __shared__ double sm[];
+  double* lut = sm;                        // [256]
+  double* hs = lut + 256;                  // H row-major [m][D] (padded to D rows) | u0 [D] | sgn [D]
+  double* px = hs + D * D + 2 * D;         // [2][4][64] partial psi
+  double* red = px + 2 * 4 * 64;           // [4][16][65]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int k = blockIdx.x, m = a.f.m;
+  lut[threadIdx.x] = a.f.lut[threadIdx.x];
+  for (int e = threadIdx.x; e < m * D; e += 256) {               // f.H is [D][m] (column by column)
+    const int r = e / D, c = e - r * D;
+    hs[e] = a.f.H[(size_t)k * m * D + c * m + r];
+  }
+  if (threadIdx.x < m) {
+    hs[D * D + threadIdx.x] = a.f.u0[(size_t)k * m + threadIdx.x];
+    hs[D * D + D + threadIdx.x] = a.f.sgn[(size_t)k * m + threadIdx.x];
+  }
+  __syncthreads();
+  switch (wave) {
+    case 0: split_body<D, split_row<D>(0), split_row<D>(1), FULL>(a, k, 0, lane, lut, hs, px, red); break;
+    case 1: split_body<D, split_row<D>(1), split_row<D>(2), FULL>(a, k, 1, lane, lut, hs, px, red); break;
+    case 2: split_body<D, split_row<D>(2), split_row<D>(3), FULL>(a, k, 2, lane, lut, hs, px, red); break;
+    default: split_body<D, split_row<D>(3), split_row<D>(4), FULL>(a, k, 3, lane, lut, hs, px, red); break;
   }
 }
 

@@ -21,6 +21,9 @@ CONFIGS = {
     "c3mini": (31, 9, 6, 5, "ltv"),
     "c3small": (32, 33, 6, 5, "ltv"),
     "c3": (3, 1025, 6, 5, "ltv"),           # BASELINE.json configs[2] (headline)
+    "c5mini": (51, 5, 12, 5, "ltv"),        # d = 24 slice (split kernel), N(24,5) = 243 905
+    "c5small": (52, 33, 12, 6, "ltv", 5),   # d = 24, p = 6: N = 2 438 801; unary factors at p = 5
+    "c5": (5, 4097, 12, 7, "ltv", 5),       # BASELINE.json configs[4]: N(24,7) = 20 557 057 (fp64, coded table)
 }
 
 # Physical scales.  They are chosen so that the joint Hessian is well conditioned (cond ~ 5e2 at
@@ -70,7 +73,8 @@ def make_chain(name: str):
     """Returns dict(T, n, specs, mu0, D0, U0).  specs[0]: the T-1 binary prior factors (d = 2n,
     QUAD_PRIOR); specs[1]: T unary measurement factors (d = n, FIXED_PRIOR), the first and the last
     being the strong end anchors."""
-    cfg, T, n, p, kind = CONFIGS[name]
+    cfg, T, n, p, kind = CONFIGS[name][:5]
+    p_unary = CONFIGS[name][5] if len(CONFIGS[name]) > 5 else p
     rng = np.random.default_rng(0x5EED + cfg)
     nd, K = n // 2, T - 1
     dt = DT[kind]
@@ -104,7 +108,7 @@ def make_chain(name: str):
         dict(kind=PSI_QUAD_PRIOR, d=2 * n, p=p, start=np.arange(K, dtype=np.int32),
              params=np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1),
              temperature=np.ones(K), Phi=Phi, Qinv=Qinv),
-        dict(kind=PSI_FIXED_PRIOR, d=n, p=p, start=np.arange(T, dtype=np.int32),
+        dict(kind=PSI_FIXED_PRIOR, d=n, p=p_unary, start=np.arange(T, dtype=np.int32),
              params=np.concatenate([meas, Kinv.reshape(T, -1)], axis=1),
              temperature=np.ones(T), mu0=meas, Kinv=Kinv),
     ]

@@ -1,4 +1,6 @@
 """Test-side glue: synthetic chains (gaussianvi_amd.synthetic) + the oracle's psi closures."""
+import functools
+
 import numpy as np
 
 import gvi_oracle as o
@@ -44,3 +46,9 @@ def make_chain(name):
         return out
     ch["oracle_sets"] = oracle_sets
     return ch
+
+
+@functools.lru_cache(maxsize=8)
+def oracle_table(d, p):
+    """o.nwspgr memoised for the session: (24,5) takes tens of seconds in numpy."""
+    return o.nwspgr(d, p)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import gvi_oracle as o
-from chains import make_chain, oracle_psi_batch
+from chains import make_chain, oracle_psi_batch, oracle_table
 from gaussianvi_amd import api, synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -87,6 +87,41 @@ def test_moments_fixed_prior_vs_oracle(d, p, variant):
     Z, w = o.nwspgr(d, p)
     r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_fixed_prior(mu0, Kinv), np.ones(K))
     assert rel(Ephi, r["E_phi"]) < TIGHT and rel(Vdmu, r["Vdmu"]) < TIGHT and rel(Vddmu, r["Vddmu"]) < TIGHT * 10
+    ctx.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("kind,d,p", [("quad", 24, 5), ("quad", 16, 4), ("quad", 20, 3), ("fixed", 24, 3), ("fixed", 16, 3)])
+def test_moments_wide_factors_split_kernel(kind, d, p, variant):
+    """BASELINE configs[4] shapes (d = 24): four waves per factor, 8-bit node codes + look-up table
+    (moments_split_kernel) against the oracle and against the generic kernel."""
+    rng = np.random.default_rng(2400 + d + p)
+    K = 3
+    if kind == "quad":
+        n = d // 2
+        Phi, Qinv = quad_params(rng, K, n)
+        params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+        temp = rng.uniform(0.5, 2.0, K)
+        ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params, temperature=temp)
+        psi = o.psi_batch_quad_prior(Phi, Qinv)
+    else:
+        mu0 = rng.normal(size=(K, d))
+        Kh = rng.normal(size=(K, d, d))
+        Kinv = Kh @ np.transpose(Kh, (0, 2, 1)) / d + 0.3 * np.eye(d)
+        temp = np.ones(K)
+        ctx, sid = single_set_ctx(api.PSI_FIXED_PRIOR, d, d, p, K, np.concatenate([mu0, Kinv.reshape(K, -1)], axis=1))
+        psi = o.psi_batch_fixed_prior(mu0, Kinv)
+    ctx.set_variant(variant)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.3)
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == (3 if variant == 0 else 1)
+    cost = ctx.costs(sid, mu, Sigma)
+    Z, w = oracle_table(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, psi, temp)
+    # |w|_1 grows to ~1e5 at (24,5): the sums themselves carry ~1e-11 relative rounding
+    assert rel(Ephi, r["E_phi"]) < 1e-8 and rel(Vdmu, r["Vdmu"]) < 1e-8 and rel(Vddmu, r["Vddmu"]) < 1e-7
+    assert rel(cost, r["cost"]) < 1e-8
+    assert np.array_equal(Vddmu, np.transpose(Vddmu, (0, 2, 1)))
     ctx.close()
 
 
