@@ -54,7 +54,7 @@ struct FactorSet {
   std::vector<int32_t> start;
   std::shared_ptr<Table> table;
   DevMem dstart, dptr, didx, A, b, sgn, raw, temperature;
-  DevMem S, Sinv, Lam, H, u0;         // per-pass products
+  DevMem S, Sinv, Lam, H, Hq, u0;     // per-pass products
   DevMem sdf;                         // HINGE_SDF_2D grid
   int sdf_rows = 0, sdf_cols = 0;
   double sdf_ox = 0, sdf_oy = 0, sdf_cell = 1;
@@ -87,7 +87,7 @@ struct FactorSet {
     f.codes = table->coded ? (const uint32_t*)table->codes.p : nullptr; f.lut = table->coded ? table->lut.d() : nullptr;
     f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
     f.temperature = temperature.d();
-    f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.u0 = u0.d();
+    f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.Hq = Hq.p ? Hq.d() : nullptr; f.u0 = u0.d();
     f.Vws = nullptr; f.warm = 0;
     f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell;
     return f;
@@ -240,20 +240,20 @@ bool reg_supported(int kind, int d, int m) {
 // split kernel (one block per factor and chunk): sum-of-squares kinds on a coded table
 bool split_supported(const FactorSet& s) {
   return (s.kind == KIND_QUAD_PRIOR || s.kind == KIND_FIXED_PRIOR) && s.table->coded &&
-         (s.d == 16 || s.d == 20 || s.d == 24) && s.m <= s.d;
+         (s.d == 16 || s.d == 20 || s.d == 24) && (s.m == s.d || s.m == s.d / 2);
 }
 
-template <int D>
+template <int D, int R>
 gvi_status launch_split(gvi_ctx* c, const MomArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)SPLIT_LDS_DOUBLES(D) * 8;
   static bool attr_set = false;
   if (!attr_set) {
-    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  if (a.full) hipLaunchKernelGGL((moments_split_kernel<D, true>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((moments_split_kernel<D, false>), grid, dim3(256), lds, st, a);
+  if (a.full) hipLaunchKernelGGL((moments_split_kernel<D, R, true>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((moments_split_kernel<D, R, false>), grid, dim3(256), lds, st, a);
   return GVI_OK;
 }
 
@@ -402,9 +402,13 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     hipLaunchKernelGGL(moments_closed_kernel, dim3(s.K), dim3(64), 0, st, a);
   } else if (split) {
     const dim3 grid(s.K, s.nchunk);
-    if (s.d == 16) GVICK(launch_split<16>(c, a, grid, st));
-    else if (s.d == 20) GVICK(launch_split<20>(c, a, grid, st));
-    else GVICK(launch_split<24>(c, a, grid, st));
+    const int R = (s.m + 3) / 4;
+    if (s.d == 16 && R == 2) GVICK((launch_split<16, 2>(c, a, grid, st)));
+    else if (s.d == 16) GVICK((launch_split<16, 4>(c, a, grid, st)));
+    else if (s.d == 20 && R == 3) GVICK((launch_split<20, 3>(c, a, grid, st)));
+    else if (s.d == 20) GVICK((launch_split<20, 5>(c, a, grid, st)));
+    else if (R == 3) GVICK((launch_split<24, 3>(c, a, grid, st)));
+    else GVICK((launch_split<24, 6>(c, a, grid, st)));
   } else if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
@@ -921,6 +925,11 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   HIPCK(ctx, s->Sinv.ensure((size_t)K * d * d * 8));
   HIPCK(ctx, s->Lam.ensure((size_t)K * d * d * 8));
   HIPCK(ctx, s->H.ensure((size_t)K * std::max(m, 1) * d * 8));
+  if (split_supported(*s)) {            // per-wave row blocks of H for the split kernel (rows >= m stay 0)
+    const size_t bytes = (size_t)K * 4 * d * ((m + 3) / 4) * 8;
+    HIPCK(ctx, s->Hq.ensure(bytes));
+    HIPCK(ctx, hipMemset(s->Hq.p, 0, bytes));
+  }
   HIPCK(ctx, s->u0.ensure((size_t)K * std::max(m, 1) * 8));
   GVICK(ensure_set_buffers(ctx, *s));
   HIPCK(ctx, hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));

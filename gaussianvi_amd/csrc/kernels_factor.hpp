@@ -53,6 +53,7 @@ struct FactorDev {
   double* Sinv;             // [K][d][d]
   double* Lam;              // [K][d][d]
   double* H;                // [K][d][m]  H = A S, stored column by column
+  double* Hq;               // [K][4][d][R], R = ceil(m/4): rows v R .. v R + R of H per wave v (split kernel) or null
   double* u0;               // [K][m]
   const double* sdf;        // HINGE_SDF_2D: column-major rows x cols signed-distance grid
   int sdf_rows, sdf_cols;
@@ -252,6 +253,10 @@ __device__ inline void prep_body(const FactorDev& f, const double* __restrict__ 
       double h = 0.0;
       for (int c = 0; c < d; ++c) h += Ak[r * d + c] * An[c * d + a];
       f.H[(size_t)k * m * d + a * m + r] = h;            // column-major [d][m]: a column's m entries contiguous
+      if (f.Hq) {
+        const int R = (m + 3) / 4;
+        f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+      }
     }
     if (lane < m) {
       double u = f.b[(size_t)k * m + lane];
@@ -691,81 +696,44 @@ __global__ __launch_bounds__(256, FULL ? 1 : 2) void moments_wide_kernel(MomArgs
 // rows [split_row(v), split_row(v+1)) of the packed upper triangle (+ m1 of those rows, wave 0 also m0)
 // and accumulates them in registers.  Row boundaries balance the (D - a + 1) entries per row.
 // ---------------------------------------------------------------------------------------------
-template <int D>
-__host__ __device__ constexpr int split_row(int j) {
-  int total = 0;
-  for (int a = 0; a < D; ++a) total += D - a + 1;
-  int acc = 0, a = 0;
-  for (int q = 0; q < j && q < 3; ++q) {
-    const int target = total * (q + 1) / 4;
-    while (a < D && acc + (D - a + 1) / 2 <= target) { acc += D - a + 1; ++a; }
-  }
-  return j >= 4 ? D : a;
-}
+// Row ownership of wave v: rows [lo, hi) plus the tail rows [lo2, hi2) (short rows from the bottom of the
+// triangle top up the waves that own the long rows).  Row a carries D - a + 1 accumulators (m1[a], M2[a][a..D)).
+struct SplitRows { int lo, hi, lo2, hi2; };
 template <int D>
 __host__ __device__ constexpr int split_count(int r0, int r1) {
   int n = 0;
   for (int a = r0; a < r1; ++a) n += D - a + 1;
   return n;
 }
-
-constexpr int SPLIT_LDS_DOUBLES(int D) { return 256 + D * D + 2 * D + 2 * 4 * 64 + 4 * 16 * 65; }
-
-template <int D, int R0, int R1, bool FULL>
-__device__ __forceinline__ void split_body(const MomArgs& a, const int k, const int wave, const int lane, const double* lut,
-                                           const double* hs, double* px, double* red) {
-  constexpr int NA = FULL ? split_count<D>(R0, R1) : 0;         // my rows: m1[a], M2[a][a..D)
-  constexpr int NT = NA + (R0 == 0 ? 1 : 0);                     // wave 0 also carries m0
-  const int m = a.f.m;
-  double acc[NT > 0 ? NT : 1];
-#pragma unroll
-  for (int j = 0; j < (NT > 0 ? NT : 1); ++j) acc[j] = 0.0;
-  const int64_t Np = a.f.Np;
-  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
-  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
-  const uint32_t* __restrict__ codes = a.f.codes;
-  const double* __restrict__ w = a.f.w;
-  int buf = 0;
-  for (int64_t base = i0; base < i1; base += 64) {               // uniform trip count: barrier inside
-    const int64_t i = base + lane;
-    uint32_t cd[D / 4];
-#pragma unroll
-    for (int g = 0; g < D / 4; ++g) cd[g] = codes[(size_t)g * Np + i];
-    const double wi = w[i];
-    double z[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) z[c] = lut[(cd[c / 4] >> (8 * (c % 4))) & 255u];
-    double part = 0.0;
-    for (int r = wave; r < m; r += 4) {
-      const double* h = hs + r * D;
-      double u0 = hs[D * D + r], u1 = 0.0;                       // two chains per row
-#pragma unroll
-      for (int c = 0; c < D; c += 2) { u0 = fma(h[c], z[c], u0); u1 = fma(h[c + 1], z[c + 1], u1); }
-      const double u = u0 + u1;
-      part = fma(hs[D * D + D + r] * u, u, part);
-    }
-    px[(buf * 4 + wave) * 64 + lane] = part;
-    lds_barrier();
-    const double* pb = px + buf * 4 * 64 + lane;
-    const double psi = (pb[0] + pb[64]) + (pb[128] + pb[192]);
-    buf ^= 1;
-    const double cw = i < a.f.N ? wi * psi : 0.0;               // pad rows: w = 0 and a non-finite psi kept out
-    if (R0 == 0) acc[NT - 1] += cw;
-    if (FULL) {
-      int q = 0;
-#pragma unroll
-      for (int c = R0; c < R1; ++c) {
-        const double t = cw * z[c];
-        acc[q++] += t;
-#pragma unroll
-        for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
-      }
-    }
+template <int D>
+__host__ __device__ constexpr SplitRows split_rows(int v) {
+  if (D == 24) {                                   // 82 / 82 / 80 / 81 accumulators
+    const SplitRows t[4] = {{0, 3, 21, 24}, {3, 7, 0, 0}, {7, 12, 0, 0}, {12, 21, 0, 0}};
+    return t[v];
   }
-  // cross-lane sums, 16 accumulators at a time through this wave's LDS tile (wave-private: no block barrier)
-  constexpr int NPK = (D + 1) * (D + 2) / 2;
-  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * (FULL ? NPK : 1);
-  double* rw = red + wave * 16 * 65;
+  // contiguous greedy split
+  int total = 0;
+  for (int a = 0; a < D; ++a) total += D - a + 1;
+  int bnd[5] = {0, 0, 0, 0, D};
+  int acc = 0, a = 0;
+  for (int q = 0; q < 3; ++q) {
+    const int target = total * (q + 1) / 4;
+    while (a < D && acc + (D - a + 1) / 2 <= target) { acc += D - a + 1; ++a; }
+    bnd[q + 1] = a;
+  }
+  return SplitRows{bnd[v], bnd[v + 1], 0, 0};
+}
+
+template <int D>
+__device__ __forceinline__ void split_decode(const uint32_t (&cd)[D / 4], const double* lut, double (&z)[D]) {
+#pragma unroll
+  for (int c = 0; c < D; ++c) z[c] = lut[(cd[c / 4] >> (8 * (c % 4))) & 255u];
+}
+
+// cross-lane sums of NT accumulators, 16 at a time through this wave's LDS tile (wave-private: no block
+// barrier); local accumulator j lands at packed index dst(j)
+template <int NT, typename Dst>
+__device__ __forceinline__ void split_reduce(const double* acc, double* rw, double* out, int lane, Dst dst) {
   constexpr int NB = (NT + 15) / 16;
 #pragma unroll
   for (int bb = 0; bb < NB; ++bb) {
@@ -780,43 +748,174 @@ __device__ __forceinline__ void split_body(const MomArgs& a, const int k, const 
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     const int loc = bb * 16 + lane;
-    if (lane < 16 && loc < NT) {
-      int dst = 0;                                                // m0
-      if (loc < NA) {
-        int row = R0, rem = loc;
-        while (rem >= D - row + 1) { rem -= D - row + 1; ++row; }
-        dst = rem == 0 ? 1 + row : pair_index(D, row, row + rem - 1);
-      }
-      out[dst] = s;
-    }
+    if (lane < 16 && loc < NT) out[dst(loc)] = s;
     wave_lds_sync();
   }
 }
 
-template <int D, bool FULL>
+// psi operands: H is wave-uniform and read-only for the whole launch, so it is addressed through the constant
+// address space -- the compiler then fetches it with s_load_dwordx* into SGPRs (scalar cache) and feeds it to
+// v_fma_f64 as the scalar source: no LDS traffic and no VGPRs for the psi operands.
+typedef const double __attribute__((address_space(4))) cdouble_t;
+
+// u[rr] = u0 + sum_c Hq[c][rr] z[c] for the R rows of one wave block; returns sum_rr sgn (u)^2.
+// The operands are re-fetched every call (scalar cache) in groups of GC columns, one group ahead of its use;
+// the empty asm makes each group's offset opaque so the loads are neither hoisted out of the point loop (that
+// would need 2 m D / 4 SGPRs and spill) nor merged into one burst.
+template <int D, int R>
+__device__ __forceinline__ double split_psi_rows(cdouble_t* hq, const double* u0s, const double* sgs, const double (&z)[D]) {
+  constexpr int GC = 4, NG = D / GC, GS = GC * R;
+  double u[R];
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) u[rr] = u0s[rr];
+  double h[GS], hn[GS];
+  int off = 0;
+  asm volatile("" : "+s"(off));
+#pragma unroll
+  for (int j = 0; j < GS; ++j) h[j] = hq[off + j];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+      int o2 = (g + 1) * GS;
+      asm volatile("" : "+s"(o2));
+#pragma unroll
+      for (int j = 0; j < GS; ++j) hn[j] = hq[o2 + j];
+    }
+#pragma unroll
+    for (int cc = 0; cc < GC; ++cc) {
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) u[rr] = fma(h[cc * R + rr], z[g * GC + cc], u[rr]);
+    }
+#pragma unroll
+    for (int j = 0; j < GS; ++j) h[j] = hn[j];
+  }
+  double part = 0.0;
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) part = fma(sgs[rr] * u[rr], u[rr], part);
+  return part;
+}
+
+template <int D, int R, int V>
+__device__ __forceinline__ void split_body(const MomArgs& a, const int k, const int lane, const double* lut,
+                                           const double* hs, double* px, double* red) {
+  constexpr SplitRows RW = split_rows<D>(V);
+  constexpr int NA1 = split_count<D>(RW.lo, RW.hi), NA = NA1 + split_count<D>(RW.lo2, RW.hi2);
+  constexpr int NT = NA + (V == 0 ? 1 : 0);                      // wave 0 also carries m0
+  double acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = 0.0;
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const uint32_t* __restrict__ codes = a.f.codes;
+  const double* __restrict__ w = a.f.w;
+  cdouble_t* hq = (cdouble_t*)(a.f.Hq + ((size_t)k * 4 + V) * D * R);
+  int buf = 0;
+  uint32_t cn[D / 4];                                            // next step's codes / weight (prefetch)
+#pragma unroll
+  for (int g = 0; g < D / 4; ++g) cn[g] = codes[(size_t)g * Np + i0 + lane];
+  double wn = w[i0 + lane];
+  for (int64_t base = i0; base < i1; base += 64) {               // uniform trip count: barrier inside
+    const int64_t i = base + lane;
+    uint32_t cd[D / 4];
+#pragma unroll
+    for (int g = 0; g < D / 4; ++g) cd[g] = cn[g];
+    const double wi = wn;
+    if (base + 64 < i1) {
+#pragma unroll
+      for (int g = 0; g < D / 4; ++g) cn[g] = codes[(size_t)g * Np + i + 64];
+      wn = w[i + 64];
+    }
+    double z[D];
+    split_decode<D>(cd, lut, z);
+    const double part = split_psi_rows<D, R>(hq, hs + V * R, hs + 4 * R + V * R, z);
+    px[(buf * 4 + V) * 64 + lane] = part;
+    lds_barrier();
+    const double* pb = px + buf * 4 * 64 + lane;
+    const double psi = (pb[0] + pb[64]) + (pb[128] + pb[192]);
+    buf ^= 1;
+    const double cw = i < a.f.N ? wi * psi : 0.0;               // pad rows: w = 0 and a non-finite psi kept out
+    if (V == 0) acc[NT - 1] += cw;
+    int q = 0;
+#pragma unroll
+    for (int c = RW.lo; c < RW.hi; ++c) {
+      const double t = cw * z[c];
+      acc[q++] += t;
+#pragma unroll
+      for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
+    }
+#pragma unroll
+    for (int c = RW.lo2; c < RW.hi2; ++c) {
+      const double t = cw * z[c];
+      acc[q++] += t;
+#pragma unroll
+      for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
+    }
+  }
+  constexpr int NPK = (D + 1) * (D + 2) / 2;
+  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * NPK;
+  split_reduce<NT>(acc, red + V * 16 * 65, out, lane, [](int loc) {
+    if (loc >= NA) return 0;                                       // m0
+    int row = loc < NA1 ? RW.lo : RW.lo2, rem = loc < NA1 ? loc : loc - NA1;
+    while (rem >= D - row + 1) { rem -= D - row + 1; ++row; }
+    return rem == 0 ? 1 + row : pair_index(D, row, row + rem - 1);
+  });
+}
+
+// cost pass: psi only, so nothing to share -- every wave takes its own 64 points of a 256-point step
+template <int D, int R>
+__device__ __forceinline__ void split_cost_body(const MomArgs& a, const int k, const int wave, const int lane,
+                                                const double* lut, const double* hs, double* red) {
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const uint32_t* __restrict__ codes = a.f.codes;
+  const double* __restrict__ w = a.f.w;
+  cdouble_t* hq = (cdouble_t*)(a.f.Hq + (size_t)k * 4 * D * R);
+  double acc = 0.0;
+  for (int64_t i = i0 + wave * 64 + lane; i < i1; i += 256) {
+    uint32_t cd[D / 4];
+#pragma unroll
+    for (int g = 0; g < D / 4; ++g) cd[g] = codes[(size_t)g * Np + i];
+    const double wi = w[i];
+    double z[D];
+    split_decode<D>(cd, lut, z);
+    double psi = 0.0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) psi += split_psi_rows<D, R>(hq + v * D * R, hs + v * R, hs + 4 * R + v * R, z);
+    acc += i < a.f.N ? wi * psi : 0.0;
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partial[(size_t)k * a.nchunk + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+constexpr int SPLIT_LDS_DOUBLES(int D) { return 256 + 2 * D + 8 + 2 * 4 * 64 + 4 * 16 * 65; }
+
+template <int D, int R, bool FULL>
 __global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
   extern __shared__ double sm[];
   double* lut = sm;                        // [256]
-  double* hs = lut + 256;                  // H row-major [m][D] (padded to D rows) | u0 [D] | sgn [D]
-  double* px = hs + D * D + 2 * D;         // [2][4][64] partial psi
+  double* hs = lut + 256;                  // u0 [4 R] | sgn [4 R]  (rows >= m: 0)
+  double* px = hs + 2 * D + 8;             // [2][4][64] partial psi
   double* red = px + 2 * 4 * 64;           // [4][16][65]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int k = blockIdx.x, m = a.f.m;
   lut[threadIdx.x] = a.f.lut[threadIdx.x];
-  for (int e = threadIdx.x; e < m * D; e += 256) {               // f.H is [D][m] (column by column)
-    const int r = e / D, c = e - r * D;
-    hs[e] = a.f.H[(size_t)k * m * D + c * m + r];
-  }
-  if (threadIdx.x < m) {
-    hs[D * D + threadIdx.x] = a.f.u0[(size_t)k * m + threadIdx.x];
-    hs[D * D + D + threadIdx.x] = a.f.sgn[(size_t)k * m + threadIdx.x];
+  if (threadIdx.x < 4 * R) {
+    const bool live = (int)threadIdx.x < m;
+    hs[threadIdx.x] = live ? a.f.u0[(size_t)k * m + threadIdx.x] : 0.0;
+    hs[4 * R + threadIdx.x] = live ? a.f.sgn[(size_t)k * m + threadIdx.x] : 0.0;
   }
   __syncthreads();
+  if (!FULL) { split_cost_body<D, R>(a, k, wave, lane, lut, hs, red); return; }
   switch (wave) {
-    case 0: split_body<D, split_row<D>(0), split_row<D>(1), FULL>(a, k, 0, lane, lut, hs, px, red); break;
-    case 1: split_body<D, split_row<D>(1), split_row<D>(2), FULL>(a, k, 1, lane, lut, hs, px, red); break;
-    case 2: split_body<D, split_row<D>(2), split_row<D>(3), FULL>(a, k, 2, lane, lut, hs, px, red); break;
-    default: split_body<D, split_row<D>(3), split_row<D>(4), FULL>(a, k, 3, lane, lut, hs, px, red); break;
+    case 0: split_body<D, R, 0>(a, k, lane, lut, hs, px, red); break;
+    case 1: split_body<D, R, 1>(a, k, lane, lut, hs, px, red); break;
+    case 2: split_body<D, R, 2>(a, k, lane, lut, hs, px, red); break;
+    default: split_body<D, R, 3>(a, k, lane, lut, hs, px, red); break;
   }
 }
 

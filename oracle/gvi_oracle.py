@@ -236,6 +236,16 @@ def psi_fixed_prior(x, mu0, Kinv):
     return float(e @ Kinv @ e)
 
 
+_NWSPGR_CACHE = {}
+
+
+def nwspgr_cached(dim, k):
+    """nwspgr memoised per process ((24,5) takes tens of seconds in numpy)."""
+    if (dim, k) not in _NWSPGR_CACHE:
+        _NWSPGR_CACHE[(dim, k)] = nwspgr(dim, k)
+    return _NWSPGR_CACHE[(dim, k)]
+
+
 def cereal_table_bytes(entries):
     """Byte image of a QuadratureWeightsMap written by cereal::BinaryOutputArchive
     (quadrature/saveSparseGHWeightMap.h:44-50; helpers/SerializeEigenMaps.h:195-224): u64 count, then per
@@ -836,7 +846,7 @@ class FactorSet:
         self.start = np.asarray(start, dtype=np.int64)
         self.d, self.p, self.psi_batch = d, p, psi_batch
         self.temperature = np.full(len(self.start), float(temperature))
-        self.Z, self.w = nwspgr(d, p)
+        self.Z, self.w = nwspgr_cached(d, p)
 
 
 class ChainNGD:

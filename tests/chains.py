@@ -48,7 +48,6 @@ def make_chain(name):
     return ch
 
 
-@functools.lru_cache(maxsize=8)
 def oracle_table(d, p):
     """o.nwspgr memoised for the session: (24,5) takes tens of seconds in numpy."""
-    return o.nwspgr(d, p)
+    return o.nwspgr_cached(d, p)

@@ -529,10 +529,11 @@ def test_chain_step_golden(golden_dir, name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,iters", [("c2", 3), ("c3small", 2)])
+@pytest.mark.parametrize("name,iters", [("c2", 3), ("c3small", 2), ("c5mini", 2)])
 def test_ngd_iterations_vs_oracle(name, iters):
-    """BASELINE configs[1] (64-factor d=4 p=3 chain) in full, and a 32-factor slice of the headline
-    d=12 p=5 LTV chain: several NGD iterations, iterate matching the CPU oracle to 1e-6."""
+    """BASELINE configs[1] (64-factor d=4 p=3 chain) in full, a 32-factor slice of the headline
+    d=12 p=5 LTV chain, and a 4-factor slice of configs[4] (d=24, n=12; split kernel, 244k sigma points per
+    factor): several NGD iterations, iterate matching the CPU oracle to 1e-6."""
     ch = make_chain(name)
     ctx, ids = api.context_for_chain(ch)
     ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
