@@ -79,7 +79,10 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic LDS kernel, 2 register kernel")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 register (LDS operands), 3 operand-resident, 5 register (SGPR operands)")
+    ap.add_argument("--restart-every", type=int, default=16,
+                    help="re-initialise (mu0, precision0) inside the timed region every R steps so that every step is a "
+                         "descending iteration with one accepted trial (the chain converges after ~35 steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,12 +122,21 @@ def main():
     # one process: the whole iteration (backtracking loop included) is one C-ABI call; sharded: the
     # Python driver interleaves the two all-reduces between the *_local / *_finish halves
     step_fn = (lambda: ctx.ngd_step(0.55, 10)) if (world == 1 and not ngd.group_forced) else (lambda: ngd.step(0.55, 10))
-    for _ in range(args.warmup):
+    def restart():
+        ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
+        ngd._cost = None
+
+    for i in range(args.warmup):
+        if i and i % args.restart_every == 0:
+            restart()
         step_fn()
+    restart()
     barrier()
     t0 = time.perf_counter()
     passes, kern_ms, log = 0, [], []
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i and i % args.restart_every == 0:
+            restart()                                   # timed: host upload + one refresh of the chain products
         r = step_fn()
         log.append(r)
         passes += 1 + r["ntrials"]
@@ -141,7 +153,11 @@ def main():
             ctx.ngd_step(0.55, 10)
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
-        flog = [ctx.ngd_step(0.55, 10) for _ in range(args.steps)]
+        flog = []
+        for i in range(args.steps):
+            if i and i % args.restart_every == 0:
+                ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
+            flog.append(ctx.ngd_step(0.55, 10))
         torch.cuda.synchronize()
         tf = time.perf_counter() - tf0
         fused = {"ms_per_step": 1e3 * tf / args.steps, "ngd_iters_per_s": args.steps / tf,
@@ -180,7 +196,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "c3: 1024-factor LTV-prior chain, d=12, sparse-GH p=5 (N=17217), T=1025 n=6, "
-                                   "+1025 unary d=6 p=5 factors; one step = one device-resident NGD iteration",
+                                   "+1025 unary d=6 p=5 factors; one step = one device-resident NGD iteration "
+                                   f"(state re-initialised inside the timed region every {args.restart_every} steps)",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": f"factors/{world} contiguous, all-reduce [g|D|U] + trial cost (RCCL)" if world > 1 else "none",
                        "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"]},
@@ -196,7 +213,10 @@ def main():
             # VALU form is the faster one (profiles/r01_fp64_pipes.txt), so the kernel uses v_fma_f64.
             "roofline": {"bound": "mfma", "achieved": f_alg * K0 * N0 / km / 1e12, "peak": FP64_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": f_alg * K0 * N0 / km / FP64_PEAK, "traffic": traffic,
-                         "kernel": "moments_tile_kernel<12, PsiQuad<12,6>, full>" if geo["variant"] == 2 else "moments_generic_kernel",
+                         "kernel": {0: "moments_sreg_kernel<12, 6, full>", 5: "moments_sreg_kernel<12, 6, full>",
+                                    2: "moments_reg_kernel<12, PsiQuad<12,6>, full>", 3: "moments_wide_kernel<12, PsiQuad<12,6>, full>",
+                                    4: "moments_tile_kernel<12, PsiQuad<12,6>, full>"}.get(args.variant, "moments_generic_kernel")
+                                   if geo["variant"] == 2 else "moments_generic_kernel",
                          "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": 188,
                          "executed_tflops": 2 * 188 * K0 * N0 / km / 1e12,
                          "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "

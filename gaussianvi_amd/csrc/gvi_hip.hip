@@ -233,7 +233,7 @@ bool reg_supported(int kind, int d, int m) {
   if (kind == KIND_HINGE_SDF_2D) return d == 2 || d == 4 || d == 6;
   if (kind == KIND_QUAD_PRIOR) return (d == 2 && m == 1) || (d == 4 && m == 2) || (d == 6 && m == 3) ||
                                       (d == 8 && m == 4) || (d == 12 && m == 6);
-  if (kind == KIND_FIXED_PRIOR) return d == m && (d == 1 || d == 2 || d == 3 || d == 4 || d == 6 || d == 8);
+  if (kind == KIND_FIXED_PRIOR) return d == m && (d == 1 || d == 2 || d == 3 || d == 4 || d == 6 || d == 8 || d == 12);
   return false;
 }
 
@@ -301,6 +301,30 @@ bool dispatch_tile(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t 
   return false;
 }
 
+template <int D, int M>
+void launch_sreg(const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (a.full) hipLaunchKernelGGL((moments_sreg_kernel<D, M, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((moments_sreg_kernel<D, M, false>), grid, dim3(256), 0, st, a);
+}
+
+// scalar-operand register kernel (variant 5)
+bool dispatch_sreg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
+  if (s.kind == KIND_QUAD_PRIOR) {
+    switch (s.d) {
+      case 4: launch_sreg<4, 2>(a, grid, st); return true;
+      case 8: launch_sreg<8, 4>(a, grid, st); return true;
+      case 12: launch_sreg<12, 6>(a, grid, st); return true;
+    }
+  }
+  if (s.kind == KIND_FIXED_PRIOR) {
+    switch (s.d) {
+      case 6: launch_sreg<6, 6>(a, grid, st); return true;
+      case 12: launch_sreg<12, 12>(a, grid, st); return true;
+    }
+  }
+  return false;
+}
+
 // operand-resident kernel: instantiated for the shapes of the BASELINE configs
 bool dispatch_wide(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
   if (s.kind == KIND_QUAD_PRIOR) {
@@ -345,6 +369,7 @@ bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t s
       case 4: launch_reg<4, PsiQuad<4, 4>>(a, grid, st); return true;
       case 6: launch_reg<6, PsiQuad<6, 6>>(a, grid, st); return true;
       case 8: launch_reg<8, PsiQuad<8, 8>>(a, grid, st); return true;
+      case 12: launch_reg<12, PsiQuad<12, 12>>(a, grid, st); return true;
     }
   }
   return false;
@@ -412,9 +437,10 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   } else if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
-    // auto: the operand-resident kernel wins for the cost pass (operands hoisted into VGPRs, 2 waves/SIMD),
-    // the LDS-operand kernel for the full pass (the 91 accumulators own the register file)
     if (c->variant == 4) done = dispatch_tile(s, a, grid, st);       // LDS-staged table (experimental)
+    // auto: psi operands from SGPRs where instantiated (fastest for both passes); otherwise the operand-
+    // resident kernel for the cost pass and the LDS-operand kernel for the full pass
+    if (c->variant == 5 || c->variant == 0) done = dispatch_sreg(s, a, grid, st);
     if (!done && (c->variant == 3 || (c->variant == 0 && !full))) done = dispatch_wide(s, a, grid, st);
     if (!done && !dispatch_reg(s, a, grid, st)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
@@ -1664,7 +1690,7 @@ gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nch
 }
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 4) return GVI_ERR_ARG;
+  if (!ctx || variant < 0 || variant > 5) return GVI_ERR_ARG;
   ctx->variant = variant;
   return GVI_OK;
 }

@@ -764,7 +764,8 @@ typedef const double __attribute__((address_space(4))) cdouble_t;
 // would need 2 m D / 4 SGPRs and spill) nor merged into one burst.
 template <int D, int R>
 __device__ __forceinline__ double split_psi_rows(cdouble_t* hq, const double* u0s, const double* sgs, const double (&z)[D]) {
-  constexpr int GC = 4, NG = D / GC, GS = GC * R;
+  constexpr int GC = (D % 4 == 0 && R <= 3) ? 4 : (D % 2 == 0 && R <= 6 ? 2 : 1);   // <= 12 doubles (24 SGPRs) per group
+  constexpr int NG = D / GC, GS = GC * R;
   double u[R];
 #pragma unroll
   for (int rr = 0; rr < R; ++rr) u[rr] = u0s[rr];
@@ -916,6 +917,76 @@ __global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
     case 1: split_body<D, R, 1>(a, k, lane, lut, hs, px, red); break;
     case 2: split_body<D, R, 2>(a, k, lane, lut, hs, px, red); break;
     default: split_body<D, R, 3>(a, k, lane, lut, hs, px, red); break;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// moments_sreg_kernel<D, M, FULL>: moments_reg_kernel for the sum-of-squares kinds with the psi operands
+// taken from SGPRs (scalar cache, see split_psi_rows) instead of LDS broadcast reads.  f.H is [D][M]: a
+// column's M entries contiguous, which is the group layout split_psi_rows walks.  Block = 4 waves = 4
+// consecutive factors over the same range of points.
+// ---------------------------------------------------------------------------------------------
+template <int D, int M, bool FULL>
+__global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
+  constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
+  constexpr int NB = (NP + 15) / 16;
+  __shared__ double us[4][2 * M];
+  __shared__ double red[4][16][65];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int kq = blockIdx.x * 4 + wave;
+  const bool active = kq < a.f.K;
+  const int k = __builtin_amdgcn_readfirstlane(active ? kq : a.f.K - 1);   // inactive waves redo the last factor
+  if (lane < M) {
+    us[wave][lane] = a.f.u0[(size_t)k * M + lane];
+    us[wave][M + lane] = a.f.sgn[(size_t)k * M + lane];
+  }
+  __syncthreads();
+  const uint64_t hbase = (uint64_t)(a.f.H + (size_t)k * M * D);
+  cdouble_t* hq = (cdouble_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(hbase >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase));
+  double acc[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const double* __restrict__ Zt = a.f.Zt;
+  const double* __restrict__ w = a.f.w;
+  for (int64_t base = i0; base < i1; base += 64) {             // wave-uniform loop (chunks are whole 64-point tiles)
+    const int64_t i = base + lane;
+    double z[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) z[c] = Zt[(size_t)c * Np + i];
+    const double wi = w[i];
+    const double psi = split_psi_rows<D, M>(hq, us[wave], us[wave] + M, z);
+    const double cw = i < a.f.N ? wi * psi : 0.0;
+    acc[0] += cw;
+    if (FULL) {
+      int q = 1 + D;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const double t = cw * z[c];
+        acc[1 + c] += t;
+#pragma unroll
+        for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
+      }
+    }
+  }
+  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * NP;
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (bb * 16 + j < NP) red[wave][j][lane] = acc[bb * 16 + j];
+    wave_lds_sync();
+    const int j = lane & 15, part = lane >> 4;
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) s += red[wave][j][part * 16 + t];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
+    wave_lds_sync();
   }
 }
 

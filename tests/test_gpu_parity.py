@@ -45,7 +45,7 @@ def quad_params(rng, K, n):
 # ------------------------------------------------------------------------------------------
 # a4-a9: moments / costs, every psi kind, both kernel variants
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("n,p,K", [(1, 3, 5), (2, 3, 7), (3, 4, 4), (4, 3, 3), (6, 5, 6)])
 def test_moments_quad_prior_vs_oracle(n, p, K, variant):
     rng = np.random.default_rng(100 + n)
@@ -71,8 +71,8 @@ def test_moments_quad_prior_vs_oracle(n, p, K, variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
-@pytest.mark.parametrize("d,p", [(1, 5), (2, 3), (3, 3), (6, 5)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("d,p", [(1, 5), (2, 3), (3, 3), (6, 5), (12, 3)])
 def test_moments_fixed_prior_vs_oracle(d, p, variant):
     rng = np.random.default_rng(200 + d)
     K = 4
