@@ -405,7 +405,9 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   if (closed) { reg = false; s.chunk = s.table->Np; s.nchunk = 1; }
   else if (split) {
     const int64_t tiles = s.table->Np / 64;                          // ~2 blocks per CU: K * nchunk >= 1024
-    int64_t nch = std::min<int64_t>(std::max<int64_t>(1, (1024 + s.K - 1) / s.K), tiles);
+    int64_t nch = std::max<int64_t>(1, (1024 + s.K - 1) / s.K);
+    nch = std::max<int64_t>(nch, (tiles + 16383) / 16384);         // <= 16k points per lane: bounds the rounding of the
+    nch = std::min<int64_t>(nch, tiles);                           // sequential sums (|w|_1 ~ 2e7 at (24,7))
     s.chunk = (tiles + nch - 1) / nch * 64;
     s.nchunk = (int)((s.table->Np + s.chunk - 1) / s.chunk);
   } else plan_chunks(c, s, reg);
