@@ -129,6 +129,9 @@ struct gvi_ctx {
   bool profile = false;
   bool profile_all = false;           // events around every moments / cost launch (else: set 0, full pass only)
   int target_waves = 2048;
+  bool no_scost = false;    // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
+  int cost_chunk_mult = 8;
+  int scost_f = 2;          // factors per wave of the cost kernel (2 or 4)  // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   hipEvent_t fork = nullptr;
   double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
   double seq = 0.0;
@@ -307,6 +310,18 @@ void launch_sreg(const MomArgs& a, dim3 grid, hipStream_t st) {
   else hipLaunchKernelGGL((moments_sreg_kernel<D, M, false>), grid, dim3(256), 0, st, a);
 }
 
+// cost pass with F factors per wave (grid.x shrinks by F); only the headline shapes
+bool scost_supported(const FactorSet& s) {
+  return (s.kind == KIND_QUAD_PRIOR && s.d == 12) || (s.kind == KIND_FIXED_PRIOR && s.d == 6);
+}
+template <int F>
+void launch_scost(const FactorSet& s, const MomArgs& a, int nchunk, hipStream_t st) {
+  const dim3 grid((s.K + 4 * F - 1) / (4 * F), nchunk);
+  if (s.kind == KIND_QUAD_PRIOR) hipLaunchKernelGGL((moments_scost_kernel<12, 6, F>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((moments_scost_kernel<6, 6, F>), grid, dim3(256), 0, st, a);
+}
+void dispatch_scost(gvi_ctx* c, const FactorSet& s, const MomArgs& a, int nchunk, hipStream_t st);
+
 // scalar-operand register kernel (variant 5)
 bool dispatch_sreg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
   if (s.kind == KIND_QUAD_PRIOR) {
@@ -375,6 +390,11 @@ bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t s
   return false;
 }
 
+void dispatch_scost(gvi_ctx* c, const FactorSet& s, const MomArgs& a, int nchunk, hipStream_t st) {
+  if (c->scost_f == 4) launch_scost<4>(s, a, nchunk, st);
+  else launch_scost<2>(s, a, nchunk, st);
+}
+
 // prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
 gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma, int slot = -1,
                     hipStream_t st = nullptr) {
@@ -411,6 +431,14 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     s.chunk = (tiles + nch - 1) / nch * 64;
     s.nchunk = (int)((s.table->Np + s.chunk - 1) / s.chunk);
   } else plan_chunks(c, s, reg);
+  if (reg && !full && !closed && (c->variant == 5 || c->variant == 0) && scost_supported(s) && !c->no_scost) {
+    // F factors per wave: keep the wave count up with more, shorter chunks
+    const int64_t iters = s.table->Np / 256;
+    int64_t nch = std::min<int64_t>(std::max<int64_t>(1, (int64_t)s.nchunk * c->cost_chunk_mult), std::max<int64_t>(1, iters));
+    const int64_t per = (iters + nch - 1) / nch;
+    s.chunk = per * 256;
+    s.nchunk = (int)((s.table->Np + s.chunk - 1) / s.chunk);
+  }
   s.use_reg = reg;
   s.use_split = split;
   const size_t need = (size_t)s.K * s.nchunk * npairs(s.d) * 8;
@@ -442,7 +470,11 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     if (c->variant == 4) done = dispatch_tile(s, a, grid, st);       // LDS-staged table (experimental)
     // auto: psi operands from SGPRs where instantiated (fastest for both passes); otherwise the operand-
     // resident kernel for the cost pass and the LDS-operand kernel for the full pass
-    if (c->variant == 5 || c->variant == 0) done = dispatch_sreg(s, a, grid, st);
+    if ((c->variant == 5 || c->variant == 0) && !full && scost_supported(s) && !c->no_scost) {
+      dispatch_scost(c, s, a, s.nchunk, st);
+      done = true;
+    }
+    if (!done && (c->variant == 5 || c->variant == 0)) done = dispatch_sreg(s, a, grid, st);
     if (!done && (c->variant == 3 || (c->variant == 0 && !full))) done = dispatch_wide(s, a, grid, st);
     if (!done && !dispatch_reg(s, a, grid, st)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
@@ -754,6 +786,9 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
+  if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
+  if (const char* w = getenv("GVI_SCOST_F")) c->scost_f = atoi(w) == 4 ? 4 : 2;
+  if (const char* w = getenv("GVI_COST_CHUNK_MULT")) c->cost_chunk_mult = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
   if (const char* w = getenv("GVI_SPECULATE")) c->speculate = atoi(w) != 0;
   if (const char* w = getenv("GVI_WARM_START")) c->warm_start = atoi(w) != 0;

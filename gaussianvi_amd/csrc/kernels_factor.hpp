@@ -991,6 +991,59 @@ __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// moments_scost_kernel<D, M, F>: cost pass (m0 only) of the sum-of-squares kinds with SGPR operands and F
+// factors per wave -- one load of the 64 sigma points feeds F psi evaluations, so the L1/L2 traffic per
+// evaluation drops by F (the cost pass executes only M D + M FMAs per point and is otherwise bound by the
+// 8-byte-per-lane table loads).  Block = 4 waves = 4 F consecutive factors over the same range of points.
+// ---------------------------------------------------------------------------------------------
+template <int D, int M, int F>
+__global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
+  __shared__ double us[4][F][2 * M];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int k0 = (blockIdx.x * 4 + wave) * F;
+  cdouble_t* hq[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const int k = __builtin_amdgcn_readfirstlane(k0 + f < a.f.K ? k0 + f : a.f.K - 1);
+    if (lane < M) {
+      us[wave][f][lane] = a.f.u0[(size_t)k * M + lane];
+      us[wave][f][M + lane] = a.f.sgn[(size_t)k * M + lane];
+    }
+    const uint64_t hbase = (uint64_t)(a.f.H + (size_t)k * M * D);
+    hq[f] = (cdouble_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(hbase >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase));
+  }
+  __syncthreads();
+  double acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.0;
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const double* __restrict__ Zt = a.f.Zt;
+  const double* __restrict__ w = a.f.w;
+  for (int64_t base = i0; base < i1; base += 64) {             // wave-uniform loop (chunks are whole 64-point tiles)
+    const int64_t i = base + lane;
+    double z[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) z[c] = Zt[(size_t)c * Np + i];
+    const double wi = i < a.f.N ? w[i] : 0.0;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const double psi = split_psi_rows<D, M>(hq[f], us[wave][f], us[wave][f] + M, z);
+      acc[f] += i < a.f.N ? wi * psi : 0.0;
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    double s = acc[f];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0 && k0 + f < a.f.K) a.partial[(size_t)(k0 + f) * a.nchunk + blockIdx.y] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // moments_tile_kernel<D, Psi, FULL>: the sigma-point table is staged through LDS.
 //   The four waves of a block (four factors) walk the same range of points, so a tile of TP = 256
 //   points x (D + 1) rows [z_0 .. z_{D-1}, w] is fetched ONCE per block by LDS-DMA
