@@ -10,6 +10,7 @@ import numpy as np
 from . import _lib
 
 PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK, PSI_HINGE_SDF_2D = 0, 1, 2, 3, 4
+PSI_HINGE_SDF_2D_BODY, PSI_HINGE_SDF_3D = 5, 6
 GVI_F64, GVI_F32 = 0, 1
 
 
@@ -138,6 +139,13 @@ class Context:
         f = np.asfortranarray(field, dtype=np.float64)                 # column-major like Eigen's MatrixXd
         self._ck(self.lib.gvi_factors_set_sdf2d(self.h, sid, float(origin[0]), float(origin[1]), float(cell_size),
                                                 f.shape[0], f.shape[1], f.ctypes.data_as(C.c_void_p)))
+
+    def factors_set_sdf3d(self, sid, origin, cell_size, field):
+        """field[r, c, z]: signed distance at (x = origin[0] + c cell, y = origin[1] + r cell, z = origin[2] + z cell)."""
+        f = np.asfortranarray(field, dtype=np.float64)                 # r fastest, then c, then z
+        o3 = _f64(np.asarray(origin, dtype=np.float64))
+        self._ck(self.lib.gvi_factors_set_sdf3d(self.h, sid, _p(o3), float(cell_size), f.shape[0], f.shape[1], f.shape[2],
+                                                f.ctypes.data_as(C.c_void_p)))
 
     def factors_set_closed_form(self, sid, on=True):
         self._ck(self.lib.gvi_factors_set_closed_form(self.h, sid, int(on)))
@@ -323,6 +331,8 @@ def context_for_chain(chain, device=0, specs=None):
     for spec in (chain["specs"] if specs is None else specs):
         ids.append(ctx.factors_add(spec["d"], spec["p"], spec["start"], spec["kind"], spec["params"],
                                    spec["temperature"]))
-        if spec["kind"] == PSI_HINGE_SDF_2D:
+        if spec["kind"] in (PSI_HINGE_SDF_2D, PSI_HINGE_SDF_2D_BODY):
             ctx.factors_set_sdf2d(ids[-1], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
+        if spec["kind"] == PSI_HINGE_SDF_3D:
+            ctx.factors_set_sdf3d(ids[-1], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
     return ctx, ids

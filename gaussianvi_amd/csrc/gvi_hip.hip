@@ -56,8 +56,8 @@ struct FactorSet {
   DevMem dstart, dptr, didx, A, b, sgn, raw, temperature;
   DevMem S, Sinv, Lam, H, Hq, u0;     // per-pass products
   DevMem sdf;                         // HINGE_SDF_2D grid
-  int sdf_rows = 0, sdf_cols = 0;
-  double sdf_ox = 0, sdf_oy = 0, sdf_cell = 1;
+  int sdf_rows = 0, sdf_cols = 0, sdf_nz = 1;
+  double sdf_ox = 0, sdf_oy = 0, sdf_oz = 0, sdf_cell = 1;
   DevMem Vws;                         // eigenvectors of the last resident-NGD prep (Jacobi warm start)
   int warm_count = 0;                 // preps since the last cold start
   DevMem partial;
@@ -89,7 +89,7 @@ struct FactorSet {
     f.temperature = temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.Hq = Hq.p ? Hq.d() : nullptr; f.u0 = u0.d();
     f.Vws = nullptr; f.warm = 0;
-    f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell;
+    f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz;
     return f;
   }
 };
@@ -234,6 +234,8 @@ FactorSet* get_set(gvi_ctx* c, int id) {
 bool reg_supported(int kind, int d, int m) {
   if (kind == KIND_RANGE_1D) return d == 1;
   if (kind == KIND_HINGE_SDF_2D) return d == 2 || d == 4 || d == 6;
+  if (kind == KIND_HINGE_SDF_2D_BODY) return d == 3 || d == 6;
+  if (kind == KIND_HINGE_SDF_3D) return d == 3 || d == 6;
   if (kind == KIND_QUAD_PRIOR) return (d == 2 && m == 1) || (d == 4 && m == 2) || (d == 6 && m == 3) ||
                                       (d == 8 && m == 4) || (d == 12 && m == 6);
   if (kind == KIND_FIXED_PRIOR) return d == m && (d == 1 || d == 2 || d == 3 || d == 4 || d == 6 || d == 8 || d == 12);
@@ -367,6 +369,14 @@ bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t s
       case 6: launch_reg<6, PsiHingeSdf2D<6>>(a, grid, st); return true;
     }
   }
+  if (s.kind == KIND_HINGE_SDF_2D_BODY) {
+    if (d == 3) { launch_reg<3, PsiHingeSdf<3, KIND_HINGE_SDF_2D_BODY>>(a, grid, st); return true; }
+    if (d == 6) { launch_reg<6, PsiHingeSdf<6, KIND_HINGE_SDF_2D_BODY>>(a, grid, st); return true; }
+  }
+  if (s.kind == KIND_HINGE_SDF_3D) {
+    if (d == 3) { launch_reg<3, PsiHingeSdf<3, KIND_HINGE_SDF_3D>>(a, grid, st); return true; }
+    if (d == 6) { launch_reg<6, PsiHingeSdf<6, KIND_HINGE_SDF_3D>>(a, grid, st); return true; }
+  }
   if (s.kind == KIND_QUAD_PRIOR) {
     switch (d) {
       case 2: launch_reg<2, PsiQuad<2, 1>>(a, grid, st); return true;
@@ -415,8 +425,8 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
 gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full,
                        hipStream_t st = nullptr) {
   if (!st) st = c->stream;
-  if (s.kind == KIND_HINGE_SDF_2D && !psi_ext && s.sdf_rows == 0)
-    return fail(c, GVI_ERR_STATE, "HINGE_SDF_2D set without a grid: call gvi_factors_set_sdf2d");
+  if (s.kind >= KIND_HINGE_SDF_2D && !psi_ext && s.sdf_rows == 0)
+    return fail(c, GVI_ERR_STATE, "HINGE_SDF set without a grid: call gvi_factors_set_sdf2d / gvi_factors_set_sdf3d");
   bool reg = reg_supported(s.kind, s.d, s.m) && !psi_ext && c->variant != 1;
   if (c->variant == 2 && !reg && !psi_ext)
     return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
@@ -902,6 +912,8 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
     case GVI_PSI_FIXED_PRIOR: m = d; need = d + (int64_t)d * d; break;
     case GVI_PSI_HOST_CALLBACK: need = 0; break;
     case GVI_PSI_HINGE_SDF_2D: if (d < 2) return fail(ctx, GVI_ERR_ARG, "HINGE_SDF_2D needs d >= 2"); need = 3; break;
+    case GVI_PSI_HINGE_SDF_2D_BODY: if (d < 3) return fail(ctx, GVI_ERR_ARG, "HINGE_SDF_2D_BODY needs d >= 3"); need = 6; break;
+    case GVI_PSI_HINGE_SDF_3D: if (d < 3) return fail(ctx, GVI_ERR_ARG, "HINGE_SDF_3D needs d >= 3"); need = 3; break;
     default: return fail(ctx, GVI_ERR_ARG, "unknown psi kind");
   }
   if (need > 0 && (!psi_params || params_per_factor < need))
@@ -961,8 +973,8 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   GVICK(up(s->A, A.data(), A.size() * 8));
   GVICK(up(s->b, b.data(), b.size() * 8));
   GVICK(up(s->sgn, sg.data(), sg.size() * 8));
-  if (psi_kind == GVI_PSI_RANGE_1D || psi_kind == GVI_PSI_HINGE_SDF_2D) {
-    const int np = psi_kind == GVI_PSI_RANGE_1D ? 5 : 3;
+  if (psi_kind == GVI_PSI_RANGE_1D || psi_kind >= GVI_PSI_HINGE_SDF_2D) {
+    const int np = (int)need;
     std::vector<double> raw((size_t)K * np);
     for (int k = 0; k < K; ++k) memcpy(&raw[(size_t)k * np], psi_params + (size_t)k * params_per_factor, (size_t)np * 8);
     s->raw_stride = np;
@@ -1019,13 +1031,32 @@ gvi_status gvi_factors_set_sdf2d(gvi_ctx* ctx, int set_id, double origin_x, doub
                                  int cols, const double* data) {
   FactorSet* s = get_set(ctx, set_id);
   if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
-  if (s->kind != KIND_HINGE_SDF_2D) return fail(ctx, GVI_ERR_ARG, "set is not GVI_PSI_HINGE_SDF_2D");
+  if (s->kind != KIND_HINGE_SDF_2D && s->kind != KIND_HINGE_SDF_2D_BODY)
+    return fail(ctx, GVI_ERR_ARG, "set is not GVI_PSI_HINGE_SDF_2D / _2D_BODY");
   if (rows < 2 || cols < 2 || !(cell_size > 0) || !data) return fail(ctx, GVI_ERR_ARG, "bad grid");
   HIPCK(ctx, hipSetDevice(ctx->device));
   GVICK(sync(ctx));
   HIPCK(ctx, s->sdf.ensure((size_t)rows * cols * 8));
   HIPCK(ctx, hipMemcpy(s->sdf.p, data, (size_t)rows * cols * 8, hipMemcpyHostToDevice));
   s->sdf_rows = rows; s->sdf_cols = cols; s->sdf_ox = origin_x; s->sdf_oy = origin_y; s->sdf_cell = cell_size;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_set_sdf3d(gvi_ctx* ctx, int set_id, const double* origin, double cell_size, int rows, int cols,
+                                 int nz, const double* data) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
+  if (s->kind != KIND_HINGE_SDF_3D) return fail(ctx, GVI_ERR_ARG, "set is not GVI_PSI_HINGE_SDF_3D");
+  if (rows < 2 || cols < 2 || nz < 2 || !(cell_size > 0) || !data || !origin) return fail(ctx, GVI_ERR_ARG, "bad grid");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  const size_t bytes = (size_t)rows * cols * nz * 8;
+  HIPCK(ctx, s->sdf.ensure(bytes));
+  HIPCK(ctx, hipMemcpy(s->sdf.p, data, bytes, hipMemcpyHostToDevice));
+  s->sdf_rows = rows; s->sdf_cols = cols; s->sdf_nz = nz;
+  s->sdf_ox = origin[0]; s->sdf_oy = origin[1]; s->sdf_oz = origin[2]; s->sdf_cell = cell_size;
   ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
   ctx->ngd.grad_valid = false;
   return GVI_OK;

@@ -26,7 +26,8 @@
 
 namespace gvi {
 
-enum { KIND_RANGE_1D = 0, KIND_QUAD_PRIOR = 1, KIND_FIXED_PRIOR = 2, KIND_HOST_CALLBACK = 3, KIND_HINGE_SDF_2D = 4 };
+enum { KIND_RANGE_1D = 0, KIND_QUAD_PRIOR = 1, KIND_FIXED_PRIOR = 2, KIND_HOST_CALLBACK = 3, KIND_HINGE_SDF_2D = 4,
+       KIND_HINGE_SDF_2D_BODY = 5, KIND_HINGE_SDF_3D = 6 };
 
 __host__ __device__ inline int npairs(int d) { return (d + 1) * (d + 2) / 2; }
 
@@ -56,8 +57,8 @@ struct FactorDev {
   double* Hq;               // [K][4][d][R], R = ceil(m/4): rows v R .. v R + R of H per wave v (split kernel) or null
   double* u0;               // [K][m]
   const double* sdf;        // HINGE_SDF_2D: column-major rows x cols signed-distance grid
-  int sdf_rows, sdf_cols;
-  double sdf_ox, sdf_oy, sdf_cell;
+  int sdf_rows, sdf_cols, sdf_nz;
+  double sdf_ox, sdf_oy, sdf_oz, sdf_cell;
   double* Vws;              // [K][d][d] eigenvectors of the previous prep (warm start) or null
   int warm;                 // 1: start the Jacobi sweeps from Vws (resident NGD iteration only)
 };
@@ -300,9 +301,9 @@ __device__ inline double psi_range_1d(const double* p, double x) {
   return e * e / p[4] / 2 + r * r / p[3] / 2;
 }
 
-// planar point-robot obstacle cost (helpers/CudaOperation.h:491-523): sigma * hinge(eps + r - sdf(x, y))^2,
-// sdf = PlanarSDF bilinear interpolation with the query clamped to the grid (:61-103).  p = [sigma, eps, r].
-__device__ inline double psi_hinge_sdf2d(const FactorDev& f, const double* p, double px, double py) {
+// PlanarSDF::getSignedDistance (helpers/CudaOperation.h:61-103): query clamped to the grid, bilinear
+// interpolation of the column-major field (data[r + c rows], :130).
+__device__ inline double sdf2d_lookup(const FactorDev& f, double px, double py) {
   const double xmax = f.sdf_ox + (f.sdf_cols - 1.0) * f.sdf_cell, ymax = f.sdf_oy + (f.sdf_rows - 1.0) * f.sdf_cell;
   const double xin = px < f.sdf_ox ? f.sdf_ox : (px > xmax ? xmax : px);
   const double yin = py < f.sdf_oy ? f.sdf_oy : (py > ymax ? ymax : py);
@@ -312,11 +313,61 @@ __device__ inline double psi_hinge_sdf2d(const FactorDev& f, const double* p, do
   const int hri = lri + 1 < f.sdf_rows ? lri + 1 : f.sdf_rows - 1;    // weight is 0 there; keeps the read in bounds
   const int hci = lci + 1 < f.sdf_cols ? lci + 1 : f.sdf_cols - 1;
   const int R = f.sdf_rows;
-  const double sd = (hr - row) * (hc - col) * f.sdf[lri + lci * R] + (row - lr) * (hc - col) * f.sdf[hri + lci * R] +
-                    (hr - row) * (col - lc) * f.sdf[lri + hci * R] + (row - lr) * (col - lc) * f.sdf[hri + hci * R];
-  const double thr = p[1] + p[2];
-  const double err = sd > thr ? 0.0 : thr - sd;
-  return err * err * p[0];
+  return (hr - row) * (hc - col) * f.sdf[lri + lci * R] + (row - lr) * (hc - col) * f.sdf[hri + lci * R] +
+         (hr - row) * (col - lc) * f.sdf[lri + hci * R] + (row - lr) * (col - lc) * f.sdf[hri + hci * R];
+}
+
+// SignedDistanceField::getSignedDistance (helpers/CudaOperation.h:165-226): clamped trilinear interpolation of
+// data[r + c rows + z rows cols] (:304-306); x -> column, y -> row, z -> slice.
+__device__ inline double sdf3d_lookup(const FactorDev& f, double px, double py, double pz) {
+  const double xmax = f.sdf_ox + (f.sdf_cols - 1.0) * f.sdf_cell, ymax = f.sdf_oy + (f.sdf_rows - 1.0) * f.sdf_cell,
+               zmax = f.sdf_oz + (f.sdf_nz - 1.0) * f.sdf_cell;
+  const double xin = px < f.sdf_ox ? f.sdf_ox : (px > xmax ? xmax : px);
+  const double yin = py < f.sdf_oy ? f.sdf_oy : (py > ymax ? ymax : py);
+  const double zin = pz < f.sdf_oz ? f.sdf_oz : (pz > zmax ? zmax : pz);
+  const double col = (xin - f.sdf_ox) / f.sdf_cell, row = (yin - f.sdf_oy) / f.sdf_cell, zz = (zin - f.sdf_oz) / f.sdf_cell;
+  const double lr = floor(row), lc = floor(col), lz = floor(zz), hr = lr + 1.0, hc = lc + 1.0, hz = lz + 1.0;
+  const int lri = (int)lr, lci = (int)lc, lzi = (int)lz;
+  const int hri = lri + 1 < f.sdf_rows ? lri + 1 : f.sdf_rows - 1;
+  const int hci = lci + 1 < f.sdf_cols ? lci + 1 : f.sdf_cols - 1;
+  const int hzi = lzi + 1 < f.sdf_nz ? lzi + 1 : f.sdf_nz - 1;
+  const size_t R = f.sdf_rows, RC = R * f.sdf_cols;
+  const double* g = f.sdf;
+  return (hr - row) * (hc - col) * (hz - zz) * g[lri + lci * R + lzi * RC] + (row - lr) * (hc - col) * (hz - zz) * g[hri + lci * R + lzi * RC] +
+         (hr - row) * (col - lc) * (hz - zz) * g[lri + hci * R + lzi * RC] + (row - lr) * (col - lc) * (hz - zz) * g[hri + hci * R + lzi * RC] +
+         (hr - row) * (hc - col) * (zz - lz) * g[lri + lci * R + hzi * RC] + (row - lr) * (hc - col) * (zz - lz) * g[hri + lci * R + hzi * RC] +
+         (hr - row) * (col - lc) * (zz - lz) * g[lri + hci * R + hzi * RC] + (row - lr) * (col - lc) * (zz - lz) * g[hri + hci * R + hzi * RC];
+}
+
+__device__ __forceinline__ double hinge_sq(double sd, double thr, double slope, double sigma) {
+  const double err = sd > thr ? 0.0 : (thr - sd) * slope;
+  return err * err * sigma;
+}
+
+// planar point robot (CudaOperation_PlanarPR::cost_obstacle_planar, helpers/CudaOperation.h:491-523): one ball at
+// (x0, x1), slope 1.  p = [sigma, eps, r].
+__device__ inline double psi_hinge_sdf2d(const FactorDev& f, const double* p, double px, double py) {
+  return hinge_sq(sdf2d_lookup(f, px, py), p[1] + p[2], 1.0, p[0]);
+}
+
+// planar quadrotor body (CudaOperation_Quad::cost_obstacle_planar / vec_balls, helpers/CudaOperation.h:565-606):
+// pose (x, z, phi) = x[0:3]; n_balls check points along the body axis starting at
+// pos - (L - 1.5 r)/2 (cos phi, sin phi), spaced L/n_balls.  p = [sigma, eps, r, slope, n_balls, L].
+__device__ inline double psi_hinge_sdf2d_body(const FactorDev& f, const double* p, double px, double pz, double phi) {
+  double sn, cs;
+  sincos(phi, &sn, &cs);
+  const double r = p[2], L = p[5], thr = p[1] + r;
+  const int nb = (int)p[4];
+  const double lx = px - (L - r * 1.5) * cs / 2.0, lz = pz - (L - r * 1.5) * sn / 2.0;
+  double cost = 0.0;
+  for (int i = 0; i < nb; ++i)
+    cost += hinge_sq(sdf2d_lookup(f, lx + L * cs / nb * i, lz + L * sn / nb * i), thr, p[3], p[0]);
+  return cost;
+}
+
+// 3-D point robot (CudaOperation_3dpR::cost_obstacle_planar, helpers/CudaOperation.h:650-683).  p = [sigma, eps, r].
+__device__ inline double psi_hinge_sdf3d(const FactorDev& f, const double* p, double px, double py, double pz) {
+  return hinge_sq(sdf3d_lookup(f, px, py, pz), p[1] + p[2], 1.0, p[0]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -438,6 +489,8 @@ __global__ __launch_bounds__(GEN_BS) void moments_generic_kernel(MomArgs a) {
       if (a.psi_ext) psi = a.psi_ext[(size_t)k * f.N + i];
       else if (f.kind == KIND_RANGE_1D) psi = psi_range_1d(f.raw + (size_t)k * f.raw_stride, xr[0]);
       else if (f.kind == KIND_HINGE_SDF_2D) psi = psi_hinge_sdf2d(f, f.raw + (size_t)k * f.raw_stride, xr[0], xr[1]);
+      else if (f.kind == KIND_HINGE_SDF_2D_BODY) psi = psi_hinge_sdf2d_body(f, f.raw + (size_t)k * f.raw_stride, xr[0], xr[1], xr[2]);
+      else if (f.kind == KIND_HINGE_SDF_3D) psi = psi_hinge_sdf3d(f, f.raw + (size_t)k * f.raw_stride, xr[0], xr[1], xr[2]);
       else {
         for (int r = 0; r < m; ++r) {
           double u = bsh[r];
@@ -527,23 +580,34 @@ struct PsiRange1D {
   }
 };
 
-// nonlinear obstacle cost: pose = (mu + S z)[0:2] (two rows of S in LDS), SDF lookups straight from L2
-template <int D>
-struct PsiHingeSdf2D {
-  static constexpr int LDS = 2 * D + 2 + 3;
+// nonlinear obstacle costs: pose = (mu + S z)[0:NPOSE] (NPOSE rows of S in LDS), SDF look-ups straight from L2
+template <int D, int KIND>
+struct PsiHingeSdf {
+  static constexpr int NPOSE = KIND == KIND_HINGE_SDF_2D ? 2 : 3;
+  static constexpr int NPAR = KIND == KIND_HINGE_SDF_2D_BODY ? 6 : 3;
+  static constexpr int LDS = NPOSE * D + NPOSE + NPAR;
   static constexpr bool GUARD = false;
   __device__ static void load(const MomArgs& a, int k, double* hs, int lane) {
-    if (lane < 2 * D) hs[lane] = a.f.S[(size_t)k * D * D + lane];          // rows 0 and 1 of S
-    if (lane < 2) hs[2 * D + lane] = a.mu[(size_t)k * D + lane];
-    if (lane < 3) hs[2 * D + 2 + lane] = a.f.raw[(size_t)k * a.f.raw_stride + lane];
+    if (lane < NPOSE * D) hs[lane] = a.f.S[(size_t)k * D * D + lane];       // rows 0 .. NPOSE-1 of S
+    if (lane < NPOSE) hs[NPOSE * D + lane] = a.mu[(size_t)k * D + lane];
+    if (lane < NPAR) hs[NPOSE * D + NPOSE + lane] = a.f.raw[(size_t)k * a.f.raw_stride + lane];
   }
   __device__ static double eval(const double (&z)[D], const double* hs, const MomArgs& a) {
-    double px = hs[2 * D], py = hs[2 * D + 1];
+    double pose[NPOSE];
 #pragma unroll
-    for (int c = 0; c < D; ++c) { px = fma(hs[c], z[c], px); py = fma(hs[D + c], z[c], py); }
-    return psi_hinge_sdf2d(a.f, hs + 2 * D + 2, px, py);
+    for (int r = 0; r < NPOSE; ++r) {
+      double v = hs[NPOSE * D + r];
+#pragma unroll
+      for (int c = 0; c < D; ++c) v = fma(hs[r * D + c], z[c], v);
+      pose[r] = v;
+    }
+    const double* p = hs + NPOSE * D + NPOSE;
+    if (KIND == KIND_HINGE_SDF_2D) return psi_hinge_sdf2d(a.f, p, pose[0], pose[1]);
+    if (KIND == KIND_HINGE_SDF_2D_BODY) return psi_hinge_sdf2d_body(a.f, p, pose[0], pose[1], pose[NPOSE - 1]);
+    return psi_hinge_sdf3d(a.f, p, pose[0], pose[1], pose[NPOSE - 1]);
   }
 };
+template <int D> using PsiHingeSdf2D = PsiHingeSdf<D, KIND_HINGE_SDF_2D>;
 
 template <int D, typename Psi, bool FULL>
 __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {

@@ -13,6 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK, PSI_HINGE_SDF_2D = 0, 1, 2, 3, 4
+PSI_HINGE_SDF_2D_BODY, PSI_HINGE_SDF_3D = 5, 6
 
 CONFIGS = {
     # name: (cfg#, T, n, p, prior kind)
@@ -162,6 +163,63 @@ def make_planar_chain(T=17, p=3, seed=0x5EED + 40):
              params=np.concatenate([anchors, Kinv.reshape(2, -1)], axis=1), temperature=np.ones(2), mu0=anchors, Kinv=Kinv),
     ]
     return dict(name="planar", T=T, n=n, specs=specs, mu0=mu0, D0=D0, U0=U0)
+
+
+def sphere_sdf3d(origin, cell, rows, cols, nz, centers, radii):
+    """Signed distance to a union of balls: field[r, c, z] at origin + (c, r, z) * cell."""
+    xs = origin[0] + np.arange(cols) * cell
+    ys = origin[1] + np.arange(rows) * cell
+    zs = origin[2] + np.arange(nz) * cell
+    Y, X, Zz = np.meshgrid(ys, xs, zs, indexing="ij")
+    f = np.full((rows, cols, nz), np.inf)
+    for (cx, cy, cz), r in zip(centers, radii):
+        f = np.minimum(f, np.sqrt((X - cx) ** 2 + (Y - cy) ** 2 + (Zz - cz) ** 2) - r)
+    return f
+
+
+def make_obstacle_chain(kind: str, T=9, p=3, seed=0x5EED + 41):
+    """n = 6 planning graphs of the reference's other two obstacle workloads: "quad2d" (planar quadrotor,
+    state [x, z, phi, vx, vz, w], body of 5 check points, helpers/CudaOperation.h:565-606) and "pr3d" (3-D point
+    robot, state [x, y, z, v], trilinear field, :650-683): minimum-acceleration priors (d = 12), one obstacle
+    factor per state (d = 6) and two end anchors."""
+    rng = np.random.default_rng(seed + (0 if kind == "quad2d" else 1))
+    n, nd, K = 6, 3, T - 1
+    dt = 0.25
+    Phi1, Qinv1 = _minacc(nd, QC, dt)
+    Phi, Qinv = np.stack([Phi1] * K), np.stack([Qinv1] * K)
+    horizon = (T - 1) * dt
+    if kind == "quad2d":
+        start, goal = np.array([-3.0, -0.5, 0.2]), np.array([3.0, 0.6, -0.1])
+        origin, cell = (-6.0, -5.0), 0.1
+        field = circle_sdf(origin, cell, 101, 121, [(0.0, 2.2), (-1.0, -3.0)], [1.2, 0.9])
+        obst = dict(kind=PSI_HINGE_SDF_2D_BODY, params=np.tile(np.array([[15.5, 0.5, 0.3, 5.0, 5.0, 1.0]]), (T, 1)))
+    else:
+        start, goal = np.array([-2.0, -0.5, 0.0]), np.array([2.0, 0.5, 0.6])
+        origin, cell = (-4.0, -3.0, -2.0), 0.2
+        field = sphere_sdf3d(origin, cell, 31, 41, 21, [(0.0, 1.4, 0.3), (-0.5, -1.8, 0.0)], [1.0, 0.8])
+        obst = dict(kind=PSI_HINGE_SDF_3D, params=np.tile(np.array([[15.5, 0.5, 0.3]]), (T, 1)))
+    vel = (goal - start) / horizon
+    t = np.arange(T)[:, None] * dt
+    nominal = np.hstack([start[None] + vel[None] * t, np.tile(vel, (T, 1))])
+    mu0 = nominal + 0.02 * rng.normal(size=nominal.shape)
+    anchors = np.stack([nominal[0], nominal[-1]])
+    Kinv = np.stack([np.eye(n) / 1e-2] * 2)
+    D0 = np.zeros((T, n, n)); U0 = np.zeros((T - 1, n, n))
+    for k in range(K):
+        Lam = np.hstack([-Phi[k], np.eye(n)])
+        M = Lam.T @ Qinv[k] @ Lam
+        D0[k] += M[:n, :n]; D0[k + 1] += M[n:, n:]; U0[k] += M[:n, n:]
+    D0[0] += 2 * Kinv[0]; D0[-1] += 2 * Kinv[1]
+    D0 += 0.5 * np.eye(n)
+    specs = [
+        dict(kind=PSI_QUAD_PRIOR, d=2 * n, p=p, start=np.arange(K, dtype=np.int32),
+             params=np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1), temperature=np.ones(K), Phi=Phi, Qinv=Qinv),
+        dict(d=n, p=p + 1, start=np.arange(T, dtype=np.int32), temperature=np.ones(T),
+             sdf_origin=origin, sdf_cell=cell, sdf_field=field, **obst),
+        dict(kind=PSI_FIXED_PRIOR, d=n, p=p, start=np.array([0, T - 1], dtype=np.int32),
+             params=np.concatenate([anchors, Kinv.reshape(2, -1)], axis=1), temperature=np.ones(2), mu0=anchors, Kinv=Kinv),
+    ]
+    return dict(name=kind, T=T, n=n, specs=specs, mu0=mu0, D0=D0, U0=U0)
 
 
 def random_marginals(rng, K, d, scale=1.0):

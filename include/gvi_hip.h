@@ -52,10 +52,16 @@ enum { GVI_F64 = 0, GVI_F32 = 1 };
  *       psi(x) = sigma * max(0, epsilon + radius - sdf(x0, x1))^2, sdf = bilinear interpolation of a 2-D
  *       signed-distance grid shared by the set (gvi_factors_set_sdf2d): the reference's planar point-robot
  *       obstacle cost (helpers/CudaOperation.h:491-523 with PlanarSDF :21-131) -- SURVEY 8(f)1
+ *   GVI_PSI_HINGE_SDF_2D_BODY [sigma, epsilon, radius, slope, n_balls, L]   d >= 3 (pose = (x, z, phi) = x[0:3])
+ *       planar quadrotor body: n_balls check points along the body axis, psi = sum_i sigma (slope hinge_i)^2
+ *       (CudaOperation_Quad::cost_obstacle_planar / vec_balls, helpers/CudaOperation.h:565-606); same 2-D grid call
+ *   GVI_PSI_HINGE_SDF_3D  [sigma, epsilon, radius]                          d >= 3 (pose = x[0:3])
+ *       3-D point robot on a trilinear signed-distance field (CudaOperation_3dpR, helpers/CudaOperation.h:650-683;
+ *       SignedDistanceField :133-322); grid by gvi_factors_set_sdf3d
  *   GVI_PSI_HOST_CALLBACK no parameters: psi is an opaque host function (the reference's
  *       std::function, ngd/NGDFactorizedBaseGH.h:30,46-48); use gvi_expand + gvi_moments_from_psi. */
 enum { GVI_PSI_RANGE_1D = 0, GVI_PSI_QUAD_PRIOR = 1, GVI_PSI_FIXED_PRIOR = 2, GVI_PSI_HOST_CALLBACK = 3,
-       GVI_PSI_HINGE_SDF_2D = 4 };
+       GVI_PSI_HINGE_SDF_2D = 4, GVI_PSI_HINGE_SDF_2D_BODY = 5, GVI_PSI_HINGE_SDF_3D = 6 };
 
 const char* gvi_version(void);
 /* Message of the last failing call on this context (never NULL). */
@@ -107,6 +113,10 @@ gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const doub
  * (data[r + c * rows], :130), row = y cell, col = x cell; queries are clamped to the grid (:61-80). */
 gvi_status gvi_factors_set_sdf2d(gvi_ctx* ctx, int set_id, double origin_x, double origin_y, double cell_size,
                                  int rows, int cols, const double* data);
+/* 3-D field of a GVI_PSI_HINGE_SDF_3D set: SignedDistanceField(origin[3], cell_size, data) with
+ * data[r + c * rows + z * rows * cols] (helpers/CudaOperation.h:148-158, 304-306): row = y, col = x, slice = z. */
+gvi_status gvi_factors_set_sdf3d(gvi_ctx* ctx, int set_id, const double* origin, double cell_size, int rows, int cols,
+                                 int nz, const double* data);
 /* Closed-form route for a QUAD_PRIOR / FIXED_PRIOR set: NGDFactorizedLinear::calculate_partial_V and
  * fact_cost_value (ngd/NGDFactorizedLinear.h:93-129) instead of quadrature -- the factors the reference's
  * classify_factors sends to its linear branch (gvibase/GVI-GH-Cuda-impl.h:31-38).  No sigma points are

@@ -304,6 +304,54 @@ def psi_batch_hinge_sdf2d(params, origin, cell, field):
     return f
 
 
+def sdf3d_lookup(px, py, pz, origin, cell, field):
+    """SignedDistanceField::convertPoint3toCell + signed_distance (helpers/CudaOperation.h:176-226): clamp, trilinear
+    interpolation; field[r, c, z] = data_array_[r + c rows + z rows cols] (:304-306), x -> col, y -> row."""
+    rows, cols, nz = field.shape
+    xin = np.clip(px, origin[0], origin[0] + (cols - 1.0) * cell)
+    yin = np.clip(py, origin[1], origin[1] + (rows - 1.0) * cell)
+    zin = np.clip(pz, origin[2], origin[2] + (nz - 1.0) * cell)
+    col, row, zz = (xin - origin[0]) / cell, (yin - origin[1]) / cell, (zin - origin[2]) / cell
+    lr, lc, lz = np.floor(row), np.floor(col), np.floor(zz)
+    hr, hc, hz = lr + 1.0, lc + 1.0, lz + 1.0
+    lri, lci, lzi = (np.nan_to_num(v, nan=0.0).astype(int) for v in (lr, lc, lz))
+    hri, hci, hzi = np.minimum(lri + 1, rows - 1), np.minimum(lci + 1, cols - 1), np.minimum(lzi + 1, nz - 1)
+    g = field
+    return ((hr - row) * (hc - col) * (hz - zz) * g[lri, lci, lzi] + (row - lr) * (hc - col) * (hz - zz) * g[hri, lci, lzi] +
+            (hr - row) * (col - lc) * (hz - zz) * g[lri, hci, lzi] + (row - lr) * (col - lc) * (hz - zz) * g[hri, hci, lzi] +
+            (hr - row) * (hc - col) * (zz - lz) * g[lri, lci, hzi] + (row - lr) * (hc - col) * (zz - lz) * g[hri, lci, hzi] +
+            (hr - row) * (col - lc) * (zz - lz) * g[lri, hci, hzi] + (row - lr) * (col - lc) * (zz - lz) * g[hri, hci, hzi])
+
+
+def psi_batch_hinge_sdf2d_body(params, origin, cell, field):
+    """CudaOperation_Quad::cost_obstacle_planar + vec_balls (helpers/CudaOperation.h:565-606): pose (x, z, phi);
+    params [K,6] = (sigma, eps, r, slope, n_balls, L)."""
+    def f(X, sel=slice(None)):
+        P = params[sel]
+        px, pz, phi = X[:, :, 0], X[:, :, 1], X[:, :, 2]
+        sig, eps, r, slope, nb, L = (P[:, j][:, None] for j in range(6))
+        lx = px - (L - r * 1.5) * np.cos(phi) / 2.0
+        lz = pz - (L - r * 1.5) * np.sin(phi) / 2.0
+        cost = np.zeros_like(px)
+        for i in range(int(P[0, 4])):
+            sd = planar_sdf_lookup(lx + L * np.cos(phi) / nb * i, lz + L * np.sin(phi) / nb * i, origin, cell, field)
+            err = np.where(sd > eps + r, 0.0, (eps + r - sd) * slope)
+            cost = cost + err * err * sig
+        return cost
+    return f
+
+
+def psi_batch_hinge_sdf3d(params, origin, cell, field):
+    """CudaOperation_3dpR::cost_obstacle_planar (helpers/CudaOperation.h:650-668): one ball at x[0:3], slope 1."""
+    def f(X, sel=slice(None)):
+        P = params[sel]
+        sd = sdf3d_lookup(X[:, :, 0], X[:, :, 1], X[:, :, 2], origin, cell, field)
+        thr = (P[:, 1] + P[:, 2])[:, None]
+        err = np.where(sd > thr, 0.0, thr - sd)
+        return err * err * P[:, 0][:, None]
+    return f
+
+
 def ltv_phi_q(A_list, B_list, delta_t: float):
     """(Phi, Q) of LTV_GP (gp/LTV_prior.h:123-197): Phi' = A(t) Phi, Q' = A Q + Q A^T + B B^T over
     [0, dt] with A, B piece-wise constant on 4 sub-intervals.  The reference integrates with GSL

@@ -12,6 +12,10 @@ def oracle_psi_batch(spec):
         return o.psi_batch_quad_prior(spec["Phi"], spec["Qinv"])
     if spec["kind"] == syn.PSI_FIXED_PRIOR:
         return o.psi_batch_fixed_prior(spec["mu0"], spec["Kinv"])
+    if spec["kind"] == syn.PSI_HINGE_SDF_2D_BODY:
+        return o.psi_batch_hinge_sdf2d_body(spec["params"], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
+    if spec["kind"] == syn.PSI_HINGE_SDF_3D:
+        return o.psi_batch_hinge_sdf3d(spec["params"], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
     if spec["kind"] == syn.PSI_HINGE_SDF_2D:
         return o.psi_batch_hinge_sdf2d(spec["params"], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
     if spec["kind"] == syn.PSI_RANGE_1D:
@@ -31,10 +35,15 @@ def oracle_psi_point(spec):
 
 
 def make_chain(name):
-    ch = syn.make_planar_chain() if name == "planar" else syn.make_chain(name)
+    if name == "planar":
+        ch = syn.make_planar_chain()
+    elif name in ("quad2d", "pr3d"):
+        ch = syn.make_obstacle_chain(name)
+    else:
+        ch = syn.make_chain(name)
     for spec in ch["specs"]:
         spec["psi_batch"] = oracle_psi_batch(spec)
-        if spec["kind"] != syn.PSI_HINGE_SDF_2D:
+        if spec["kind"] < syn.PSI_HINGE_SDF_2D:
             spec["psi_point"] = oracle_psi_point(spec)
 
     def oracle_sets():

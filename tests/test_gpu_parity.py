@@ -262,6 +262,64 @@ def test_mixed_linear_nonlinear_graph_without_quadrature_for_priors():
     ctx.close()
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("kind,d,p", [("body", 3, 4), ("body", 6, 3), ("body", 4, 3), ("sdf3d", 3, 4), ("sdf3d", 6, 3), ("sdf3d", 5, 3)])
+def test_moments_hinge_body_and_3d_vs_oracle(kind, d, p, variant):
+    """Planar quadrotor body (5 check points, slope 5; helpers/CudaOperation.h:565-606) and the 3-D point robot on a
+    trilinear field (:133-322, 650-683): register policies (d = 3, 6) and the generic kernel (other d)."""
+    rng = np.random.default_rng(500 + d + (0 if kind == "body" else 50))
+    K = 5
+    if kind == "body":
+        origin, cell = (-6.0, -5.0), 0.1
+        field = syn.circle_sdf(origin, cell, 101, 121, [(0.0, 2.2), (-1.0, -3.0)], [1.2, 0.9])
+        params = np.column_stack([rng.uniform(5, 20, K), rng.uniform(0.2, 0.8, K), rng.uniform(0.1, 0.5, K),
+                                  np.full(K, 5.0), np.full(K, 5.0), rng.uniform(0.8, 2.0, K)])
+        ctx, sid = single_set_ctx(api.PSI_HINGE_SDF_2D_BODY, d, d, p, K, params)
+        ctx.factors_set_sdf2d(sid, origin, cell, field)
+        psi = o.psi_batch_hinge_sdf2d_body(params, origin, cell, field)
+        poses = [(0.0, 1.9, 0.3), (0.1, 0.2, 1.2), (-1.0, -2.0, -0.7), (3.0, 3.0, 2.5), (7.5, 0.0, 0.0)]
+    else:
+        origin, cell = (-4.0, -3.0, -2.0), 0.2
+        field = syn.sphere_sdf3d(origin, cell, 31, 41, 21, [(0.0, 1.4, 0.3), (-0.5, -1.8, 0.0)], [1.0, 0.8])
+        params = np.column_stack([rng.uniform(5, 20, K), rng.uniform(0.2, 0.8, K), rng.uniform(0.1, 0.5, K)])
+        ctx, sid = single_set_ctx(api.PSI_HINGE_SDF_3D, d, d, p, K, params)
+        with pytest.raises(api.GviError):
+            ctx.factors_set_sdf2d(sid, origin[:2], cell, field[:, :, 0])             # wrong grid call for this kind
+        ctx.factors_set_sdf3d(sid, origin, cell, field)
+        psi = o.psi_batch_hinge_sdf3d(params, origin, cell, field)
+        poses = [(0.0, 1.3, 0.3), (0.1, 0.2, 0.1), (-0.5, -1.0, 0.2), (3.0, 2.0, 1.5), (5.5, 0.0, -3.0)]
+    reg = d in (3, 6)
+    ctx.set_variant(variant if reg else 0)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.2)
+    mu[:, :3] = poses
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == (variant if reg else 1)
+    Z, w = o.nwspgr(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, psi, np.ones(K))
+    assert np.abs(r["E_phi"]).max() > 0.05
+    assert rel(Ephi, r["E_phi"]) < TIGHT and rel(Vdmu, r["Vdmu"]) < TIGHT and rel(Vddmu, r["Vddmu"]) < TIGHT * 10
+    assert rel(ctx.costs(sid, mu, Sigma), r["cost"]) < TIGHT
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["quad2d", "pr3d"])
+def test_obstacle_chains_vs_oracle(name):
+    """n = 6 planning graphs with the quadrotor-body / 3-D obstacle factors: NGD iterations against the oracle."""
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    chain = o.ChainNGD(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"])
+    for it in range(4):
+        r = ctx.ngd_step(0.55, 10)
+        ok, cost, ntr = chain.step()
+        assert r["accepted"] == ok and r["ntrials"] == ntr
+        assert np.isclose(r["new_cost"], cost, rtol=1e-9)
+    st = ctx.ngd_get_state()
+    assert rel(st["mu"], chain.mu) < RTOL / 10 and rel(st["D"], chain.D) < RTOL / 10 and rel(st["SigD"], chain.SigD) < RTOL / 10
+    assert ctx.ngd_factor_costs(ids[1]).max() > 0
+    ctx.close()
+
+
 def test_k9_golden_fixture(golden_dir):
     """Committed K9 vectors: device GH moments == oracle GH == closed form (ngd/NGDFactorizedLinear.h:93-129)."""
     g = np.load(os.path.join(golden_dir, "k9_moments.npz"))
