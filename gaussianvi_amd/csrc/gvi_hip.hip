@@ -133,6 +133,14 @@ struct gvi_ctx {
   int cost_chunk_mult = 8;
   int scost_f = 2;          // factors per wave of the cost kernel (2 or 4)  // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   hipEvent_t fork = nullptr;
+  // side-stream solve: the chain solve of the gradients runs beside the trial factorisation (independent given Vddmu)
+  bool side_solve = true;             // GVI_SIDE_SOLVE=0 keeps everything on one stream
+  hipStream_t side = nullptr;
+  hipEvent_t ev_grad = nullptr, ev_solve[2] = {nullptr, nullptr};
+  bool solve_pending[2] = {false, false};
+  DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
+  hipStream_t chain_stream = nullptr; // stream of the chain launches being queued (null: ctx->stream)
+  int chain_ws = 0;
   double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
   double seq = 0.0;
   double* host_slot_dev = nullptr;
@@ -172,6 +180,7 @@ gvi_status d2h(gvi_ctx* c, void* dst, const void* src, size_t bytes) {
 }
 gvi_status sync(gvi_ctx* c) {
   HIPCK(c, hipStreamSynchronize(c->stream));
+  if (c->side) HIPCK(c, hipStreamSynchronize(c->side));
   return GVI_OK;
 }
 
@@ -536,15 +545,17 @@ gvi_status ensure_set_buffers(gvi_ctx* c, FactorSet& s) {
 gvi_status ensure_chain_ws(gvi_ctx* c, BcrWs& w) {
   const size_t T = c->T, nn = nn_(c), n = c->n;
   const size_t words = 9 * T * nn + 4 * T * n + T;
-  HIPCK(c, c->Wbuf.ensure(words * 8));
-  HIPCK(c, c->Ibuf.ensure(T * sizeof(int)));
-  double* p = c->Wbuf.d();
+  DevMem& Wb = c->chain_ws ? c->Wbuf2 : c->Wbuf;
+  DevMem& Ib = c->chain_ws ? c->Ibuf2 : c->Ibuf;
+  HIPCK(c, Wb.ensure(words * 8));
+  HIPCK(c, Ib.ensure(T * sizeof(int)));
+  double* p = Wb.d();
   w.E = p; p += T * nn;  w.GA = p; p += T * nn; w.GB = p; p += T * nn; w.CL = p; p += T * nn;
   w.CR = p; p += T * nn; w.NU = p; p += T * nn; w.SL = p; p += T * nn; w.SR = p; p += T * nn;
   w.Deff = p; p += T * nn;
   w.v = p; p += T * n;   w.yL = p; p += T * n;  w.yR = p; p += T * n; w.yeff = p; p += T * n;
   w.logp = p;
-  w.bad = (int*)c->Ibuf.p;
+  w.bad = (int*)Ib.p;
   return GVI_OK;
 }
 
@@ -651,13 +662,14 @@ gvi_status launch_seg(gvi_ctx* c, SegArgs a, const SegPlan& pl) {
     attr = true;
   }
   const bool rhs = a.rhs != nullptr;
+  hipStream_t st = c->chain_stream ? c->chain_stream : c->stream;
   for (const SegPass& ps : pl.passes) {
     a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.prev0 = ps.prev0; a.top = ps.top;
     const size_t lds = seg_fwd_lds_doubles(N, ps.S, rhs, ps.top != 0, pl.threads / 64) * 8;
     if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: LDS budget");
     const int stride = ps.S << ps.level0;
     const int blocks = ps.top ? 1 : (c->T + stride - 1) / stride;
-    hipLaunchKernelGGL((bcr_seg_forward_kernel<PIVOT, N>), dim3(blocks), dim3(pl.threads), lds, c->stream, a);
+    hipLaunchKernelGGL((bcr_seg_forward_kernel<PIVOT, N>), dim3(blocks), dim3(pl.threads), lds, st, a);
   }
   if (rhs || a.need_E) {
     for (int i = (int)pl.passes.size() - 2; i >= 0; --i) {
@@ -666,7 +678,7 @@ gvi_status launch_seg(gvi_ctx* c, SegArgs a, const SegPlan& pl) {
       const size_t lds = seg_bwd_lds_doubles(N, ps.S, rhs) * 8;
       const int stride = ps.S << ps.level0;
       hipLaunchKernelGGL((bcr_seg_backward_kernel<N>), dim3((c->T + stride - 1) / stride), dim3(pl.threads), lds,
-                         c->stream, a);
+                         st, a);
     }
   }
   HIPCK(c, hipGetLastError());
@@ -797,6 +809,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
+  if (const char* w = getenv("GVI_SIDE_SOLVE")) c->side_solve = atoi(w) != 0;
   if (const char* w = getenv("GVI_SCOST_F")) c->scost_f = atoi(w) == 4 ? 4 : 2;
   if (const char* w = getenv("GVI_COST_CHUNK_MULT")) c->cost_chunk_mult = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
@@ -818,6 +831,10 @@ gvi_status gvi_ctx_destroy(gvi_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->sets.clear();
   if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+  if (ctx->side) (void)hipStreamSynchronize(ctx->side);
+  if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
+  for (auto& e : ctx->ev_solve) if (e) (void)hipEventDestroy(e);
+  if (ctx->side) (void)hipStreamDestroy(ctx->side);
   if (ctx->host_slot) (void)hipHostFree(ctx->host_slot);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1379,14 +1396,21 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full) {
 }
 
 // marginals + log-det of Lam[i], then gather every set's (mu_k, Sigma_k) into slot i (one launch)
-static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
+static gvi_status ngd_refresh_factor(gvi_ctx* ctx, int i) {
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, nn = nn_(ctx);
   double* D = g.Lam[i].d();
   double* U = D + T * nn;
   double* sD = g.Sig[i].d();
   double* sU = sD + T * nn;
-  GVICK(run_bt_factor(ctx, D, U, sD, sU, g.hld[i].d()));
+  return run_bt_factor(ctx, D, U, sD, sU, g.hld[i].d());
+}
+
+static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i) {
+  NgdState& g = ctx->ngd;
+  const size_t T = ctx->T, nn = nn_(ctx);
+  double* sD = g.Sig[i].d();
+  double* sU = sD + T * nn;
   if (ctx->sets.empty()) return GVI_OK;
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
   int64_t maxwork = 0;
@@ -1398,6 +1422,11 @@ static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
                      ctx->stream, make_set_list(ctx, i), ctx->n, g.mu[i].d(), sD, sU);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
+}
+
+static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
+  GVICK(ngd_refresh_factor(ctx, i));
+  return ngd_refresh_gather(ctx, i);
 }
 
 // sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0].  Everything stays on ONE stream: side streams
@@ -1554,7 +1583,34 @@ static gvi_status ngd_grad_finish(gvi_ctx* ctx, int gb) {
   double* eg = g.exch0[gb].d();
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
+  if (ctx->side_solve && seg_supported(ctx->n) && ctx->bcr_variant != 1) {
+    // the solve only feeds mu_trial; the trial precision and its factorisation need Vddmu alone, so the solve goes
+    // to the side stream and ngd_join_solve() waits for it right before the first reader of dmu
+    if (!ctx->side) {
+      HIPCK(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+      HIPCK(ctx, hipEventCreateWithFlags(&ctx->ev_grad, hipEventDisableTiming));
+      for (auto& e : ctx->ev_solve) HIPCK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIPCK(ctx, hipEventRecord(ctx->ev_grad, ctx->stream));
+    HIPCK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_grad, 0));
+    ctx->chain_stream = ctx->side; ctx->chain_ws = 1;
+    const gvi_status st = run_bt_solve(ctx, eD, eU, eg, -1.0, g.dmu2[gb].d());
+    ctx->chain_stream = nullptr; ctx->chain_ws = 0;
+    GVICK(st);
+    HIPCK(ctx, hipEventRecord(ctx->ev_solve[gb], ctx->side));
+    ctx->solve_pending[gb] = true;
+    return GVI_OK;
+  }
   return run_bt_solve(ctx, eD, eU, eg, -1.0, g.dmu2[gb].d());
+}
+
+// main stream waits for a side-stream solve of gradient buffer gb (no-op when none is pending)
+static gvi_status ngd_join_solve(gvi_ctx* ctx, int gb) {
+  if (ctx->solve_pending[gb]) {
+    HIPCK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_solve[gb], 0));
+    ctx->solve_pending[gb] = false;
+  }
+  return GVI_OK;
 }
 
 gvi_status gvi_ngd_gradients_local(gvi_ctx* ctx) {
@@ -1584,12 +1640,24 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
   if (!(g.grad_valid && g.grad_slot == g.cur)) return fail(ctx, GVI_ERR_STATE, "call gvi_ngd_gradients first");
   const size_t Tn = (size_t)ctx->T * ctx->n, bt = bt_count(ctx);
   const int c = g.cur, t = 1 - c;
-  hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn,
-                     (int64_t)bt, step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn,
-                     g.mu[t].d(), g.Lam[t].d());
-  HIPCK(ctx, hipGetLastError());
   g.cost_valid[t] = false;
-  GVICK(ngd_refresh(ctx, t));
+  if (ctx->solve_pending[g.gcur]) {
+    // precision part first (needs no dmu), factorise, then join the side-stream solve and form mu_trial
+    hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)0, (int64_t)bt,
+                       step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
+    GVICK(ngd_refresh_factor(ctx, t));
+    GVICK(ngd_join_solve(ctx, g.gcur));
+    hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn, (int64_t)0,
+                       step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
+    HIPCK(ctx, hipGetLastError());
+    GVICK(ngd_refresh_gather(ctx, t));
+  } else {
+    hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn,
+                       (int64_t)bt, step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn,
+                       g.mu[t].d(), g.Lam[t].d());
+    HIPCK(ctx, hipGetLastError());
+    GVICK(ngd_refresh(ctx, t));
+  }
   g.have_trial = true;
   return GVI_OK;
 }
@@ -1712,6 +1780,7 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, n = ctx->n, nn = n * n, bt = bt_count(ctx);
   if (!(g.grad_valid)) return fail(ctx, GVI_ERR_STATE, "no gradients computed for the current proposal");
+  GVICK(ngd_join_solve(ctx, g.gcur));
   if (dmu) GVICK(d2h(ctx, dmu, g.dmu2[g.gcur].p, T * n * 8));
   if (gq) GVICK(d2h(ctx, gq, g.exch0[g.gcur].p, T * n * 8));
   std::vector<double> V, L;

@@ -629,6 +629,27 @@ def test_step_scheduling_modes_give_identical_iterates(speculate, fuse):
     assert rel(s1["mu"], s0["mu"]) < 1e-10 and rel(s1["D"], s0["D"]) < 1e-10
 
 
+def test_side_stream_solve_gives_identical_iterates(monkeypatch):
+    """GVI_SIDE_SOLVE (default on): the gradient solve runs on a side stream beside the trial factorisation and is
+    joined before mu_trial is formed.  Same arithmetic, so the iterates are bit-identical to the one-stream order,
+    including rejected trials (huge base step) where the speculative buffer is dropped."""
+    ch = make_chain("c2")
+    out = []
+    for side in ("0", "1"):
+        monkeypatch.setenv("GVI_SIDE_SOLVE", side)
+        ctx, ids = api.context_for_chain(ch)
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        log = [ctx.ngd_step(40.0 if it == 2 else 0.55, 10) for it in range(6)]
+        g = ctx.ngd_get_gradients() if hasattr(ctx, "ngd_get_gradients") else None
+        out.append((log, ctx.ngd_get_state()))
+        ctx.close()
+    (l0, s0), (l1, s1) = out
+    assert any(r["ntrials"] > 1 for r in l0)
+    for a, b in zip(l0, l1):
+        assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"] and a["new_cost"] == b["new_cost"]
+    assert np.array_equal(s0["mu"], s1["mu"]) and np.array_equal(s0["D"], s1["D"])
+
+
 def test_linesearch_rejects_nan_and_backtracks():
     """A huge base step makes the trial precision indefinite: log-det NaN -> rejected -> backtrack
     (gvibase/GVI-GH-impl.h:92-117 with the NaN rule of section 3.1)."""
