@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 register (LDS operands), 3 operand-resident, 5 register (SGPR operands)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default, BASELINE configs[3]): the same 1024-factor chain over N GPUs; "
+                         "weak: 1024 factors per GPU, i.e. a (1024 N)-factor chain (config c3xN)")
     ap.add_argument("--restart-every", type=int, default=16,
                     help="re-initialise (mu0, precision0) inside the timed region every R steps so that every step is a "
                          "descending iteration with one accepted trial (the chain converges after ~35 steps)")
@@ -103,6 +106,8 @@ def main():
     from gaussianvi_amd import api, synthetic
     from gaussianvi_amd.dist import HipEngine, ShardedNGD, shard_chain
 
+    if args.scaling == "weak" and world > 1 and args.config == "c3":
+        args.config = f"c3x{world}"
     chain = synthetic.make_chain(args.config)
     local = shard_chain(chain, rank, world)
     ctx, ids = api.context_for_chain(local, device=local_rank)
@@ -194,9 +199,9 @@ def main():
             "value": total_evals / elapsed, "unit": "psi-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "c3: 1024-factor LTV-prior chain, d=12, sparse-GH p=5 (N=17217), T=1025 n=6, "
-                                   "+1025 unary d=6 p=5 factors; one step = one device-resident NGD iteration "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {chain['T'] - 1}-factor LTV-prior chain, d=12, sparse-GH p=5 (N=17217), "
+                                   f"T={chain['T']} n=6, +{chain['T']} unary d=6 p=5 factors; one step = one device-resident NGD iteration "
                                    f"(state re-initialised inside the timed region every {args.restart_every} steps)",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": f"factors/{world} contiguous, all-reduce [g|D|U] + trial cost (RCCL)" if world > 1 else "none",

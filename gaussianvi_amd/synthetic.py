@@ -74,6 +74,8 @@ def make_chain(name: str):
     """Returns dict(T, n, specs, mu0, D0, U0).  specs[0]: the T-1 binary prior factors (d = 2n,
     QUAD_PRIOR); specs[1]: T unary measurement factors (d = n, FIXED_PRIOR), the first and the last
     being the strong end anchors."""
+    if name not in CONFIGS and name.startswith("c3x") and name[3:].isdigit():
+        CONFIGS[name] = (3, 1024 * int(name[3:]) + 1, 6, 5, "ltv")      # weak-scaling family: 1024 factors per GPU
     cfg, T, n, p, kind = CONFIGS[name][:5]
     p_unary = CONFIGS[name][5] if len(CONFIGS[name]) > 5 else p
     rng = np.random.default_rng(0x5EED + cfg)
