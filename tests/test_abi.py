@@ -61,7 +61,7 @@ def test_generator_matches_golden_tables_bit_exact(lib, golden_dir, d, p):
 
 def test_generator_12_5_headline_table(lib, golden_dir):
     import sys
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_golden import idx_checksum
     g = np.load(os.path.join(golden_dir, "spgh_tables.npz"))
     Z, w, idx = api.spgh_nodes(12, 5)

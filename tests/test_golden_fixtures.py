@@ -1,4 +1,4 @@
-"""The committed golden fixtures (tests/golden/*.npz, made by tools/make_golden.py) still match
+"""The committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py) still match
 the oracle, and the K9 fixtures match the reference's closed form.  CPU only."""
 import os
 
