@@ -50,5 +50,7 @@ int main(int argc, char** argv) {
   SparseGaussHermite<> gh(gh_degree, 1, opt.mean(), MatrixXd::Constant(1, 1, opt.covariance().coeff(0, 0)));
   MatrixXd e = gh.Integrate([](const VectorXd& x) { return MatrixXd::Constant(1, 1, cost_function(x, NoneType{})); });
   std::printf("E[psi] at the final proposal via the host-callback route: %.15g\n", e(0, 0));
+  // the reference's device-variant timing hook (gvibase/GVI-GH-Cuda-impl.h:463-527)
+  opt.time_test();
   return 0;
 }

@@ -20,6 +20,8 @@
 //     device-resident iteration (gvi_ngd_*), one launch sequence per pass for ALL factors.
 #pragma once
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -314,6 +316,30 @@ class GVIGH {
       for (size_t k = 0; k < c.size(); ++k) out(_sets[s].members[k]) = c[k];
     }
     return out;
+  }
+
+  // GVIGH::time_test of the reference's device variant (gvibase/GVI-GH-Cuda-impl.h:463-527): _niters + 1 timed
+  // evaluations of the factor-cost vector at the current proposal (marginals + one cost pass over every factor),
+  // the first discarded; same "% ..." lines.  Returns {average, min, max} in ms.
+  std::tuple<double, double, double> time_test(bool print = true) {
+    std::vector<double> times;
+    for (int i = 0; i < _niters + 1; ++i) {
+      // a fresh evaluation each round: re-setting the state drops the device-side cache of the cost
+      _dev->check(gvi_ngd_init(_dev->get(), _mu.data(), _D.data(), _U.data()));
+      const auto t0 = std::chrono::steady_clock::now();
+      (void)factor_cost_vector();
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (i != 0) times.push_back(ms);
+    }
+    double avg = 0.0;
+    for (double v : times) avg += v;
+    avg /= (double)times.size();
+    const double mn = *std::min_element(times.begin(), times.end()), mx = *std::max_element(times.begin(), times.end());
+    if (print) {
+      std::printf("%% %zu\n", _vec_factors.size());
+      std::printf("%% GPU average: %g ms\n%% GPU min: %g ms\n%% GPU max: %g ms\n", avg, mn, mx);
+    }
+    return {avg, mn, mx};
   }
 
   // GVIGH::optimize with backtracking (gvibase/GVI-GH-impl.h:33-124)

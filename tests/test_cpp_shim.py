@@ -40,3 +40,6 @@ def test_1d_example_reproduces_reference_trace(tmp_path, golden_dir):
     line = [l for l in r.stdout.splitlines() if l.startswith("E[psi] at the final proposal")][0]
     e_host = float(line.split(":")[1])
     assert abs(e_host - 2.57) < 0.01
+    # time_test prints the reference's "% GPU average/min/max" lines and leaves the state untouched
+    avg = [l for l in r.stdout.splitlines() if l.startswith("% GPU average:")]
+    assert len(avg) == 1 and float(avg[0].split(":")[1].split()[0]) > 0
