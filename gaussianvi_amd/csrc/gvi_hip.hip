@@ -1374,7 +1374,7 @@ static gvi_status ngd_prep_all(gvi_ctx* ctx, int i) {
 }
 
 // epilogue of every set -- one launch (full: Vdmu / Vddmu / Ephi / cost; else cost only)
-static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full) {
+static EpiList make_epi_list(gvi_ctx* ctx, int full, int* dmax_out) {
   EpiList L;
   L.nsets = (int)ctx->sets.size();
   L.koff[0] = 0;
@@ -1389,6 +1389,13 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full) {
     L.koff[si + 1] = L.koff[si] + s.K;
     dmax = std::max(dmax, s.d);
   }
+  if (dmax_out) *dmax_out = dmax;
+  return L;
+}
+
+static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full) {
+  int dmax = 0;
+  const EpiList L = make_epi_list(ctx, full, &dmax);
   const size_t lds = (size_t)(npairs(dmax) + 2 * dmax * dmax) * 8;
   hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L);
   HIPCK(ctx, hipGetLastError());
@@ -1406,20 +1413,28 @@ static gvi_status ngd_refresh_factor(gvi_ctx* ctx, int i) {
   return run_bt_factor(ctx, D, U, sD, sU, g.hld[i].d());
 }
 
-static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i) {
+// mu_from / dmu / step: form mu[i] = mu_from + step dmu inside the gather launch (trial state); null: mu[i] is current
+static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i, const double* mu_from = nullptr, const double* dmu = nullptr,
+                                     double step = 0.0) {
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, nn = nn_(ctx);
+  const int64_t nmu = (int64_t)T * ctx->n;
   double* sD = g.Sig[i].d();
   double* sU = sD + T * nn;
-  if (ctx->sets.empty()) return GVI_OK;
+  if (ctx->sets.empty()) {
+    if (dmu) hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((nmu + 255) / 256)), dim3(256), 0, ctx->stream, nmu, (int64_t)0, step,
+                                mu_from, dmu, (const double*)nullptr, (const double*)nullptr, g.mu[i].d(), (double*)nullptr);
+    return GVI_OK;
+  }
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
-  int64_t maxwork = 0;
+  int64_t maxwork = dmu ? nmu : 0;
   for (auto& s : ctx->sets) {
     if (s->prep_slot == i) s->prep_slot = -1;
     maxwork = std::max<int64_t>(maxwork, (int64_t)s->K * (s->d + s->d * s->d));
   }
-  hipLaunchKernelGGL(gather_all_kernel, dim3((unsigned)((maxwork + 255) / 256), (unsigned)ctx->sets.size()), dim3(256), 0,
-                     ctx->stream, make_set_list(ctx, i), ctx->n, g.mu[i].d(), sD, sU);
+  hipLaunchKernelGGL(gather_all_kernel, dim3((unsigned)((maxwork + 255) / 256), (unsigned)ctx->sets.size() + (dmu ? 1u : 0u)),
+                     dim3(256), 0, ctx->stream, make_set_list(ctx, i), ctx->n, dmu ? mu_from : g.mu[i].d(), sD, sU, dmu, step,
+                     g.mu[i].d(), nmu);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -1432,14 +1447,24 @@ static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
 // sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0].  Everything stays on ONE stream: side streams
 // share the hardware queue on this part and every cross-stream dependency costs a 6-30 us barrier
 // packet (profiles/r01_d_*); the small sets ride along inside the fused prep / epilogue launches.
-static gvi_status ngd_cost_local(gvi_ctx* ctx, int i) {
+// publish = true (single-process iteration): the same launch also writes {cost, half log-det, sequence} to the
+// host-mapped slot, so no separate publish_kernel follows
+static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
   NgdState& g = ctx->ngd;
-  if (ctx->sets.empty()) { HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream)); return GVI_OK; }
+  if (ctx->sets.empty()) {
+    HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
+    if (publish) {
+      ctx->seq += 1.0;
+      hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev, ctx->seq);
+    }
+    return GVI_OK;
+  }
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
   GVICK(ngd_prep_all(ctx, i));
   for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0));
-  GVICK(ngd_epilogue_all(ctx, 0));
-  hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, i), g.exch1.d());
+  if (publish) ctx->seq += 1.0;
+  hipLaunchKernelGGL(cost_tail_kernel, dim3(1), dim3(256), 0, ctx->stream, make_epi_list(ctx, 0, nullptr), g.exch1.d(),
+                     g.hld[i].d(), publish ? ctx->host_slot_dev : nullptr, ctx->seq);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -1647,10 +1672,7 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
                        step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
     GVICK(ngd_refresh_factor(ctx, t));
     GVICK(ngd_join_solve(ctx, g.gcur));
-    hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn, (int64_t)0,
-                       step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
-    HIPCK(ctx, hipGetLastError());
-    GVICK(ngd_refresh_gather(ctx, t));
+    GVICK(ngd_refresh_gather(ctx, t, g.mu[c].d(), g.dmu2[g.gcur].d(), step));     // forms mu_trial in the same launch
   } else {
     hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn,
                        (int64_t)bt, step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn,
@@ -1717,8 +1739,7 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
       GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
       GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
     } else {
-      GVICK(ngd_cost_local(ctx, t));
-      GVICK(ngd_cost_publish(ctx, t));
+      GVICK(ngd_cost_local(ctx, t, true));          // cost tail publishes in the same launch
       // Speculation: the first trial is accepted in the common case, and then the next iteration starts
       // with the gradients at exactly this trial state.  Queue them BEHIND the publish, into the other
       // gradient buffer, so the device never idles while the host reads the cost and decides.  A rejected

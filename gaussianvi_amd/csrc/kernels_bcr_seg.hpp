@@ -96,23 +96,30 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
   int bad = 0;
 #pragma unroll
   for (int p = 0; p < N; ++p) {
-    double ap[N];
-#pragma unroll
-    for (int r = 0; r < N; ++r) ap[r] = readlane_f64(col[r], p);
     if (PIVOT) {
+      // threshold partial pivoting, searched inside lane p (the pivot column lives in that lane's registers):
+      // rows are swapped only when the natural pivot is more than 8x smaller than the column maximum -- for the
+      // near-SPD blocks of an NGD iteration that is rare, so the common path is one wave-uniform branch
+      double best = fabs(col[p]);
       int rs = p;
-      double best = fabs(ap[p]);
-#pragma unroll
-      for (int r = p + 1; r < N; ++r)
-        if (fabs(ap[r]) > best) { best = fabs(ap[r]); rs = r; }
 #pragma unroll
       for (int r = p + 1; r < N; ++r) {
-        if (r == rs) {
-          const double t = col[p]; col[p] = col[r]; col[r] = t;
-          const double u = ap[p]; ap[p] = ap[r]; ap[r] = u;
+        const bool gt = fabs(col[r]) > best;
+        best = gt ? fabs(col[r]) : best;
+        rs = gt ? r : rs;
+      }
+      rs = fabs(col[p]) * 8.0 >= best ? p : rs;
+      rs = __builtin_amdgcn_readlane(rs, p);
+      if (rs != p) {
+#pragma unroll
+        for (int r = p + 1; r < N; ++r) {
+          if (r == rs) { const double t = col[p]; col[p] = col[r]; col[r] = t; }
         }
       }
     }
+    double ap[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) ap[r] = readlane_f64(col[r], p);
     const double piv = ap[p];
     if (!(piv > 0.0)) bad = 1;
     pivs[p] = piv;
@@ -125,13 +132,20 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
       if (r != p) col[r] = fma(-ap[r], f, col[r]);
     col[p] = f;
   }
-  double lg = 0.0;
+  if (a.hld && lane == 0) {
+    // log-pivots only feed the log-det (factor calls).  The pivots are wave-uniform: keep their product as
+    // (mantissa product, exponent sum) -- two instructions per pivot -- and take ONE log per node in the final
+    // reduction instead of an fp64 log + a 6-step shuffle reduction on the critical path of every level.
+    double mp = 1.0;
+    int es = 0;
 #pragma unroll
-  for (int p = 0; p < N; ++p) lg = (lane == p) ? pivs[p] : lg;
-  lg = lane < N ? log(lg) : 0.0;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
-  if (lane == 0) { a.w.logp[x] = lg; a.w.bad[x] = bad; }
+    for (int p = 0; p < N; ++p) {
+      mp *= __builtin_amdgcn_frexp_mant(pivs[p]);
+      es += __builtin_amdgcn_frexp_exp(pivs[p]);
+    }
+    a.w.logp[x] = mp;                    // in [2^-N, 1) for positive pivots
+    a.w.bad[x] = es * 2 + bad;           // exponent sum and the non-positive-pivot flag
+  }
   // ---- park the reduced tile [I | E | GA | GB | v] in LDS, then finish element-wise on all lanes ----
   if (lane < NC) {
 #pragma unroll
@@ -358,7 +372,11 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
     int* redb = (int*)(red + 64);
     double s = 0.0;
     int bflag = 0;
-    for (int t = tid; t < T; t += blockDim.x) { s += a.w.logp[t]; bflag |= a.w.bad[t]; }
+    for (int t = tid; t < T; t += blockDim.x) {
+      const int eb = a.w.bad[t];
+      s += log(a.w.logp[t]) + (double)(eb >> 1) * 0.6931471805599453094;
+      bflag |= eb & 1;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); bflag |= __shfl_xor(bflag, o); }
     if (lane == 0) { red[wave] = s; redb[wave] = bflag; }

@@ -676,16 +676,28 @@ __global__ __launch_bounds__(256) void bt_scatter_all_kernel(SetList L, int T, i
   else if (t < T - 1) U[(size_t)t * nn + (e - n - nn)] = acc;
 }
 
-// gather (mu_k, Sigma_k) for ALL sets: blockIdx.y = set
+// gather (mu_k, Sigma_k) for ALL sets: blockIdx.y = set.  With dmu != null the trial mean mu + step dmu is formed on
+// the fly (same arithmetic as trial_kernel) and the extra slice blockIdx.y == nsets writes it to mu_out [nmu], so the
+// separate mu part of trial_kernel disappears from the iteration.
 __global__ __launch_bounds__(256) void gather_all_kernel(SetList L, int n, const double* __restrict__ mu,
                                                          const double* __restrict__ SigD,
-                                                         const double* __restrict__ SigU) {
+                                                         const double* __restrict__ SigU,
+                                                         const double* __restrict__ dmu, double step,
+                                                         double* __restrict__ mu_out, int64_t nmu) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.y == L.nsets) {
+    if (gid < nmu) mu_out[gid] = mu[gid] + step * dmu[gid];
+    return;
+  }
   const SetDesc& a = L.s[blockIdx.y];
   const int d = a.d, per = d + d * d, nn = n * n;
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)a.K * per) return;
   const int k = (int)(gid / per), e = (int)(gid % per), s = a.start[k];
-  if (e < d) { a.mu_k[(size_t)k * d + e] = mu[(size_t)s * n + e]; return; }
+  if (e < d) {
+    const size_t j = (size_t)s * n + e;
+    a.mu_k[(size_t)k * d + e] = dmu ? mu[j] + step * dmu[j] : mu[j];
+    return;
+  }
   const int r = (e - d) / d, c = (e - d) % d;
   double v;
   if (r < n && c < n) v = SigD[(size_t)s * nn + r * n + c];

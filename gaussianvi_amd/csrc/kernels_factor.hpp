@@ -1318,6 +1318,45 @@ struct EpiList {
   EpiArgs e[MAX_FSETS];
 };
 
+// Tail of a cost pass in ONE launch: per-factor cost = (ordered chunk sum of m0) / T_k for every set, the ordered
+// sum over all factors (same order as cost_sum_all_kernel: thread-strided partial sums, then a fixed 256-leaf tree
+// per set) into acc[0], and -- single-process iteration only -- the publish into host-mapped memory
+// ({cost_sum, half_logdet, sequence}).  Replaces epilogue_all_kernel(full = 0) -> cost_sum_all_kernel -> publish_kernel.
+__global__ __launch_bounds__(256) void cost_tail_kernel(EpiList L, double* acc, const double* half_logdet, double* host_out,
+                                                        double seq) {
+  __shared__ double sh[256];
+  double total = 0.0;
+  for (int si = 0; si < L.nsets; ++si) {
+    const EpiArgs& e = L.e[si];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < e.f.K; k += 256) {
+      const double* P = e.partial + (size_t)k * e.nchunk;
+      double m0 = 0.0;
+      for (int c = 0; c < e.nchunk; ++c) m0 += P[c];               // fixed order: deterministic
+      const double ck = m0 / e.f.temperature[k];
+      e.cost[k] = ck;
+      s += ck;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+      __syncthreads();
+    }
+    total += sh[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    acc[0] = total;
+    if (host_out) {
+      host_out[0] = total;
+      host_out[1] = half_logdet[0];
+      __threadfence_system();
+      host_out[2] = seq;               // the host spins on this word: payload first, then the sequence
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L) {
   extern __shared__ double sm[];
   int si = 0;
