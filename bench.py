@@ -187,6 +187,16 @@ def main():
         alg_bytes = K0 * N0 * (d0 + 1) * 8                      # (d+1) s bytes per eval
         n_half = d0 // 2
         f_alg = 2 * (d0 * d0 + 2 * n_half * n_half + 2 * n_half + 1 + d0 + d0 * (d0 + 1) // 2)
+        flop_launch, evals_launch = f_alg * K0 * N0, K0 * N0
+        fused_pair = geo["variant"] == 5 and len(ctx.sets) == 2
+        if fused_pair:
+            # the timed launch also carries the unary set (d = n, psi = (x-mu0)^T Kinv (x-mu0): d^2 + d for psi):
+            # SURVEY 8(d) formula with the unary residual count
+            K1, d1, p1, N1 = ctx.sets[1]
+            f_alg1 = 2 * (d1 * d1 + d1 * d1 + d1 + 1 + d1 + d1 * (d1 + 1) // 2)
+            flop_launch += f_alg1 * K1 * N1
+            evals_launch += K1 * N1
+            alg_bytes += K1 * N1 * (d1 + 1) * 8
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(tpath):
@@ -211,19 +221,20 @@ def main():
             "trials_per_step": float(np.mean([r["ntrials"] for r in log])),
             "final_cost": log[-1]["new_cost"],
             "fused_trial_mode": fused,
-            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": K0 * N0 / km},
+            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": evals_launch / km,
+                               "launch": "prior set (1024 x 17217) + unary set (1025 x 1433) in one launch" if fused_pair else "prior set"},
             # The dominant kernel streams only the (d,p) table, which is L2-resident (profiles/r01_traffic.json:
             # HBM traffic ~0.5 % of the algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.
             # The schema's compute label is "mfma"; fp64 MFMA and fp64 VALU share one pipe on MI355X and the
             # VALU form is the faster one (profiles/r01_fp64_pipes.txt), so the kernel uses v_fma_f64.
-            "roofline": {"bound": "mfma", "achieved": f_alg * K0 * N0 / km / 1e12, "peak": FP64_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": f_alg * K0 * N0 / km / FP64_PEAK, "traffic": traffic,
-                         "kernel": {0: "moments_sreg_kernel<12, 6, full>", 5: "moments_sreg_kernel<12, 6, full>",
+            "roofline": {"bound": "mfma", "achieved": flop_launch / km / 1e12, "peak": FP64_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": flop_launch / km / FP64_PEAK, "traffic": traffic,
+                         "kernel": "moments_sreg_pair_kernel<12, 6, 6, 6, full>" if fused_pair else {0: "moments_sreg_kernel<12, 6, full>", 5: "moments_sreg_kernel<12, 6, full>",
                                     2: "moments_reg_kernel<12, PsiQuad<12,6>, full>", 3: "moments_wide_kernel<12, PsiQuad<12,6>, full>",
                                     4: "moments_tile_kernel<12, PsiQuad<12,6>, full>"}.get(args.variant, "moments_generic_kernel")
-                                   if geo["variant"] == 2 else "moments_generic_kernel",
+                                   if geo["variant"] in (2, 5) else "moments_generic_kernel",
                          "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": 188,
-                         "executed_tflops": 2 * 188 * K0 * N0 / km / 1e12,
+                         "executed_tflops": 2 * 188 * K0 * N0 / km / 1e12,   # prior set only (unary: 1.5e6 of 19.1e6 evaluations)
                          "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "
                                         "Measured on this box (tools/ubench/fp64_pipes.hip): 70 TF v_fma_f64, 48 TF v_mfma_f64_16x16x4",
                          "hbm_algorithmic": {"bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / km / 1e9,

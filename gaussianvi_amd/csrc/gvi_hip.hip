@@ -65,6 +65,7 @@ struct FactorSet {
   int64_t chunk = 0;
   bool use_reg = false;
   bool use_split = false;
+  bool fused_pair = false;            // last resident launch went out fused with the other set
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
@@ -132,6 +133,10 @@ struct gvi_ctx {
   bool no_scost = false;    // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
   int cost_chunk_mult = 8;
   int scost_f = 2;          // factors per wave of the cost kernel (2 or 4)  // cost pass of the F-factor kernel: chunks per factor relative to the full pass
+  // run_moments in planning mode: the launch that WOULD be issued is recorded instead (pair fusion of two sets)
+  struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; };
+  Deferred* defer = nullptr;
+  bool pair_fuse = true;              // GVI_NO_PAIR=1: one launch per set
   hipEvent_t fork = nullptr;
   // side-stream solve: the chain solve of the gradients runs beside the trial factorisation (independent given Vddmu)
   bool side_solve = true;             // GVI_SIDE_SOLVE=0 keeps everything on one stream
@@ -333,6 +338,12 @@ void launch_scost(const FactorSet& s, const MomArgs& a, int nchunk, hipStream_t 
 }
 void dispatch_scost(gvi_ctx* c, const FactorSet& s, const MomArgs& a, int nchunk, hipStream_t st);
 
+bool sreg_supported(const FactorSet& s) {
+  if (s.kind == KIND_QUAD_PRIOR) return s.d == 4 || s.d == 8 || s.d == 12;
+  if (s.kind == KIND_FIXED_PRIOR) return s.d == 6 || s.d == 12;
+  return false;
+}
+
 // scalar-operand register kernel (variant 5)
 bool dispatch_sreg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
   if (s.kind == KIND_QUAD_PRIOR) {
@@ -466,7 +477,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   a.f = s.dev(); a.mu = mu; a.psi_ext = psi_ext; a.partial = s.partial.d();
   a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full;
   const int which = full ? 0 : 1;
-  const bool prof = c->profile && (c->profile_all || (full && &s == c->sets[0].get()));
+  const bool prof = !c->defer && c->profile && (c->profile_all || (full && &s == c->sets[0].get()));
   if (prof) {
     for (int e = 0; e < 2; ++e)
       if (!s.ev[which][e]) HIPCK(c, hipEventCreate(&s.ev[which][e]));
@@ -490,8 +501,16 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     // auto: psi operands from SGPRs where instantiated (fastest for both passes); otherwise the operand-
     // resident kernel for the cost pass and the LDS-operand kernel for the full pass
     if ((c->variant == 5 || c->variant == 0) && !full && scost_supported(s) && !c->no_scost) {
+      if (c->defer && c->scost_f == 2) {
+        c->defer->kind = 1; c->defer->a = a; c->defer->grid = dim3((s.K + 7) / 8, s.nchunk); c->defer->d = s.d; c->defer->m = s.m;
+        return GVI_OK;
+      }
       dispatch_scost(c, s, a, s.nchunk, st);
       done = true;
+    }
+    if (!done && (c->variant == 5 || c->variant == 0) && c->defer && full && sreg_supported(s)) {
+      c->defer->kind = 0; c->defer->a = a; c->defer->grid = grid; c->defer->d = s.d; c->defer->m = s.m;
+      return GVI_OK;
     }
     if (!done && (c->variant == 5 || c->variant == 0)) done = dispatch_sreg(s, a, grid, st);
     if (!done && (c->variant == 3 || (c->variant == 0 && !full))) done = dispatch_wide(s, a, grid, st);
@@ -809,6 +828,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
+  if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
   if (const char* w = getenv("GVI_SIDE_SOLVE")) c->side_solve = atoi(w) != 0;
   if (const char* w = getenv("GVI_SCOST_F")) c->scost_f = atoi(w) == 4 ? 4 : 2;
   if (const char* w = getenv("GVI_COST_CHUNK_MULT")) c->cost_chunk_mult = std::max(1, atoi(w));
@@ -1447,6 +1467,8 @@ static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
 // sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0].  Everything stays on ONE stream: side streams
 // share the hardware queue on this part and every cross-stream dependency costs a 6-30 us barrier
 // packet (profiles/r01_d_*); the small sets ride along inside the fused prep / epilogue launches.
+static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full);
+
 // publish = true (single-process iteration): the same launch also writes {cost, half log-det, sequence} to the
 // host-mapped slot, so no separate publish_kernel follows
 static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
@@ -1461,9 +1483,9 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
   }
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
   GVICK(ngd_prep_all(ctx, i));
-  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[i].d(), nullptr, 0));
+  GVICK(ngd_moments_launch(ctx, i, 0));
   if (publish) ctx->seq += 1.0;
-  hipLaunchKernelGGL(cost_tail_kernel, dim3(1), dim3(256), 0, ctx->stream, make_epi_list(ctx, 0, nullptr), g.exch1.d(),
+  hipLaunchKernelGGL(cost_tail_kernel, dim3(1), dim3(1024), 0, ctx->stream, make_epi_list(ctx, 0, nullptr), g.exch1.d(),
                      g.hld[i].d(), publish ? ctx->host_slot_dev : nullptr, ctx->seq);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
@@ -1575,10 +1597,55 @@ gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs) {
 }
 
 // full moments pass of every set at NGD slot `slot` (per-factor Vdmu / Vddmu / E[psi] / cost)
+// All sets' moments (full = 1) or cost (full = 0) launches at slot.  The chain pattern -- set 0 binary priors (d = 2n,
+// m = n), set 1 unary factors (d = m = n), both on the SGPR-operand kernels -- goes out as ONE launch.
+static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
+  if (ctx->pair_fuse && ctx->sets.size() == 2 && !ctx->profile_all) {
+    FactorSet& s0 = *ctx->sets[0];
+    FactorSet& s1 = *ctx->sets[1];
+    const bool shape = s0.kind == KIND_QUAD_PRIOR && s1.kind == KIND_FIXED_PRIOR && s0.d == 12 && s1.d == 6 &&
+                       !s0.closed_form && !s1.closed_form;
+    if (shape) {
+      gvi_ctx::Deferred d0, d1;
+      ctx->defer = &d0;
+      gvi_status st = run_moments(ctx, s0, s0.mu_k[slot].d(), nullptr, full);
+      if (st == GVI_OK) { ctx->defer = &d1; st = run_moments(ctx, s1, s1.mu_k[slot].d(), nullptr, full); }
+      ctx->defer = nullptr;
+      GVICK(st);
+      const int want = full ? 0 : 1;
+      if (d0.kind == want && d1.kind == want) {
+        const int nb0 = (int)(d0.grid.x * d0.grid.y), nb1 = (int)(d1.grid.x * d1.grid.y);
+        const bool prof = ctx->profile && full;
+        if (prof) {
+          for (int e = 0; e < 2; ++e)
+            if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
+          HIPCK(ctx, hipEventRecord(s0.ev[0][0], ctx->stream));
+        }
+        if (full)
+          hipLaunchKernelGGL((moments_sreg_pair_kernel<12, 6, 6, 6, true>), dim3(nb0 + nb1), dim3(256), 0, ctx->stream, d0.a,
+                             d1.a, (int)d0.grid.x, nb0, (int)d1.grid.x);
+        else
+          hipLaunchKernelGGL((moments_scost_pair_kernel<12, 6, 6, 6, 2>), dim3(nb0 + nb1), dim3(256), 0, ctx->stream, d0.a, d1.a,
+                             (int)d0.grid.x, nb0, (int)d1.grid.x);
+        HIPCK(ctx, hipGetLastError());
+        if (prof) { HIPCK(ctx, hipEventRecord(s0.ev[0][1], ctx->stream)); s0.ev_set[0] = true; }
+        s0.fused_pair = s1.fused_pair = true;
+        return GVI_OK;
+      }
+      // a deferred launch that did not pair up: issue it on its own below (run_moments again, undeferred)
+      if (d0.kind < 0 && d1.kind < 0) { s0.fused_pair = s1.fused_pair = false; return GVI_OK; }   // both already launched
+      if (d0.kind >= 0 && d1.kind < 0) { s0.fused_pair = false; return run_moments(ctx, s0, s0.mu_k[slot].d(), nullptr, full); }
+      if (d1.kind >= 0 && d0.kind < 0) { s1.fused_pair = false; return run_moments(ctx, s1, s1.mu_k[slot].d(), nullptr, full); }
+    }
+  }
+  for (auto& s : ctx->sets) { s->fused_pair = false; GVICK(run_moments(ctx, *s, s->mu_k[slot].d(), nullptr, full)); }
+  return GVI_OK;
+}
+
 static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot) {
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
   GVICK(ngd_prep_all(ctx, slot));
-  for (auto& s : ctx->sets) GVICK(run_moments(ctx, *s, s->mu_k[slot].d(), nullptr, 1));
+  GVICK(ngd_moments_launch(ctx, slot, 1));
   return ngd_epilogue_all(ctx, 1);
 }
 
@@ -1841,7 +1908,7 @@ gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what, float* ms) {
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk) {
   FactorSet* s = get_set(ctx, set_id);
   if (!s) return GVI_ERR_ARG;
-  if (variant) *variant = s->closed_form ? 0 : (s->use_reg ? 2 : (s->use_split ? 3 : 1));
+  if (variant) *variant = s->closed_form ? 0 : (s->fused_pair ? 5 : (s->use_reg ? 2 : (s->use_split ? 3 : 1)));
   if (nchunk) *nchunk = s->nchunk;
   if (chunk) *chunk = s->chunk;
   return GVI_OK;

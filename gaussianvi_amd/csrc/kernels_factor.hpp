@@ -991,18 +991,18 @@ __global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
 // consecutive factors over the same range of points.
 // ---------------------------------------------------------------------------------------------
 template <int D, int M, bool FULL>
-__global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
+__device__ __forceinline__ void sreg_body(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
   constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
   constexpr int NB = (NP + 15) / 16;
-  __shared__ double us[4][2 * M];
-  __shared__ double red[4][16][65];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int kq = blockIdx.x * 4 + wave;
+  double* us_w = usb + wave * 2 * M;               // [2 M] u0 | sgn of this wave's factor
+  double (*red_w)[65] = (double (*)[65])(redb + wave * 16 * 65);
+  const int kq = bx * 4 + wave;
   const bool active = kq < a.f.K;
   const int k = __builtin_amdgcn_readfirstlane(active ? kq : a.f.K - 1);   // inactive waves redo the last factor
   if (lane < M) {
-    us[wave][lane] = a.f.u0[(size_t)k * M + lane];
-    us[wave][M + lane] = a.f.sgn[(size_t)k * M + lane];
+    us_w[lane] = a.f.u0[(size_t)k * M + lane];
+    us_w[M + lane] = a.f.sgn[(size_t)k * M + lane];
   }
   __syncthreads();
   const uint64_t hbase = (uint64_t)(a.f.H + (size_t)k * M * D);
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
 #pragma unroll
   for (int j = 0; j < NP; ++j) acc[j] = 0.0;
   const int64_t Np = a.f.Np;
-  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i0 = (int64_t)by * a.chunk;
   const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
   const double* __restrict__ Zt = a.f.Zt;
   const double* __restrict__ w = a.f.w;
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
 #pragma unroll
     for (int c = 0; c < D; ++c) z[c] = Zt[(size_t)c * Np + i];
     const double wi = w[i];
-    const double psi = split_psi_rows<D, M>(hq, us[wave], us[wave] + M, z);
+    const double psi = split_psi_rows<D, M>(hq, us_w, us_w + M, z);
     const double cw = i < a.f.N ? wi * psi : 0.0;
     acc[0] += cw;
     if (FULL) {
@@ -1036,22 +1036,42 @@ __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
       }
     }
   }
-  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * NP;
+  double* out = a.partial + ((size_t)k * a.nchunk + by) * NP;
 #pragma unroll
   for (int bb = 0; bb < NB; ++bb) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)
-      if (bb * 16 + j < NP) red[wave][j][lane] = acc[bb * 16 + j];
+      if (bb * 16 + j < NP) red_w[j][lane] = acc[bb * 16 + j];
     wave_lds_sync();
     const int j = lane & 15, part = lane >> 4;
     double s = 0.0;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) s += red[wave][j][part * 16 + t];
+    for (int t = 0; t < 16; ++t) s += red_w[j][part * 16 + t];
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
     wave_lds_sync();
   }
+}
+
+template <int D, int M, bool FULL>
+__global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
+  __shared__ double us[4 * 2 * M];
+  __shared__ double red[4 * 16 * 65];
+  sreg_body<D, M, FULL>(a, blockIdx.x, blockIdx.y, us, red);
+}
+
+// Two sets in one launch (the chain pattern: binary priors d = 2n and unary factors d = n).  The launches are
+// independent, so fusing them removes one dependent-launch boundary (~6 us on this part) and lets the small set's
+// blocks fill the tail of the large one.  Blocks [0, nb0) belong to set 0 (x fastest), the rest to set 1.
+template <int D0, int M0, int D1, int M1, bool FULL>
+__global__ __launch_bounds__(256) void moments_sreg_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
+  constexpr int MM = M0 > M1 ? M0 : M1;
+  __shared__ double us[4 * 2 * MM];
+  __shared__ double red[4 * 16 * 65];
+  const int b = blockIdx.x;
+  if (b < nb0) sreg_body<D0, M0, FULL>(a0, b % nbx0, b / nbx0, us, red);
+  else sreg_body<D1, M1, FULL>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1061,17 +1081,17 @@ __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
 // 8-byte-per-lane table loads).  Block = 4 waves = 4 F consecutive factors over the same range of points.
 // ---------------------------------------------------------------------------------------------
 template <int D, int M, int F>
-__global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
-  __shared__ double us[4][F][2 * M];
+__device__ __forceinline__ void scost_body(const MomArgs& a, const int bx, const int by, double* usb) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int k0 = (blockIdx.x * 4 + wave) * F;
+  double (*us_w)[2 * M] = (double (*)[2 * M])(usb + wave * F * 2 * M);     // [F][2 M]
+  const int k0 = (bx * 4 + wave) * F;
   cdouble_t* hq[F];
 #pragma unroll
   for (int f = 0; f < F; ++f) {
     const int k = __builtin_amdgcn_readfirstlane(k0 + f < a.f.K ? k0 + f : a.f.K - 1);
     if (lane < M) {
-      us[wave][f][lane] = a.f.u0[(size_t)k * M + lane];
-      us[wave][f][M + lane] = a.f.sgn[(size_t)k * M + lane];
+      us_w[f][lane] = a.f.u0[(size_t)k * M + lane];
+      us_w[f][M + lane] = a.f.sgn[(size_t)k * M + lane];
     }
     const uint64_t hbase = (uint64_t)(a.f.H + (size_t)k * M * D);
     hq[f] = (cdouble_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(hbase >> 32)) << 32) |
@@ -1082,7 +1102,7 @@ __global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
 #pragma unroll
   for (int f = 0; f < F; ++f) acc[f] = 0.0;
   const int64_t Np = a.f.Np;
-  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i0 = (int64_t)by * a.chunk;
   const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
   const double* __restrict__ Zt = a.f.Zt;
   const double* __restrict__ w = a.f.w;
@@ -1094,7 +1114,7 @@ __global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
     const double wi = i < a.f.N ? w[i] : 0.0;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      const double psi = split_psi_rows<D, M>(hq[f], us[wave][f], us[wave][f] + M, z);
+      const double psi = split_psi_rows<D, M>(hq[f], us_w[f], us_w[f] + M, z);
       acc[f] += i < a.f.N ? wi * psi : 0.0;
     }
   }
@@ -1103,8 +1123,23 @@ __global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
     double s = acc[f];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0 && k0 + f < a.f.K) a.partial[(size_t)(k0 + f) * a.nchunk + blockIdx.y] = s;
+    if (lane == 0 && k0 + f < a.f.K) a.partial[(size_t)(k0 + f) * a.nchunk + by] = s;
   }
+}
+
+template <int D, int M, int F>
+__global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
+  __shared__ double us[4 * F * 2 * M];
+  scost_body<D, M, F>(a, blockIdx.x, blockIdx.y, us);
+}
+
+template <int D0, int M0, int D1, int M1, int F>
+__global__ __launch_bounds__(256) void moments_scost_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
+  constexpr int MM = M0 > M1 ? M0 : M1;
+  __shared__ double us[4 * F * 2 * MM];
+  const int b = blockIdx.x;
+  if (b < nb0) scost_body<D0, M0, F>(a0, b % nbx0, b / nbx0, us);
+  else scost_body<D1, M1, F>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1322,22 +1357,29 @@ struct EpiList {
 // sum over all factors (same order as cost_sum_all_kernel: thread-strided partial sums, then a fixed 256-leaf tree
 // per set) into acc[0], and -- single-process iteration only -- the publish into host-mapped memory
 // ({cost_sum, half_logdet, sequence}).  Replaces epilogue_all_kernel(full = 0) -> cost_sum_all_kernel -> publish_kernel.
-__global__ __launch_bounds__(256) void cost_tail_kernel(EpiList L, double* acc, const double* half_logdet, double* host_out,
-                                                        double seq) {
+__global__ __launch_bounds__(1024) void cost_tail_kernel(EpiList L, double* acc, const double* half_logdet, double* host_out,
+                                                         double seq) {
   __shared__ double sh[256];
-  double total = 0.0;
+  // phase 1 (all 1024 threads): per-factor costs to global
   for (int si = 0; si < L.nsets; ++si) {
     const EpiArgs& e = L.e[si];
-    double s = 0.0;
-    for (int k = threadIdx.x; k < e.f.K; k += 256) {
+    for (int k = threadIdx.x; k < e.f.K; k += 1024) {
       const double* P = e.partial + (size_t)k * e.nchunk;
       double m0 = 0.0;
       for (int c = 0; c < e.nchunk; ++c) m0 += P[c];               // fixed order: deterministic
-      const double ck = m0 / e.f.temperature[k];
-      e.cost[k] = ck;
-      s += ck;
+      e.cost[k] = m0 / e.f.temperature[k];
     }
-    sh[threadIdx.x] = s;
+  }
+  __syncthreads();                       // workgroup-scope release/acquire: the costs written above are visible below
+  // phase 2 (threads 0..255): the summation order of cost_sum_all_kernel
+  double total = 0.0;
+  for (int si = 0; si < L.nsets; ++si) {
+    const EpiArgs& e = L.e[si];
+    if (threadIdx.x < 256) {
+      double s = 0.0;
+      for (int k = threadIdx.x; k < e.f.K; k += 256) s += e.cost[k];
+      sh[threadIdx.x] = s;
+    }
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
       if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];

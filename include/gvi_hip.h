@@ -221,7 +221,8 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
  *      ~10 us of queue gaps; on = 2: every moments / cost launch of every set. ---- */
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on);
 gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kernel, 1 cost kernel*/, float* ms);
-/* Launch geometry of the set's last moments/cost launch: variant (0 closed form, 1 generic, 2 register, 3 split = four waves per factor, d = 16/20/24), chunks. */
+/* Launch geometry of the set's last moments/cost launch: variant (0 closed form, 1 generic, 2 register, 3 split = four waves per factor, d = 16/20/24,
+ * 5 register kernel fused with the chain's other set in one launch), chunks. */
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk);
 /* Kernel variant override for A/B runs: 0 = auto, 1 = generic LDS kernel, 2 = register kernel (psi operands in
  * LDS), 3 = operand-resident, 4 = LDS-staged table (experimental), 5 = register kernel with psi operands in SGPRs. */
