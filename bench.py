@@ -233,6 +233,10 @@ def main():
                                     2: "moments_reg_kernel<12, PsiQuad<12,6>, full>", 3: "moments_wide_kernel<12, PsiQuad<12,6>, full>",
                                     4: "moments_tile_kernel<12, PsiQuad<12,6>, full>"}.get(args.variant, "moments_generic_kernel")
                                    if geo["variant"] in (2, 5) else "moments_generic_kernel",
+                         "note": "achieved/frac use SURVEY 8(d)'s ALGORITHMIC count (the reference's x-space expand + psi + three "
+                                 "moment passes = 638 flop per evaluation).  The kernel's z-space formulation executes 188 fp64 "
+                                 "FMA/MUL (376 flop) per evaluation, so frac can exceed 1; executed_tflops / 78.6 is the "
+                                 "fraction of the pipe actually used.",
                          "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": 188,
                          "executed_tflops": 2 * 188 * K0 * N0 / km / 1e12,   # prior set only (unary: 1.5e6 of 19.1e6 evaluations)
                          "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "
