@@ -108,6 +108,9 @@ struct NgdState {
   bool cost_valid[2] = {false, false};
   double cost[2] = {0, 0};
   bool have_trial = false;
+  // gather of slot i deferred into the next prep launch of that slot (ngd_prep_all) -- see PrepList
+  struct GatherPending { bool on = false; const double* mu_from = nullptr; const double* dmu = nullptr; double step = 0.0; };
+  GatherPending gpend[2];
 };
 
 }  // namespace
@@ -137,6 +140,8 @@ struct gvi_ctx {
   struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; };
   Deferred* defer = nullptr;
   bool pair_fuse = true;              // GVI_NO_PAIR=1: one launch per set
+  bool defer_gather = false;          // set around the trial-state refresh (a prep of that slot always follows)
+  bool fuse_gather = true;            // GVI_NO_FUSE_GATHER=1: stand-alone gather launch before the trial's prep
   hipEvent_t fork = nullptr;
   // side-stream solve: the chain solve of the gradients runs beside the trial factorisation (independent given Vddmu)
   bool side_solve = true;             // GVI_SIDE_SOLVE=0 keeps everything on one stream
@@ -829,6 +834,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
+  if (const char* w = getenv("GVI_NO_FUSE_GATHER")) c->fuse_gather = atoi(w) == 0;
   if (const char* w = getenv("GVI_SIDE_SOLVE")) c->side_solve = atoi(w) != 0;
   if (const char* w = getenv("GVI_SCOST_F")) c->scost_f = atoi(w) == 4 ? 4 : 2;
   if (const char* w = getenv("GVI_COST_CHUNK_MULT")) c->cost_chunk_mult = std::max(1, atoi(w));
@@ -1359,13 +1365,35 @@ static SetList make_set_list(gvi_ctx* ctx, int slot) {
 }
 
 // prep of every set whose per-pass products are not those of NGD slot i -- one launch
+static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i, const double* mu_from, const double* dmu, double step);
+
+// stand-alone gather of a slot whose gather was left to the next prep (consumers other than prep call this)
+static gvi_status ngd_flush_gather(gvi_ctx* ctx, int i) {
+  NgdState::GatherPending& gp = ctx->ngd.gpend[i];
+  if (!gp.on) return GVI_OK;
+  const NgdState::GatherPending p = gp;
+  gp.on = false;
+  const bool keep = ctx->fuse_gather;
+  ctx->fuse_gather = false;
+  const gvi_status st = ngd_refresh_gather(ctx, i, p.mu_from, p.dmu, p.step);
+  ctx->fuse_gather = keep;
+  return st;
+}
+
 static gvi_status ngd_prep_all(gvi_ctx* ctx, int i) {
+  NgdState& g = ctx->ngd;
   PrepList L;
   L.nsets = 0;
   L.koff[0] = 0;
+  L.gather = 0;
   int dmax = 0;
+  bool all = true;
   for (auto& s : ctx->sets) {
     if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
+    if (s->prep_slot == i) { all = false; break; }
+  }
+  if (g.gpend[i].on && !all) GVICK(ngd_flush_gather(ctx, i));      // cannot happen (a pending gather resets every prep_slot)
+  for (auto& s : ctx->sets) {
     if (s->prep_slot == i) continue;
     s->prep_slot = i;
     L.f[L.nsets] = s->dev();
@@ -1377,14 +1405,28 @@ static gvi_status ngd_prep_all(gvi_ctx* ctx, int i) {
     }
     L.mu[L.nsets] = s->mu_k[i].d();
     L.Sigma[L.nsets] = s->Sigma_k[i].d();
+    L.start[L.nsets] = (const int32_t*)s->dstart.p;
+    L.mu_k[L.nsets] = s->mu_k[i].d();
+    L.Sigma_k[L.nsets] = s->Sigma_k[i].d();
     L.koff[L.nsets + 1] = L.koff[L.nsets] + s->K;
     dmax = std::max(dmax, s->d);
     ++L.nsets;
   }
   if (L.nsets == 0) return GVI_OK;
+  int extra = 0;
+  if (g.gpend[i].on) {
+    const size_t T = ctx->T, nn = nn_(ctx);
+    L.gather = 1; L.n = ctx->n;
+    L.gmu = g.gpend[i].dmu ? g.gpend[i].mu_from : g.mu[i].d();
+    L.gdmu = g.gpend[i].dmu; L.gstep = g.gpend[i].step;
+    L.SigD = g.Sig[i].d(); L.SigU = g.Sig[i].d() + T * nn;
+    L.mu_out = g.mu[i].d(); L.nmu = (int64_t)T * ctx->n;
+    if (L.gdmu) extra = (int)((L.nmu + 63) / 64);
+    g.gpend[i].on = false;
+  }
   const int dp = dmax + (dmax & 1);
-  const size_t lds = (size_t)(4 * dmax * dmax + 2 * dp + 3 * dmax) * 8 + (size_t)dp * 4 + 16;
-  const dim3 grid(L.koff[L.nsets]);
+  const size_t lds = (size_t)(4 * dmax * dmax + 2 * dp + 3 * dmax + (dp + 1) / 2 + 1 + dmax * dmax + dmax) * 8 + 16;
+  const dim3 grid(L.koff[L.nsets] + extra);
   if (dmax <= 8) hipLaunchKernelGGL(prep_all_kernel<1>, grid, dim3(64), lds, ctx->stream, L);
   else if (dmax <= 16) hipLaunchKernelGGL(prep_all_kernel<4>, grid, dim3(64), lds, ctx->stream, L);
   else if (dmax <= 32) hipLaunchKernelGGL(prep_all_kernel<16>, grid, dim3(64), lds, ctx->stream, L);
@@ -1434,9 +1476,14 @@ static gvi_status ngd_refresh_factor(gvi_ctx* ctx, int i) {
 }
 
 // mu_from / dmu / step: form mu[i] = mu_from + step dmu inside the gather launch (trial state); null: mu[i] is current
-static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i, const double* mu_from = nullptr, const double* dmu = nullptr,
-                                     double step = 0.0) {
+static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i, const double* mu_from, const double* dmu, double step) {
   NgdState& g = ctx->ngd;
+  if (ctx->fuse_gather && ctx->defer_gather && !ctx->sets.empty()) {   // trial state: the prep launch that follows gathers
+    for (auto& s : ctx->sets) if (s->prep_slot == i) s->prep_slot = -1;
+    g.gpend[i].on = true; g.gpend[i].mu_from = mu_from; g.gpend[i].dmu = dmu; g.gpend[i].step = step;
+    return GVI_OK;
+  }
+  g.gpend[i].on = false;
   const size_t T = ctx->T, nn = nn_(ctx);
   const int64_t nmu = (int64_t)T * ctx->n;
   double* sD = g.Sig[i].d();
@@ -1461,7 +1508,7 @@ static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i, const double* mu_from 
 
 static gvi_status ngd_refresh(gvi_ctx* ctx, int i) {
   GVICK(ngd_refresh_factor(ctx, i));
-  return ngd_refresh_gather(ctx, i);
+  return ngd_refresh_gather(ctx, i, nullptr, nullptr, 0.0);
 }
 
 // sum over sets of sum_k E[psi]/T_k at slot i -> exch1[0].  Everything stays on ONE stream: side streams
@@ -1591,6 +1638,7 @@ gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs) {
   if (!s || !costs) return fail(ctx, GVI_ERR_ARG, "bad set id / NULL");
   HIPCK(ctx, hipSetDevice(ctx->device));
   const int i = ctx->ngd.cur;
+  GVICK(ngd_flush_gather(ctx, i));
   GVICK(gvi_costs_dev(ctx, set_id, s->mu_k[i].d(), s->Sigma_k[i].d(), s->cost.d()));
   GVICK(d2h(ctx, costs, s->cost.p, (size_t)s->K * 8));
   return sync(ctx);
@@ -1739,7 +1787,10 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
                        step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
     GVICK(ngd_refresh_factor(ctx, t));
     GVICK(ngd_join_solve(ctx, g.gcur));
-    GVICK(ngd_refresh_gather(ctx, t, g.mu[c].d(), g.dmu2[g.gcur].d(), step));     // forms mu_trial in the same launch
+    ctx->defer_gather = true;               // mu_trial and the gather ride in the prep launch of the cost pass
+    const gvi_status gs = ngd_refresh_gather(ctx, t, g.mu[c].d(), g.dmu2[g.gcur].d(), step);
+    ctx->defer_gather = false;
+    GVICK(gs);
   } else {
     hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn,
                        (int64_t)bt, step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn,
@@ -1773,6 +1824,7 @@ gvi_status gvi_ngd_trial(gvi_ctx* ctx, double step, double* new_cost) {
 gvi_status gvi_ngd_accept(gvi_ctx* ctx) {
   GVICK(ngd_check(ctx));
   if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
+  GVICK(ngd_flush_gather(ctx, 1 - ctx->ngd.cur));      // no-op once the trial's cost pass has run
   ctx->ngd.cur = 1 - ctx->ngd.cur;
   ctx->ngd.have_trial = false;
   ctx->ngd.grad_valid = false;

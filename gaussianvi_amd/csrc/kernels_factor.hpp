@@ -86,8 +86,9 @@ __device__ inline double wave_sum(double v) {
 }
 
 template <int EPLP>   // elements of the d x d block per lane: 1 (d <= 8), 4 (d <= 16), 16 (d <= 32)
-__device__ inline void prep_body(const FactorDev& f, const double* __restrict__ mu, const double* __restrict__ Sigma,
-                                 int k, double* sm) {
+// kin: index of the factor inside the (mu, Sigma) INPUT arrays (== k, or 0 when the caller staged this factor's
+// marginal in LDS); outputs always go to slot k
+__device__ inline void prep_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
   const int d = f.d, dd = d * d, lane = threadIdx.x;
   const int dp = d + (d & 1);
   double* A0 = sm;
@@ -105,7 +106,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* __restrict__ 
     ei[q] = e < dd ? e / d : -1;
     ej[q] = e < dd ? e % d : 0;
   }
-  const double* Sg = Sigma + (size_t)k * dd;
+  const double* Sg = Sigma + (size_t)kin * dd;
   // Warm start (device-resident NGD iteration): consecutive proposals differ little, so the previous
   // eigenvectors W almost diagonalise the new block; sweeping A0 = W^T Sigma W from V0 = W needs 2-4
   // sweeps instead of 7-8.  Any orthogonal start gives the same decomposition up to rounding; a NaN
@@ -261,7 +262,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* __restrict__ 
     }
     if (lane < m) {
       double u = f.b[(size_t)k * m + lane];
-      for (int c = 0; c < d; ++c) u += Ak[lane * d + c] * mu[(size_t)k * d + c];
+      for (int c = 0; c < d; ++c) u += Ak[lane * d + c] * mu[(size_t)kin * d + c];
       f.u0[(size_t)k * m + lane] = u;
     }
   }
@@ -271,7 +272,7 @@ template <int EPLP>
 __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __restrict__ mu,
                                                   const double* __restrict__ Sigma) {
   extern __shared__ double sm[];
-  prep_body<EPLP>(f, mu, Sigma, blockIdx.x, sm);
+  prep_body<EPLP>(f, mu, Sigma, blockIdx.x, sm, blockIdx.x);
 }
 
 // every factor set of the problem in ONE launch: block -> (set, factor) through the offsets
@@ -282,14 +283,59 @@ struct PrepList {
   FactorDev f[MAX_FSETS];
   const double* mu[MAX_FSETS];
   const double* Sigma[MAX_FSETS];
+  // optional fused gather (update_mu_from_joint / update_precision_from_joint, gvibase/GVIFactorizedBase.h:104-114):
+  // every block first pulls its factor's (mu_k, Sigma_k) out of the chain arrays -- forming the trial mean
+  // gmu + gstep * gdmu on the fly when gdmu != null -- parks them in LDS for the decomposition and writes them to
+  // mu_k / Sigma_k for the later kernels; blocks past koff[nsets] write the chain-level trial mean mu_out.
+  int gather, n;
+  const double* gmu;
+  const double* gdmu;
+  double gstep;
+  const double* SigD;
+  const double* SigU;
+  double* mu_out;
+  int64_t nmu;
+  const int32_t* start[MAX_FSETS];
+  double* mu_k[MAX_FSETS];
+  double* Sigma_k[MAX_FSETS];
 };
 
 template <int EPLP>
 __global__ __launch_bounds__(64) void prep_all_kernel(PrepList L) {
   extern __shared__ double sm[];
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= L.koff[L.nsets]) {                      // chain-level trial mean (gather mode only)
+    const int64_t j = (int64_t)((int)blockIdx.x - L.koff[L.nsets]) * 64 + lane;
+    if (j < L.nmu) L.mu_out[j] = L.gmu[j] + L.gstep * L.gdmu[j];
+    return;
+  }
   int si = 0;
   while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
-  prep_body<EPLP>(L.f[si], L.mu[si], L.Sigma[si], (int)blockIdx.x - L.koff[si], sm);
+  const int k = (int)blockIdx.x - L.koff[si];
+  if (!L.gather) { prep_body<EPLP>(L.f[si], L.mu[si], L.Sigma[si], k, sm, k); return; }
+  const FactorDev& f = L.f[si];
+  const int d = f.d, dd = d * d, dp = d + (d & 1), n = L.n, nn = n * n;
+  double* Sl = sm + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;  // behind prep_body's own LDS
+  double* ml = Sl + dd;
+  const int s = L.start[si][k];
+  for (int e = lane; e < dd; e += 64) {
+    const int r = e / d, c = e % d;
+    double v;
+    if (r < n && c < n) v = L.SigD[(size_t)s * nn + r * n + c];
+    else if (r >= n && c >= n) v = L.SigD[(size_t)(s + 1) * nn + (r - n) * n + (c - n)];
+    else if (r < n) v = L.SigU[(size_t)s * nn + r * n + (c - n)];
+    else v = L.SigU[(size_t)s * nn + c * n + (r - n)];
+    Sl[e] = v;
+    L.Sigma_k[si][(size_t)k * dd + e] = v;
+  }
+  for (int e = lane; e < d; e += 64) {
+    const size_t j = (size_t)s * n + e;
+    const double v = L.gdmu ? L.gmu[j] + L.gstep * L.gdmu[j] : L.gmu[j];
+    ml[e] = v;
+    L.mu_k[si][(size_t)k * d + e] = v;
+  }
+  wave_lds_sync();
+  prep_body<EPLP>(f, ml, Sl, k, sm, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
