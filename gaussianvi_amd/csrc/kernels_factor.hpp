@@ -1412,7 +1412,13 @@ __global__ __launch_bounds__(1024) void cost_tail_kernel(EpiList L, double* acc,
     for (int k = threadIdx.x; k < e.f.K; k += 1024) {
       const double* P = e.partial + (size_t)k * e.nchunk;
       double m0 = 0.0;
-      for (int c = 0; c < e.nchunk; ++c) m0 += P[c];               // fixed order: deterministic
+      for (int c0 = 0; c0 < e.nchunk; c0 += 8) {                   // eight loads in flight, then the ordered sum
+        double p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] = c0 + j < e.nchunk ? P[c0 + j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m0 += p[j];                    // fixed order (x + 0.0 == x): deterministic
+      }
       e.cost[k] = m0 / e.f.temperature[k];
     }
   }
