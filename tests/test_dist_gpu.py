@@ -1,0 +1,70 @@
+"""Sharded HIP path on ONE GPU: two processes (two contexts on cuda:0), each owning half of the factors, exchanging
+through torch.distributed -- gloo here, because RCCL refuses two ranks on one device; the driver's N>1 runs use
+RCCL on one GPU per rank with the same code.  The replicated state after the iterations must equal the
+single-process device run (and thereby the oracle, tests/test_gpu_parity.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from chains import make_chain
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, iters, q):
+    import torch.distributed as dist
+    from gaussianvi_amd import api
+    from gaussianvi_amd.dist import HipEngine, ShardedNGD, shard_chain
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ch = make_chain(name)
+        ctx, ids = api.context_for_chain(shard_chain(ch, rank, world), device=0)
+        ngd = ShardedNGD(HipEngine(ctx, 0), world=world)
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        log = [ngd.step(0.55, 10) for _ in range(iters)]
+        st = ctx.ngd_get_state()
+        q.put((rank, log, st["mu"], st["D"], st["SigD"]))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,iters", [("c2", 4), ("c3small", 3)])
+def test_two_ranks_on_one_gpu_match_single_process(name, iters):
+    from gaussianvi_amd import api
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    ref_log = [ctx.ngd_step(0.55, 10) for _ in range(iters)]
+    ref = ctx.ngd_get_state()
+    ctx.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, name, iters, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, log, mu, D, SigD in res:
+        for a, b in zip(log, ref_log):
+            assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"]
+            assert np.isclose(a["new_cost"], b["new_cost"], rtol=1e-10)
+        s = np.abs(ref["mu"]).max()
+        assert np.abs(mu - ref["mu"]).max() < 1e-9 * s
+        assert np.abs(D - ref["D"]).max() < 1e-9 * np.abs(ref["D"]).max()
+        assert np.abs(SigD - ref["SigD"]).max() < 1e-9 * np.abs(ref["SigD"]).max()
+    # the replicated chain state is bit-identical across ranks (same all-reduced inputs, same chain code)
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
