@@ -38,35 +38,53 @@ HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_M
 FP64_PEAK = 78.6e12        # FLOP/s, AMD public spec sheet (vector = matrix fp64 on MI355X); not in the guide
 
 
+def api_count(d, p):
+    from gaussianvi_amd import api
+    return api.spgh_count(d, p)
+
+
 def cpu_baseline(chain, seconds):
     """Reference-shaped CPU port (oracle/c/gvi_oracle.c: per-factor symmetric sqrt + expand, three
     Integrate passes with psi re-evaluated through a function pointer, OpenMP over factors) timed on
-    this box's host cores on a bounded sample of the SAME workload: the first 256 prior factors of
-    the chain at their start-state marginals, repeated until ~`seconds` of CPU work."""
+    this box's host cores on a bounded sample of the SAME workload: the first factors of the prior set
+    at their start-state marginals (as many as ~`seconds` of CPU work allow, at most 256), repeated."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     import gvi_oracle as o
     spec = chain["specs"][0]
-    K = min(256, len(spec["start"]))
     d, n = spec["d"], chain["n"]
+    Kall = len(spec["start"])
+    N_est = api_count(d, spec["p"])
+    if N_est * d * 8 > 2 ** 28:
+        # the reference-shaped port materialises an N x d sigma-point batch PER THREAD (as the reference does per
+        # factor): at (24,7) that is 3.9 GB x 128 threads.  Not run: it would exhaust the host (it took a box down once).
+        return {"value": None, "unit": "psi-evals/s", "cores": 0, "kind": "port",
+                "sample": f"skipped: the (d={d}, p={spec['p']}) table has {N_est} points; the reference-shaped CPU path needs "
+                          f"{N_est * d * 8 / 2**30:.1f} GiB per thread"}
     SD, SU = o.inverse_gbp(chain["D0"], chain["U0"])
-    mk, Sk = o.gather_marginals(chain["mu0"], SD, SU, spec["start"][:K], d)
+    mk, Sk = o.gather_marginals(chain["mu0"], SD, SU, spec["start"][:min(256, Kall)], d)
     Z, w = o.nwspgr(d, spec["p"])
     threads = c_oracle.max_threads()
+    # size the sample from a probe of one factor per thread (all threads)
+    Kp = min(Kall, threads, len(mk))
+    t0 = time.perf_counter()
+    c_oracle.moments(Z, w, mk[:Kp], Sk[:Kp], spec["kind"], spec["params"][:Kp], n, fused=False)
+    t_probe = max(time.perf_counter() - t0, 1e-6)
+    K = int(max(1, min(256, Kall, len(mk), Kp * max(1, int(seconds * 0.1 / t_probe)))))
     out = {}
     for name, fused in (("reference_style", False), ("fused", True)):
-        c_oracle.moments(Z, w, mk[:8], Sk[:8], spec["kind"], spec["params"][:8], n, fused=fused)   # warm
+        c_oracle.moments(Z, w, mk[:min(8, K)], Sk[:min(8, K)], spec["kind"], spec["params"][:min(8, K)], n, fused=fused)   # warm
         reps, t0 = 0, time.perf_counter()
         budget = seconds * (0.7 if not fused else 0.3)
         while True:
-            c_oracle.moments(Z, w, mk, Sk, spec["kind"], spec["params"][:K], n, fused=fused)
+            c_oracle.moments(Z, w, mk[:K], Sk[:K], spec["kind"], spec["params"][:K], n, fused=fused)
             reps += 1
             el = time.perf_counter() - t0
             if el >= budget:
                 break
         out[name] = K * len(w) * reps / el
     return {"value": out["reference_style"], "unit": "psi-evals/s", "cores": threads, "kind": "port",
-            "sample": f"{K} of the 1024 d=12 p=5 prior factors x 17217 sigma points, full moments pass "
+            "sample": f"{K} of the {Kall} d={d} p={spec['p']} prior factors x {len(w)} sigma points, full moments pass "
                       f"(3 Integrate passes, psi x3 per point) repeated for ~{seconds:.0f} s, OpenMP {threads} threads",
             "fused_single_pass_value": out["fused"]}
 
@@ -188,6 +206,7 @@ def main():
         n_half = d0 // 2
         f_alg = 2 * (d0 * d0 + 2 * n_half * n_half + 2 * n_half + 1 + d0 + d0 * (d0 + 1) // 2)
         flop_launch, evals_launch = f_alg * K0 * N0, K0 * N0
+        exec_ops = n_half * d0 + 2 * n_half + 2 + 2 * d0 + d0 * (d0 + 1) // 2   # psi rows (+ square, sign), c = w psi, m0, t = c z, m1, packed M2
         fused_pair = geo["variant"] == 5 and len(ctx.sets) == 2
         if fused_pair:
             # the timed launch also carries the unary set (d = n, psi = (x-mu0)^T Kinv (x-mu0): d^2 + d for psi):
@@ -205,13 +224,14 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "sigma-point psi-evals/sec + NGD iters/sec, 1024-factor d=12 p=5 chain",
+            "metric": "sigma-point psi-evals/sec + NGD iters/sec, 1024-factor d=12 p=5 chain" if args.config.startswith("c3")
+                      else f"sigma-point psi-evals/sec + NGD iters/sec, {chain['T'] - 1}-factor d={d0} p={p0} chain",
             "value": total_evals / elapsed, "unit": "psi-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {chain['T'] - 1}-factor LTV-prior chain, d=12, sparse-GH p=5 (N=17217), "
-                                   f"T={chain['T']} n=6, +{chain['T']} unary d=6 p=5 factors; one step = one device-resident NGD iteration "
+            "config": {"workload": f"{args.config}: {chain['T'] - 1}-factor prior chain, d={d0}, sparse-GH p={p0} (N={N0}), "
+                                   f"T={chain['T']} n={chain['n']}, +{chain['T']} unary d={chain['n']} factors; one step = one device-resident NGD iteration "
                                    f"(state re-initialised inside the timed region every {args.restart_every} steps)",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": f"factors/{world} contiguous, all-reduce [g|D|U] + trial cost (RCCL)" if world > 1 else "none",
@@ -222,7 +242,7 @@ def main():
             "final_cost": log[-1]["new_cost"],
             "fused_trial_mode": fused,
             "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": evals_launch / km,
-                               "launch": "prior set (1024 x 17217) + unary set (1025 x 1433) in one launch" if fused_pair else "prior set"},
+                               "launch": "prior set + unary set in one launch" if fused_pair else "prior set"},
             # The dominant kernel streams only the (d,p) table, which is L2-resident (profiles/r01_traffic.json:
             # HBM traffic ~0.5 % of the algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.
             # The schema's compute label is "mfma"; fp64 MFMA and fp64 VALU share one pipe on MI355X and the
@@ -232,13 +252,13 @@ def main():
                          "kernel": "moments_sreg_pair_kernel<12, 6, 6, 6, full>" if fused_pair else {0: "moments_sreg_kernel<12, 6, full>", 5: "moments_sreg_kernel<12, 6, full>",
                                     2: "moments_reg_kernel<12, PsiQuad<12,6>, full>", 3: "moments_wide_kernel<12, PsiQuad<12,6>, full>",
                                     4: "moments_tile_kernel<12, PsiQuad<12,6>, full>"}.get(args.variant, "moments_generic_kernel")
-                                   if geo["variant"] in (2, 5) else "moments_generic_kernel",
+                                   if geo["variant"] in (2, 5) else ("moments_split_kernel<24, 3, full>" if geo["variant"] == 3 else "moments_generic_kernel"),
                          "note": "achieved/frac use SURVEY 8(d)'s ALGORITHMIC count (the reference's x-space expand + psi + three "
                                  "moment passes = 638 flop per evaluation).  The kernel's z-space formulation executes 188 fp64 "
                                  "FMA/MUL (376 flop) per evaluation, so frac can exceed 1; executed_tflops / 78.6 is the "
                                  "fraction of the pipe actually used.",
-                         "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": 188,
-                         "executed_tflops": 2 * 188 * K0 * N0 / km / 1e12,   # prior set only (unary: 1.5e6 of 19.1e6 evaluations)
+                         "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": exec_ops,
+                         "executed_tflops": 2 * exec_ops * K0 * N0 / km / 1e12,   # prior set only
                          "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "
                                         "Measured on this box (tools/ubench/fp64_pipes.hip): 70 TF v_fma_f64, 48 TF v_mfma_f64_16x16x4",
                          "hbm_algorithmic": {"bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / km / 1e9,
