@@ -205,6 +205,18 @@ def main():
         alg_bytes = K0 * N0 * (d0 + 1) * 8                      # (d+1) s bytes per eval
         n_half = d0 // 2
         f_alg = 2 * (d0 * d0 + 2 * n_half * n_half + 2 * n_half + 1 + d0 + d0 * (d0 + 1) // 2)
+        sreg_shapes = (4, 8, 12)
+        if geo["variant"] == 5:
+            kernel_name = f"moments_sreg_pair_kernel<{d0}, {d0 // 2}, {d0 // 2}, {d0 // 2}, full>"
+        elif geo["variant"] == 2:
+            kernel_name = {0: f"moments_sreg_kernel<{d0}, {d0 // 2}, full>" if d0 in sreg_shapes else f"moments_reg_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>",
+                           5: f"moments_sreg_kernel<{d0}, {d0 // 2}, full>", 2: f"moments_reg_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>",
+                           3: f"moments_wide_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>",
+                           4: f"moments_tile_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>"}.get(args.variant, "moments_reg_kernel")
+        elif geo["variant"] == 3:
+            kernel_name = f"moments_split_kernel<{d0}, {(d0 // 2 + 3) // 4}, full>"
+        else:
+            kernel_name = "moments_generic_kernel"
         flop_launch, evals_launch = f_alg * K0 * N0, K0 * N0
         exec_ops = n_half * d0 + 2 * n_half + 2 + 2 * d0 + d0 * (d0 + 1) // 2   # psi rows (+ square, sign), c = w psi, m0, t = c z, m1, packed M2
         fused_pair = geo["variant"] == 5 and len(ctx.sets) == 2
@@ -249,10 +261,7 @@ def main():
             # VALU form is the faster one (profiles/r01_fp64_pipes.txt), so the kernel uses v_fma_f64.
             "roofline": {"bound": "mfma", "achieved": flop_launch / km / 1e12, "peak": FP64_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": flop_launch / km / FP64_PEAK, "traffic": traffic,
-                         "kernel": "moments_sreg_pair_kernel<12, 6, 6, 6, full>" if fused_pair else {0: "moments_sreg_kernel<12, 6, full>", 5: "moments_sreg_kernel<12, 6, full>",
-                                    2: "moments_reg_kernel<12, PsiQuad<12,6>, full>", 3: "moments_wide_kernel<12, PsiQuad<12,6>, full>",
-                                    4: "moments_tile_kernel<12, PsiQuad<12,6>, full>"}.get(args.variant, "moments_generic_kernel")
-                                   if geo["variant"] in (2, 5) else ("moments_split_kernel<24, 3, full>" if geo["variant"] == 3 else "moments_generic_kernel"),
+                         "kernel": kernel_name,
                          "note": "achieved/frac use SURVEY 8(d)'s ALGORITHMIC count (the reference's x-space expand + psi + three "
                                  "moment passes = 638 flop per evaluation).  The kernel's z-space formulation executes 188 fp64 "
                                  "FMA/MUL (376 flop) per evaluation, so frac can exceed 1; executed_tflops / 78.6 is the "
