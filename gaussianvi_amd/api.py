@@ -11,6 +11,7 @@ from . import _lib
 
 PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK, PSI_HINGE_SDF_2D = 0, 1, 2, 3, 4
 PSI_HINGE_SDF_2D_BODY, PSI_HINGE_SDF_3D = 5, 6
+RULE_NGD, RULE_PROX_JKO = 0, 1
 GVI_F64, GVI_F32 = 0, 1
 
 
@@ -318,6 +319,24 @@ class Context:
         v, nch, ch = C.c_int(), C.c_int(), C.c_int64()
         self._ck(self.lib.gvi_profile_geometry(self.h, sid, C.byref(v), C.byref(nch), C.byref(ch)))
         return dict(variant=v.value, nchunk=nch.value, chunk=ch.value)
+
+    # ---- proximal (JKO) rule ----
+    def ngd_set_update_rule(self, rule):
+        self._ck(self.lib.gvi_ngd_set_update_rule(self.h, int(rule)))
+
+    def prox_gradients(self, h):
+        self._ck(self.lib.gvi_prox_gradients(self.h, float(h)))
+
+    def prox_trial(self, step):
+        c = C.c_double()
+        self._ck(self.lib.gvi_prox_trial(self.h, float(step), C.byref(c)))
+        return c.value
+
+    def prox_step(self, step_size_base=0.55, max_backtrack=10):
+        c0, c1, ok, nt = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        self._ck(self.lib.gvi_prox_step(self.h, float(step_size_base), int(max_backtrack), C.byref(c0), C.byref(ok),
+                                        C.byref(c1), C.byref(nt)))
+        return dict(cost_iter=c0.value, decreased=bool(ok.value), new_cost=c1.value, ntrials=nt.value)
 
     def set_variant(self, v):
         self._ck(self.lib.gvi_set_variant(self.h, v))

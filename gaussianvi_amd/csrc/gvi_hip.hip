@@ -55,6 +55,9 @@ struct FactorSet {
   std::shared_ptr<Table> table;
   DevMem dstart, dptr, didx, A, b, sgn, raw, temperature;
   DevMem S, Sinv, Lam, H, Hq, u0;     // per-pass products
+  DevMem ones;                        // [K] unit temperatures (proximal rule: the reference's prox classes never divide by T)
+  bool unit_temperature = false;
+  DevMem jko_half, jko_S, jko_Sinv, jko_Lam;   // scratch of the JKO map
   DevMem sdf;                         // HINGE_SDF_2D grid
   int sdf_rows = 0, sdf_cols = 0, sdf_nz = 1;
   double sdf_ox = 0, sdf_oy = 0, sdf_oz = 0, sdf_cell = 1;
@@ -87,9 +90,9 @@ struct FactorSet {
     f.Zt = table->Zt.d(); f.w = table->w.d();
     f.codes = table->coded ? (const uint32_t*)table->codes.p : nullptr; f.lut = table->coded ? table->lut.d() : nullptr;
     f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
-    f.temperature = temperature.d();
+    f.temperature = unit_temperature ? ones.d() : temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.Hq = Hq.p ? Hq.d() : nullptr; f.u0 = u0.d();
-    f.Vws = nullptr; f.warm = 0;
+    f.Vws = nullptr; f.warm = 0; f.jko_h = 0.0;
     f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz;
     return f;
   }
@@ -139,6 +142,7 @@ struct gvi_ctx {
   // run_moments in planning mode: the launch that WOULD be issued is recorded instead (pair fusion of two sets)
   struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; };
   Deferred* defer = nullptr;
+  int update_rule = 0;                // 0 natural gradient (NGD-GH), 1 proximal / JKO (ProxGVI-GH)
   bool pair_fuse = true;              // GVI_NO_PAIR=1: one launch per set
   bool defer_gather = false;          // set around the trial-state refresh (a prep of that slot always follows)
   bool fuse_gather = true;            // GVI_NO_FUSE_GATHER=1: stand-alone gather launch before the trial's prep
@@ -1028,6 +1032,10 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   std::vector<double> temp(K, 1.0);
   if (temperature) temp.assign(temperature, temperature + K);
   GVICK(up(s->temperature, temp.data(), temp.size() * 8));
+  {
+    std::vector<double> one((size_t)K, 1.0);
+    GVICK(up(s->ones, one.data(), one.size() * 8));
+  }
   // CSR over states for the ordered assemble
   std::vector<int32_t> ptr(ctx->T + 1, 0), idx(K);
   for (int k = 0; k < K; ++k) ptr[start[k] + 1]++;
@@ -1834,6 +1842,7 @@ gvi_status gvi_ngd_accept(gvi_ctx* ctx) {
 gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter, int* accepted,
                         double* new_cost, int* ntrials) {
   GVICK(ngd_check(ctx));
+  if (ctx->update_rule != GVI_RULE_NGD) return fail(ctx, GVI_ERR_STATE, "proximal rule selected: use gvi_prox_step");
   HIPCK(ctx, hipSetDevice(ctx->device));
   NgdState& g = ctx->ngd;
   double c0 = 0.0;
@@ -1881,6 +1890,101 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
   if (accepted) *accepted = ok;
   if (new_cost) *new_cost = ok ? c1 : c0;
   if (ntrials) *ntrials = cnt;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_set_update_rule(gvi_ctx* ctx, int rule) {
+  if (!ctx || (rule != GVI_RULE_NGD && rule != GVI_RULE_PROX_JKO)) return GVI_ERR_ARG;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  ctx->update_rule = rule;
+  for (auto& s : ctx->sets) { s->unit_temperature = rule == GVI_RULE_PROX_JKO; s->prep_slot = -1; }
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
+  return GVI_OK;
+}
+
+// factor-level JKO increments at step h for every set (moments at the current proposal), assembled into exch0[gcur]:
+// g = joint dmu, [D | U] = joint dprecision (proxgd/ProxGVI-GH-impl.h:43-60: plain sums, no solve)
+gvi_status gvi_prox_gradients(gvi_ctx* ctx, double h) {
+  GVICK(ngd_check(ctx));
+  if (ctx->update_rule != GVI_RULE_PROX_JKO) return fail(ctx, GVI_ERR_STATE, "call gvi_ngd_set_update_rule(GVI_RULE_PROX_JKO) first");
+  if (!(h > 0.0)) return fail(ctx, GVI_ERR_ARG, "step must be positive");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  g.grad_valid = false;
+  GVICK(ngd_flush_gather(ctx, g.cur));
+  GVICK(ngd_moments_full(ctx, g.cur));                    // Vdmu = b, Vddmu = S at unit temperature; f.Lam = Lam_k
+  for (auto& sp : ctx->sets) {
+    FactorSet& s = *sp;
+    const size_t K = s.K, d = s.d, dd = d * d;
+    HIPCK(ctx, s.jko_half.ensure(K * dd * 8));
+    HIPCK(ctx, s.jko_S.ensure(K * dd * 8));
+    HIPCK(ctx, s.jko_Sinv.ensure(K * dd * 8));
+    HIPCK(ctx, s.jko_Lam.ensure(K * dd * 8));
+    JkoArgs a;
+    a.K = s.K; a.d = s.d; a.h = h; a.Vdmu = s.Vdmu.d(); a.Vddmu = s.Vddmu.d(); a.Sigma = s.Sigma_k[g.cur].d();
+    a.Lam = s.Lam.d(); a.Shalf = s.jko_half.d(); a.LamNew = s.jko_Lam.d();
+    hipLaunchKernelGGL(jko_half_kernel, dim3(s.K), dim3(64), 3 * dd * 8, ctx->stream, a);
+    FactorDev f = s.dev();                                 // spectral map of Sig_half into scratch (no psi operands)
+    f.m = 0; f.S = s.jko_S.d(); f.Sinv = s.jko_Sinv.d(); f.Lam = s.jko_Lam.d(); f.H = nullptr; f.Hq = nullptr; f.u0 = nullptr;
+    f.jko_h = h;
+    const int dp = s.d + (s.d & 1);
+    const size_t lds = (size_t)(4 * dd + 2 * dp + 3 * d) * 8 + (size_t)dp * 4 + 16;
+    if (s.d <= 8) hipLaunchKernelGGL(prep_kernel<1>, dim3(s.K), dim3(64), lds, ctx->stream, f, (const double*)nullptr, (const double*)s.jko_half.d());
+    else if (s.d <= 16) hipLaunchKernelGGL(prep_kernel<4>, dim3(s.K), dim3(64), lds, ctx->stream, f, (const double*)nullptr, (const double*)s.jko_half.d());
+    else if (s.d <= 32) hipLaunchKernelGGL(prep_kernel<16>, dim3(s.K), dim3(64), lds, ctx->stream, f, (const double*)nullptr, (const double*)s.jko_half.d());
+    else return fail(ctx, GVI_ERR_UNSUPPORTED, "factor dimension > 32");
+    hipLaunchKernelGGL(jko_finish_kernel, dim3((unsigned)((K * dd + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    HIPCK(ctx, hipGetLastError());
+  }
+  GVICK(ngd_scatter(ctx, g.cur, g.gcur));
+  g.grad_valid = true;
+  g.grad_slot = g.cur;
+  return GVI_OK;
+}
+
+// trial of the proximal rule: mu + step dmu, Lam + step dprecision (proxgd/ProxGVI-GH-impl.h:24-41)
+gvi_status gvi_prox_trial(gvi_ctx* ctx, double step, double* new_cost) {
+  GVICK(ngd_check(ctx));
+  if (ctx->update_rule != GVI_RULE_PROX_JKO) return fail(ctx, GVI_ERR_STATE, "call gvi_ngd_set_update_rule(GVI_RULE_PROX_JKO) first");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  if (!(g.grad_valid && g.grad_slot == g.cur)) return fail(ctx, GVI_ERR_STATE, "call gvi_prox_gradients first");
+  const size_t Tn = (size_t)ctx->T * ctx->n, bt = bt_count(ctx);
+  const int c = g.cur, t = 1 - c;
+  const double* ex = g.exch0[g.gcur].d();
+  hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((Tn + bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)Tn, (int64_t)bt,
+                     step, g.mu[c].d(), ex, g.Lam[c].d(), ex + Tn, g.mu[t].d(), g.Lam[t].d(), 1);
+  HIPCK(ctx, hipGetLastError());
+  g.cost_valid[t] = false;
+  GVICK(ngd_refresh(ctx, t));
+  g.have_trial = true;
+  GVICK(ngd_cost_local(ctx, t));
+  return ngd_cost_finish(ctx, t, new_cost);
+}
+
+// ProxGVIGH::optimize body (proxgd/ProxGVI-GH-impl.h:121-202): gradients once at step = base, trial B uses base^B,
+// the first decreasing trial is accepted; after max_backtrack failures the last trial is accepted anyway (:177-184)
+gvi_status gvi_prox_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter, int* decreased,
+                         double* new_cost, int* ntrials) {
+  GVICK(ngd_check(ctx));
+  if (ctx->update_rule != GVI_RULE_PROX_JKO) return fail(ctx, GVI_ERR_STATE, "call gvi_ngd_set_update_rule(GVI_RULE_PROX_JKO) first");
+  double c0 = 0.0;
+  GVICK(gvi_ngd_cost(ctx, &c0));
+  if (cost_iter) *cost_iter = c0;
+  GVICK(gvi_prox_gradients(ctx, step_size_base));
+  int B = 1, cnt = 0, ok = 0;
+  double c1 = c0;
+  while (true) {
+    GVICK(gvi_prox_trial(ctx, std::pow(step_size_base, B), &c1));
+    ok = c1 < c0;
+    if (!ok) { ++B; ++cnt; }
+    if (ok || cnt > max_backtrack) { GVICK(gvi_ngd_accept(ctx)); break; }
+  }
+  if (decreased) *decreased = ok;
+  if (new_cost) *new_cost = c1;
+  if (ntrials) *ntrials = cnt + (ok ? 1 : 0);
   return GVI_OK;
 }
 

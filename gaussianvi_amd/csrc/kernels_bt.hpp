@@ -726,17 +726,18 @@ __global__ __launch_bounds__(256) void cost_sum_all_kernel(SetList L, double* ac
   if (threadIdx.x == 0) acc[0] = total;
 }
 
-// trial point in one launch: mu_t = mu + step dmu ; Lam_t = Lam + step (V - Lam)
+// trial point in one launch: mu_t = mu + step dmu ; Lam_t = Lam + step (V - Lam)   (NGD: dprecision = Vddmu - Lam)
+// direct = 1 (proximal update): V already is dprecision, Lam_t = Lam + step V
 __global__ __launch_bounds__(256) void trial_kernel(int64_t nmu, int64_t nlam, double step, const double* __restrict__ mu,
                                                     const double* __restrict__ dmu, const double* __restrict__ lam,
                                                     const double* __restrict__ V, double* __restrict__ mu_t,
-                                                    double* __restrict__ lam_t) {
+                                                    double* __restrict__ lam_t, int direct = 0) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < nmu) mu_t[i] = mu[i] + step * dmu[i];
   else if (i < nmu + nlam) {
     const int64_t j = i - nmu;
     const double l = lam[j];
-    lam_t[j] = l + step * (V[j] - l);
+    lam_t[j] = direct ? l + step * V[j] : l + step * (V[j] - l);
   }
 }
 

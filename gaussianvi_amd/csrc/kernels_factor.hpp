@@ -59,6 +59,7 @@ struct FactorDev {
   const double* sdf;        // HINGE_SDF_2D: column-major rows x cols signed-distance grid
   int sdf_rows, sdf_cols, sdf_nz;
   double sdf_ox, sdf_oy, sdf_oz, sdf_cell;
+  double jko_h;             // > 0: the third spectral output is the JKO map 1 / (l/2 + h + sqrt(l (l + 4h))/2) instead of 1/l
   double* Vws;              // [K][d][d] eigenvectors of the previous prep (warm start) or null
   int warm;                 // 1: start the Jacobi sweeps from Vws (resident NGD iteration only)
 };
@@ -226,7 +227,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
     const double l = A[lane * d + lane];
     lam[lane] = sqrt(l);               // negative eigenvalue -> NaN, as the reference's operatorSqrt
     lam[d + lane] = 1.0 / sqrt(l);
-    lam[2 * d + lane] = 1.0 / l;
+    lam[2 * d + lane] = f.jko_h > 0.0 ? 1.0 / (0.5 * l + f.jko_h + 0.5 * sqrt(l * (l + 4.0 * f.jko_h))) : 1.0 / l;
   }
   wave_lds_sync();
   // S, S^-1, Lam = V f(lambda) V^T; S is also kept in LDS (An) for H = A_k S
@@ -273,6 +274,61 @@ __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __r
                                                   const double* __restrict__ Sigma) {
   extern __shared__ double sm[];
   prep_body<EPLP>(f, mu, Sigma, blockIdx.x, sm, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Proximal (JKO) update, factor level: ProxGVIFactorizedBaseGH::compute_BW_grads + BW_JKO
+// (proxgd/ProxGVIFactorizedBaseGH.h:64-113, 152-160).  The quadrature moments are the NGD ones
+// (b = Vdmu, S = Vddmu at unit temperature), so the map is three small launches around the prep kernel:
+//   jko_half:   Sig_half = (I - h S) Sigma (I - h S)^T,  Vdmu <- -b
+//   prep (jko_h = h) on Sig_half:  Lam_new = W diag(1 / (l/2 + h + sqrt(l (l + 4h))/2)) W^T
+//   jko_finish: Vddmu <- (Lam_new - Lam) / h
+// ---------------------------------------------------------------------------------------------
+struct JkoArgs {
+  int K, d;
+  double h;
+  double* Vdmu;          // [K][d]     in: b, out: -b
+  double* Vddmu;         // [K][d][d]  in: S, out: (Lam_new - Lam) / h
+  const double* Sigma;   // [K][d][d]
+  const double* Lam;     // [K][d][d]
+  double* Shalf;         // [K][d][d]
+  const double* LamNew;  // [K][d][d]
+};
+
+__global__ __launch_bounds__(64) void jko_half_kernel(JkoArgs a) {
+  extern __shared__ double sm[];
+  const int d = a.d, dd = d * d, k = blockIdx.x, lane = threadIdx.x;
+  double* M = sm;            // I - h S
+  double* Sg = M + dd;
+  double* Tm = Sg + dd;      // M Sigma
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    M[e] = (i == j ? 1.0 : 0.0) - a.h * a.Vddmu[(size_t)k * dd + e];
+    Sg[e] = a.Sigma[(size_t)k * dd + e];
+  }
+  for (int e = lane; e < d; e += 64) a.Vdmu[(size_t)k * d + e] = -a.Vdmu[(size_t)k * d + e];
+  wave_lds_sync();
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    double s = 0.0;
+    for (int c = 0; c < d; ++c) s += M[i * d + c] * Sg[c * d + j];
+    Tm[e] = s;
+  }
+  wave_lds_sync();
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    if (i <= j) {                                           // upper triangle, mirrored: exactly symmetric
+      double s = 0.0;
+      for (int c = 0; c < d; ++c) s += Tm[i * d + c] * M[j * d + c];
+      a.Shalf[(size_t)k * dd + i * d + j] = s;
+      a.Shalf[(size_t)k * dd + j * d + i] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void jko_finish_kernel(JkoArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < (int64_t)a.K * a.d * a.d) a.Vddmu[i] = (a.LamNew[i] - a.Lam[i]) / a.h;
 }
 
 // every factor set of the problem in ONE launch: block -> (set, factor) through the offsets

@@ -197,6 +197,25 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
  *              also the next iteration's gradient pass (one psi pass per accepted iteration instead of
  *              the reference's cost pass + gradient pass); 0 (default): separate passes as the reference. */
 gvi_status gvi_ngd_set_mode(gvi_ctx* ctx, int speculate, int fuse_trial);
+
+/* ---- proximal (JKO / Bures-Wasserstein) update rule: ProxGVIGH + ProxGVIFactorizedBaseGH
+ *      (proxgd/ProxGVI-GH-impl.h:24-60, 121-202; proxgd/ProxGVIFactorizedBaseGH.h:64-113, 152-160).  Same quadrature
+ *      moments as the natural-gradient path; per factor b = Lam E[(x-mu)psi], S = Lam E[(x-mu)(x-mu)^T psi] Lam - Lam E[psi],
+ *      Sig_half = (I - h S) Sigma (I - h S)^T, Sigma_new = Sig_half/2 + h I + sqrtm(Sig_half (Sig_half + 4hI))/2,
+ *      Vdmu = -b, Vddmu = (Sigma_new^-1 - Lam)/h; the joint dmu / dprecision are their plain scattered sums (no solve).
+ *      The reference's prox classes never divide by the temperature: selecting the rule switches every set to unit
+ *      temperature.  Single process only.
+ * gvi_ngd_set_update_rule: GVI_RULE_NGD (default) or GVI_RULE_PROX_JKO; state set by gvi_ngd_init is kept.
+ * gvi_prox_gradients(h): increments at the current proposal for step h (read back with gvi_ngd_get_gradients:
+ *      dmu = gq, dprecision = (VD, VU)).   gvi_prox_trial(step): cost at mu + step dmu, Lam + step dprecision.
+ * gvi_prox_step: one optimize() iteration -- gradients at h = base, trial B at base^B, first decreasing trial accepted,
+ *      the last one accepted anyway after max_backtrack failures (decreased = 0 then). */
+enum { GVI_RULE_NGD = 0, GVI_RULE_PROX_JKO = 1 };
+gvi_status gvi_ngd_set_update_rule(gvi_ctx* ctx, int rule);
+gvi_status gvi_prox_gradients(gvi_ctx* ctx, double h);
+gvi_status gvi_prox_trial(gvi_ctx* ctx, double step, double* new_cost);
+gvi_status gvi_prox_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter, int* decreased,
+                         double* new_cost, int* ntrials);
 /* Split forms for sharded factors (one process per GPU): *_local does the rank's factors and leaves
  * the partial sums in the exchange buffer; the caller all-reduces gvi_ngd_exchange() over the ranks
  * (RCCL); *_finish does the replicated chain work.  Single GPU: local; finish. */

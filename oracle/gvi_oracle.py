@@ -941,3 +941,85 @@ class ChainNGD:
             cnt += 1
             if cnt > self.max_backtrack:
                 return False, cost_iter, cnt
+
+
+# --------------------------------------------------------------------------------------------
+# Proximal (JKO / Bures-Wasserstein) update -- SURVEY 8(f)4.  Same quadrature moments as the NGD path; the
+# factor-level map and the joint loop follow proxgd/ProxGVIFactorizedBaseGH.h and proxgd/ProxGVI-GH-impl.h.
+# --------------------------------------------------------------------------------------------
+def bw_jko(mu, Sigma, Lam, E_phi, E_xmuphi, E_xxphi, h):
+    """compute_BW_grads + BW_JKO for one factor (proxgd/ProxGVIFactorizedBaseGH.h:64-113, 152-160):
+    b = Lam E[(x-mu) psi];  S = Lam E[(x-mu)(x-mu)^T psi] Lam - Lam E[psi];  M = I - h S;
+    Sig_half = M Sigma M^T;  Sigma_new = Sig_half/2 + h I + sqrtm(Sig_half (Sig_half + 4 h I))/2;
+    Vdmu = -b (= (mu_new - mu)/h), Vddmu = (Sigma_new^-1 - Lam)/h.  Sig_half commutes with Sig_half + 4hI, so the
+    product is symmetric PSD and the reference's Schur-based sqrtm (:213-243) is the symmetric square root."""
+    d = mu.shape[0]
+    b = Lam @ E_xmuphi
+    S = Lam @ E_xxphi @ Lam - Lam * E_phi
+    M = np.eye(d) - h * S
+    Sh = M @ Sigma @ M.T
+    lam, W = np.linalg.eigh(0.5 * (Sh + Sh.T))
+    with np.errstate(invalid="ignore"):
+        root = np.sqrt(lam * (lam + 4.0 * h))
+    new = 0.5 * lam + h + 0.5 * root
+    Lam_new = (W / new) @ W.T
+    return -b, (Lam_new - Lam) / h
+
+
+class ChainProx:
+    """ProxGVIGH::optimize (proxgd/ProxGVI-GH-impl.h:121-202) on a chain.  Differences from ChainNGD restated from
+    the source: gradients are the scattered sums of the factor-level JKO increments computed ONCE at step = base
+    (:149-151), dmu is used directly (no solve, :30-31), the step of trial B is base**B (:160), the raw integrals are
+    not divided by the temperature (ProxGVIFactorizedBaseGH.h:152-160, 245-252), and after max_backtrack failed
+    trials the last trial is accepted anyway (:177-184)."""
+
+    def __init__(self, T, n, sets, mu0, D0, U0, step_size_base=0.55, max_backtrack=10):
+        self.T, self.n, self.sets = T, n, sets
+        self.mu = np.asarray(mu0, dtype=np.float64).reshape(T, n).copy()
+        self.D, self.U = D0.copy(), U0.copy()
+        self.step_size_base, self.max_backtrack = step_size_base, max_backtrack
+        self.SigD, self.SigU = inverse_gbp(self.D, self.U)
+
+    def factor_costs(self, mu, SigD, SigU):
+        out = []
+        for fs in self.sets:
+            mk, Sk = gather_marginals(mu, SigD, SigU, fs.start, fs.d)
+            out.append(batched_moments(fs.Z, fs.w, mk, Sk, fs.psi_batch, 1.0)["E_phi"])
+        return out
+
+    def cost_value(self, mu, D, U, SigD=None, SigU=None):
+        if SigD is None:
+            SigD, SigU = inverse_gbp(D, U)
+        return sum(c.sum() for c in self.factor_costs(mu, SigD, SigU)) + logdet_half(bt_ldlt_pivots(D, U))
+
+    def gradients(self, h):
+        parts = []
+        for fs in self.sets:
+            mk, Sk = gather_marginals(self.mu, self.SigD, self.SigU, fs.start, fs.d)
+            r = batched_moments(fs.Z, fs.w, mk, Sk, fs.psi_batch, 1.0)
+            K = mk.shape[0]
+            Vd = np.zeros((K, fs.d)); Vdd = np.zeros((K, fs.d, fs.d))
+            for k in range(K):
+                Vd[k], Vdd[k] = bw_jko(mk[k], Sk[k], np.linalg.inv(Sk[k]), r["E_phi"][k], r["E_xmuphi"][k], r["E_xxphi"][k], h)
+            parts.append((fs.start, Vd, Vdd))
+        g, Dv, Uv = bt_assemble(self.T, self.n, parts)
+        return g, Dv, Uv
+
+    def step(self):
+        """One iteration.  Returns (decreased, cost after the update, n_trials)."""
+        cost_iter = self.cost_value(self.mu, self.D, self.U, self.SigD, self.SigU)
+        dmu, dD, dU = self.gradients(self.step_size_base)
+        B, cnt = 1, 0
+        while True:
+            step = self.step_size_base ** B
+            mu, D, U = self.mu + step * dmu, self.D + step * dD, self.U + step * dU
+            SigD, SigU = inverse_gbp(D, U)
+            new_cost = self.cost_value(mu, D, U, SigD, SigU)
+            ok = bool(new_cost < cost_iter)
+            if not ok:
+                B += 1
+                cnt += 1
+            if ok or cnt > self.max_backtrack:
+                self.mu, self.D, self.U, self.SigD, self.SigU = mu, D, U, SigD, SigU     # accepted even when not decreased
+                return ok, new_cost, cnt + (1 if ok else 0)
+

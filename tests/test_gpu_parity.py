@@ -650,6 +650,52 @@ def test_side_stream_solve_gives_identical_iterates(monkeypatch):
     assert np.array_equal(s0["mu"], s1["mu"]) and np.array_equal(s0["D"], s1["D"])
 
 
+def test_prox_jko_golden_trace_on_device(golden_dir):
+    """the reference's committed proximal-GVI run (src/1d_example_proxGVI.cpp -> data/1d_proxgvi/*.csv,
+    10 iterations, base step 0.75) reproduced through gvi_prox_step."""
+    g = os.path.join(golden_dir, "ref_1d_proxgvi")
+    mean = np.loadtxt(os.path.join(g, "mean.csv"), delimiter=",").ravel()
+    prec = np.loadtxt(os.path.join(g, "precision.csv"), delimiter=",").ravel()
+    cost = np.loadtxt(os.path.join(g, "cost.csv")).ravel()
+    y = 400 * 0.1 / 20 - 0.8
+    ctx, sid = single_set_ctx(api.PSI_RANGE_1D, 1, 1, 10, 1, np.array([[y, 20.0, 40.0, 0.09, 9.0]]))
+    ctx.ngd_set_update_rule(api.RULE_PROX_JKO)
+    ctx.ngd_init(np.array([[20.0]]), np.array([[[1.0 / 9.0]]]), np.zeros((0, 1, 1)))
+    with pytest.raises(api.GviError):
+        ctx.ngd_step(0.75, 10)                                   # the NGD loop refuses the proximal rule
+    for it in range(10):
+        st = ctx.ngd_get_state()
+        assert abs(st["mu"][0, 0] - mean[it]) < 1e-9 and abs(st["D"][0, 0, 0] - prec[it]) < 1e-10
+        r = ctx.prox_step(0.75, 10)
+        assert abs(r["cost_iter"] - cost[it]) < 1e-10
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "c2"])
+def test_prox_jko_chain_vs_oracle(name):
+    """The factor-level JKO map on d = 4 and d = 2 blocks (Jacobi spectral map of Sig_half), plain scattered sums and
+    the base^B line search against the oracle's restatement (oracle/gvi_oracle.py::ChainProx)."""
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_set_update_rule(api.RULE_PROX_JKO)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    chain = o.ChainProx(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"], step_size_base=0.55)
+    ctx.prox_gradients(0.55)
+    gr = ctx.ngd_get_gradients()
+    g, Dv, Uv = chain.gradients(0.55)
+    assert rel(gr["g"], g) < TIGHT and rel(gr["VD"], Dv) < 1e-8 and rel(gr["VU"], Uv) < 1e-8
+    for it in range(3):
+        r = ctx.prox_step(0.55, 10)
+        ok, cost, ntr = chain.step()
+        assert r["decreased"] == ok and r["ntrials"] == ntr
+        assert np.isclose(r["new_cost"], cost, rtol=1e-9)
+        st = ctx.ngd_get_state()
+        assert rel(st["mu"], chain.mu) < RTOL / 10 and rel(st["D"], chain.D) < RTOL / 10
+    ctx.ngd_set_update_rule(api.RULE_NGD)                         # back to the natural-gradient loop on the same state
+    assert ctx.ngd_step(0.55, 10)["accepted"] in (True, False)
+    ctx.close()
+
+
 def test_linesearch_rejects_nan_and_backtracks():
     """A huge base step makes the trial precision indefinite: log-det NaN -> rejected -> backtrack
     (gvibase/GVI-GH-impl.h:92-117 with the NaN rule of section 3.1)."""

@@ -153,3 +153,30 @@ def test_k9_degree2_is_not_exact_for_vddmu():
     _, _, Vddmu = o.linear_factor_closed_form(mu, Sigma, np.linalg.inv(Sigma),
                                               np.hstack([-Phi, np.eye(2)]), Qinv, np.zeros(2), 0.5, 1.0)
     assert np.abs(fac._Vddmu - Vddmu).max() > 1e-2 * np.abs(Vddmu).max()
+
+
+def test_prox_jko_reference_trace(golden_dir):
+    """SURVEY 8(f)4 pin: the oracle's proximal (JKO) restatement reproduces the reference's committed 1-D prox run
+    data/1d_proxgvi/{mean,precision,cost,factor_costs}.csv (src/1d_example_proxGVI.cpp, 10 iterations)."""
+    import os
+    g = os.path.join(golden_dir, "ref_1d_proxgvi")
+    mean = np.loadtxt(os.path.join(g, "mean.csv"), delimiter=",").ravel()
+    prec = np.loadtxt(os.path.join(g, "precision.csv"), delimiter=",").ravel()
+    cov = np.loadtxt(os.path.join(g, "cov.csv"), delimiter=",").ravel()
+    cost = np.loadtxt(os.path.join(g, "cost.csv")).ravel()
+    fc = np.loadtxt(os.path.join(g, "factor_costs.csv"), delimiter=",").ravel()
+
+    class FS:
+        pass
+    fs = FS()
+    fs.d, fs.start = 1, np.array([0])
+    fs.Z, fs.w = o.nwspgr(1, 10)
+    fs.psi_batch = o.psi_batch_range_1d(400 * 0.1 / 20 - 0.8)
+    ch = o.ChainProx(1, 1, [fs], np.array([[20.0]]), np.array([[[1 / 9.0]]]), np.zeros((0, 1, 1)), step_size_base=0.75)
+    for it in range(10):
+        c = ch.cost_value(ch.mu, ch.D, ch.U, ch.SigD, ch.SigU)
+        f = ch.factor_costs(ch.mu, ch.SigD, ch.SigU)[0][0]
+        assert abs(ch.mu[0, 0] - mean[it]) < 1e-12 and abs(ch.D[0, 0, 0] - prec[it]) < 1e-14
+        assert abs(ch.SigD[0, 0, 0] - cov[it]) < 1e-12 and abs(c - cost[it]) < 1e-13 and abs(f - fc[it]) < 1e-13
+        ch.step()
+
