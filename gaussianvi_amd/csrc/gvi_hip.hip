@@ -136,9 +136,9 @@ struct gvi_ctx {
   bool profile = false;
   bool profile_all = false;           // events around every moments / cost launch (else: set 0, full pass only)
   int target_waves = 2048;
-  bool no_scost = false;    // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
-  int cost_chunk_mult = 8;
-  int scost_f = 2;          // factors per wave of the cost kernel (2 or 4)  // cost pass of the F-factor kernel: chunks per factor relative to the full pass
+  bool no_scost = false;              // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
+  int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
+  int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
   // run_moments in planning mode: the launch that WOULD be issued is recorded instead (pair fusion of two sets)
   struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; };
   Deferred* defer = nullptr;
