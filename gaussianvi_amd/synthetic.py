@@ -21,6 +21,8 @@ CONFIGS = {
     "c2": (2, 65, 2, 3, "minacc"),          # BASELINE.json configs[1]
     "c3mini": (31, 9, 6, 5, "ltv"),
     "c3small": (32, 33, 6, 5, "ltv"),
+    "c3t2": (33, 2, 6, 5, "ltv"),           # shortest chains: one / two prior factors (tail blocks of the fused launches)
+    "c3t3": (34, 3, 6, 5, "ltv"),
     "c3": (3, 1025, 6, 5, "ltv"),           # BASELINE.json configs[2] (headline)
     "c5mini": (51, 5, 12, 5, "ltv"),        # d = 24 slice (split kernel), N(24,5) = 243 905
     "c5small": (52, 33, 12, 6, "ltv", 5),   # d = 24, p = 6: N = 2 438 801; unary factors at p = 5

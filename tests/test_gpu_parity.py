@@ -587,7 +587,7 @@ def test_chain_step_golden(golden_dir, name):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,iters", [("c2", 3), ("c3small", 2), ("c5mini", 2)])
+@pytest.mark.parametrize("name,iters", [("c2", 3), ("c3small", 2), ("c5mini", 2), ("c3t2", 3), ("c3t3", 3)])
 def test_ngd_iterations_vs_oracle(name, iters):
     """BASELINE configs[1] (64-factor d=4 p=3 chain) in full, a 32-factor slice of the headline
     d=12 p=5 LTV chain, and a 4-factor slice of configs[4] (d=24, n=12; split kernel, 244k sigma points per
