@@ -121,6 +121,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    from gaussianvi_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):          # checkout without build artefacts: build once (rank 0 first)
+        if rank == 0:
+            build.build_lib()
+        if use_pg:
+            dist.barrier()
     from gaussianvi_amd import api, synthetic
     from gaussianvi_amd.dist import HipEngine, ShardedNGD, shard_chain
 
