@@ -36,6 +36,8 @@ SIGNATURES = {
     "gvi_prox_step": [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "gvi_factors_set_closed_form": [C.c_void_p, C.c_int, C.c_int],
     "gvi_factors_set_sdf3d": [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "gvi_factors_set_arm": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                            C.c_void_p, C.c_void_p],
     "gvi_factors_set_temperature": [C.c_void_p, C.c_int, C.c_void_p],
     "gvi_factors_info": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                          C.POINTER(C.c_int64)],

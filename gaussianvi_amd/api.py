@@ -10,7 +10,7 @@ import numpy as np
 from . import _lib
 
 PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK, PSI_HINGE_SDF_2D = 0, 1, 2, 3, 4
-PSI_HINGE_SDF_2D_BODY, PSI_HINGE_SDF_3D = 5, 6
+PSI_HINGE_SDF_2D_BODY, PSI_HINGE_SDF_3D, PSI_HINGE_SDF_3D_ARM = 5, 6, 7
 RULE_NGD, RULE_PROX_JKO = 0, 1
 GVI_F64, GVI_F32 = 0, 1
 
@@ -147,6 +147,13 @@ class Context:
         o3 = _f64(np.asarray(origin, dtype=np.float64))
         self._ck(self.lib.gvi_factors_set_sdf3d(self.h, sid, _p(o3), float(cell_size), f.shape[0], f.shape[1], f.shape[2],
                                                 f.ctypes.data_as(C.c_void_p)))
+
+    def factors_set_arm(self, sid, arm):
+        """arm: dict(a, alpha, d, theta_bias [ndof], frames [ns] int, centers [ns,3], radii [ns])."""
+        f = lambda k: _f64(np.asarray(arm[k], dtype=np.float64))
+        a_, al, d_, tb, ce, ra = f("a"), f("alpha"), f("d"), f("theta_bias"), f("centers"), f("radii")
+        fr = np.ascontiguousarray(arm["frames"], dtype=np.int32)
+        self._ck(self.lib.gvi_factors_set_arm(self.h, sid, len(a_), _p(a_), _p(al), _p(d_), _p(tb), len(fr), _p(fr), _p(ce), _p(ra)))
 
     def factors_set_closed_form(self, sid, on=True):
         self._ck(self.lib.gvi_factors_set_closed_form(self.h, sid, int(on)))
@@ -352,6 +359,8 @@ def context_for_chain(chain, device=0, specs=None):
                                    spec["temperature"]))
         if spec["kind"] in (PSI_HINGE_SDF_2D, PSI_HINGE_SDF_2D_BODY):
             ctx.factors_set_sdf2d(ids[-1], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
-        if spec["kind"] == PSI_HINGE_SDF_3D:
+        if spec["kind"] in (PSI_HINGE_SDF_3D, PSI_HINGE_SDF_3D_ARM):
             ctx.factors_set_sdf3d(ids[-1], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
+        if spec["kind"] == PSI_HINGE_SDF_3D_ARM:
+            ctx.factors_set_arm(ids[-1], spec["arm"])
     return ctx, ids

@@ -58,7 +58,8 @@ struct FactorSet {
   DevMem ones;                        // [K] unit temperatures (proximal rule: the reference's prox classes never divide by T)
   bool unit_temperature = false;
   DevMem jko_half, jko_S, jko_Sinv, jko_Lam;   // scratch of the JKO map
-  DevMem sdf;                         // HINGE_SDF_2D grid
+  DevMem sdf;                         // HINGE_SDF_* grid
+  DevMem arm;                         // HINGE_SDF_3D_ARM: DH chain + collision spheres
   int sdf_rows = 0, sdf_cols = 0, sdf_nz = 1;
   double sdf_ox = 0, sdf_oy = 0, sdf_oz = 0, sdf_cell = 1;
   DevMem Vws;                         // eigenvectors of the last resident-NGD prep (Jacobi warm start)
@@ -93,7 +94,7 @@ struct FactorSet {
     f.temperature = unit_temperature ? ones.d() : temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.Hq = Hq.p ? Hq.d() : nullptr; f.u0 = u0.d();
     f.Vws = nullptr; f.warm = 0; f.jko_h = 0.0;
-    f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz;
+    f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz; f.arm = arm.p ? arm.d() : nullptr;
     return f;
   }
 };
@@ -454,6 +455,8 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
 gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full,
                        hipStream_t st = nullptr) {
   if (!st) st = c->stream;
+  if (s.kind == KIND_HINGE_SDF_3D_ARM && !psi_ext && !s.arm.p)
+    return fail(c, GVI_ERR_STATE, "HINGE_SDF_3D_ARM set without an arm model: call gvi_factors_set_arm");
   if (s.kind >= KIND_HINGE_SDF_2D && !psi_ext && s.sdf_rows == 0)
     return fail(c, GVI_ERR_STATE, "HINGE_SDF set without a grid: call gvi_factors_set_sdf2d / gvi_factors_set_sdf3d");
   bool reg = reg_supported(s.kind, s.d, s.m) && !psi_ext && c->variant != 1;
@@ -961,6 +964,7 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
     case GVI_PSI_HINGE_SDF_2D: if (d < 2) return fail(ctx, GVI_ERR_ARG, "HINGE_SDF_2D needs d >= 2"); need = 3; break;
     case GVI_PSI_HINGE_SDF_2D_BODY: if (d < 3) return fail(ctx, GVI_ERR_ARG, "HINGE_SDF_2D_BODY needs d >= 3"); need = 6; break;
     case GVI_PSI_HINGE_SDF_3D: if (d < 3) return fail(ctx, GVI_ERR_ARG, "HINGE_SDF_3D needs d >= 3"); need = 3; break;
+    case GVI_PSI_HINGE_SDF_3D_ARM: need = 2; break;
     default: return fail(ctx, GVI_ERR_ARG, "unknown psi kind");
   }
   if (need > 0 && (!psi_params || params_per_factor < need))
@@ -1099,7 +1103,8 @@ gvi_status gvi_factors_set_sdf3d(gvi_ctx* ctx, int set_id, const double* origin,
                                  int nz, const double* data) {
   FactorSet* s = get_set(ctx, set_id);
   if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
-  if (s->kind != KIND_HINGE_SDF_3D) return fail(ctx, GVI_ERR_ARG, "set is not GVI_PSI_HINGE_SDF_3D");
+  if (s->kind != KIND_HINGE_SDF_3D && s->kind != KIND_HINGE_SDF_3D_ARM)
+    return fail(ctx, GVI_ERR_ARG, "set is not GVI_PSI_HINGE_SDF_3D / _3D_ARM");
   if (rows < 2 || cols < 2 || nz < 2 || !(cell_size > 0) || !data || !origin) return fail(ctx, GVI_ERR_ARG, "bad grid");
   HIPCK(ctx, hipSetDevice(ctx->device));
   GVICK(sync(ctx));
@@ -1108,6 +1113,33 @@ gvi_status gvi_factors_set_sdf3d(gvi_ctx* ctx, int set_id, const double* origin,
   HIPCK(ctx, hipMemcpy(s->sdf.p, data, bytes, hipMemcpyHostToDevice));
   s->sdf_rows = rows; s->sdf_cols = cols; s->sdf_nz = nz;
   s->sdf_ox = origin[0]; s->sdf_oy = origin[1]; s->sdf_oz = origin[2]; s->sdf_cell = cell_size;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_factors_set_arm(gvi_ctx* ctx, int set_id, int ndof, const double* a, const double* alpha, const double* d,
+                               const double* theta_bias, int nspheres, const int32_t* frames, const double* centers,
+                               const double* radii) {
+  FactorSet* s = get_set(ctx, set_id);
+  if (!s) return fail(ctx, GVI_ERR_ARG, "bad set id");
+  if (s->kind != KIND_HINGE_SDF_3D_ARM) return fail(ctx, GVI_ERR_ARG, "set is not GVI_PSI_HINGE_SDF_3D_ARM");
+  if (ndof < 1 || ndof > s->d || nspheres < s->d || !a || !alpha || !d || !theta_bias || !frames || !centers || !radii)
+    return fail(ctx, GVI_ERR_ARG, "bad arm model (need 1 <= ndof <= factor dimension <= nspheres: n_balls = factor dimension)");
+  for (int q = 0; q < nspheres; ++q)
+    if (frames[q] < 0 || frames[q] >= ndof || (q && frames[q] < frames[q - 1]))
+      return fail(ctx, GVI_ERR_ARG, "sphere frames must be non-decreasing and < ndof");
+  std::vector<double> pk;
+  pk.push_back(ndof); pk.push_back(nspheres);
+  pk.insert(pk.end(), a, a + ndof); pk.insert(pk.end(), alpha, alpha + ndof);
+  pk.insert(pk.end(), d, d + ndof); pk.insert(pk.end(), theta_bias, theta_bias + ndof);
+  for (int q = 0; q < nspheres; ++q) pk.push_back(frames[q]);
+  pk.insert(pk.end(), centers, centers + 3 * (size_t)nspheres);
+  pk.insert(pk.end(), radii, radii + nspheres);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  HIPCK(ctx, s->arm.ensure(pk.size() * 8));
+  HIPCK(ctx, hipMemcpy(s->arm.p, pk.data(), pk.size() * 8, hipMemcpyHostToDevice));
   ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
   ctx->ngd.grad_valid = false;
   return GVI_OK;

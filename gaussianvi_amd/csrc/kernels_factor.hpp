@@ -27,7 +27,7 @@
 namespace gvi {
 
 enum { KIND_RANGE_1D = 0, KIND_QUAD_PRIOR = 1, KIND_FIXED_PRIOR = 2, KIND_HOST_CALLBACK = 3, KIND_HINGE_SDF_2D = 4,
-       KIND_HINGE_SDF_2D_BODY = 5, KIND_HINGE_SDF_3D = 6 };
+       KIND_HINGE_SDF_2D_BODY = 5, KIND_HINGE_SDF_3D = 6, KIND_HINGE_SDF_3D_ARM = 7 };
 
 __host__ __device__ inline int npairs(int d) { return (d + 1) * (d + 2) / 2; }
 
@@ -59,6 +59,7 @@ struct FactorDev {
   const double* sdf;        // HINGE_SDF_2D: column-major rows x cols signed-distance grid
   int sdf_rows, sdf_cols, sdf_nz;
   double sdf_ox, sdf_oy, sdf_oz, sdf_cell;
+  const double* arm;        // HINGE_SDF_3D_ARM: [ndof, ns, a[ndof], alpha[ndof], d[ndof], bias[ndof], frame[ns], centre[ns][3], radius[ns]]
   double jko_h;             // > 0: the third spectral output is the JKO map 1 / (l/2 + h + sqrt(l (l + 4h))/2) instead of 1/l
   double* Vws;              // [K][d][d] eigenvectors of the previous prep (warm start) or null
   int warm;                 // 1: start the Jacobi sweeps from Vws (resident NGD iteration only)
@@ -472,6 +473,48 @@ __device__ inline double psi_hinge_sdf3d(const FactorDev& f, const double* p, do
   return hinge_sq(sdf3d_lookup(f, px, py, pz), p[1] + p[2], 1.0, p[0]);
 }
 
+// 7-DOF-style arm (CudaOperation_3dArm::cost_obstacle + ForwardKinematics, helpers/CudaOperation.h:325-399, 752-771):
+// sphere s sits on frame[s] of the DH chain T = prod_{i <= frame} DH(i, x_i + bias_i); n_balls = the factor dimension
+// (theta.size(), :753), cost = sigma sum_s hinge(eps + radius_s - sdf(p_s))^2.  The reference builds every DH matrix
+// from cosf / sinf (single precision, :388-395; products of two trig terms are float products) -- restated as such.
+// Frames are non-decreasing (checked on the host), so the chain is advanced once.  p = [sigma, eps].
+__device__ inline double psi_hinge_sdf3d_arm(const FactorDev& f, const double* p, const double* x, int d) {
+  const double* A = f.arm;
+  const int nd = (int)A[0], ns = (int)A[1];
+  const double *a = A + 2, *al = a + nd, *dl = al + nd, *tb = dl + nd, *fr = tb + nd, *ce = fr + ns, *ra = ce + 3 * ns;
+  double T[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};           // rows 0..2 of the homogeneous transform
+  const int nb = d < ns ? d : ns;
+  int done = -1;                                                  // last joint folded into T
+  double cost = 0.0;
+  for (int s = 0; s < nb; ++s) {
+    const int frame = (int)fr[s];
+    while (done < frame) {
+      const int i = ++done;
+      const float th = (float)(x[i] + tb[i]), alf = (float)al[i];
+      // cosf / sinf of the reference: float in, float out.  Libm's differ in the last float bit; the correctly rounded
+      // value (double trig of the float argument, rounded to float) is the representative, as in the oracle
+      const float c = (float)cos((double)th), sn = (float)sin((double)th), cA = (float)cos((double)alf), sA = (float)sin((double)alf);
+      const double m00 = c, m01 = -sn * cA, m02 = sn * sA, m03 = a[i] * c;
+      const double m10 = sn, m11 = c * cA, m12 = -c * sA, m13 = a[i] * sn;
+      const double m21 = sA, m22 = cA, m23 = dl[i];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double t0 = T[r * 4], t1 = T[r * 4 + 1], t2 = T[r * 4 + 2], t3 = T[r * 4 + 3];
+        T[r * 4] = t0 * m00 + t1 * m10;
+        T[r * 4 + 1] = t0 * m01 + t1 * m11 + t2 * m21;
+        T[r * 4 + 2] = t0 * m02 + t1 * m12 + t2 * m22;
+        T[r * 4 + 3] = t0 * m03 + t1 * m13 + t2 * m23 + t3;
+      }
+    }
+    const double cx = ce[3 * s], cy = ce[3 * s + 1], cz = ce[3 * s + 2];
+    const double px = T[3] + (T[0] * cx + T[1] * cy + T[2] * cz);
+    const double py = T[7] + (T[4] * cx + T[5] * cy + T[6] * cz);
+    const double pz = T[11] + (T[8] * cx + T[9] * cy + T[10] * cz);
+    cost += hinge_sq(sdf3d_lookup(f, px, py, pz), p[1] + ra[s], 1.0, p[0]);
+  }
+  return cost;
+}
+
 // ---------------------------------------------------------------------------------------------
 // moments_generic_kernel: any d (<= 32), any psi kind.  Block = 256 threads handles one factor and a
 // range of points in sub-chunks of 256: stage 1 (thread = point) expands x = mu + S z, evaluates
@@ -593,6 +636,7 @@ __global__ __launch_bounds__(GEN_BS) void moments_generic_kernel(MomArgs a) {
       else if (f.kind == KIND_HINGE_SDF_2D) psi = psi_hinge_sdf2d(f, f.raw + (size_t)k * f.raw_stride, xr[0], xr[1]);
       else if (f.kind == KIND_HINGE_SDF_2D_BODY) psi = psi_hinge_sdf2d_body(f, f.raw + (size_t)k * f.raw_stride, xr[0], xr[1], xr[2]);
       else if (f.kind == KIND_HINGE_SDF_3D) psi = psi_hinge_sdf3d(f, f.raw + (size_t)k * f.raw_stride, xr[0], xr[1], xr[2]);
+      else if (f.kind == KIND_HINGE_SDF_3D_ARM) psi = psi_hinge_sdf3d_arm(f, f.raw + (size_t)k * f.raw_stride, xr, d);
       else {
         for (int r = 0; r < m; ++r) {
           double u = bsh[r];

@@ -13,7 +13,7 @@ from __future__ import annotations
 import numpy as np
 
 PSI_RANGE_1D, PSI_QUAD_PRIOR, PSI_FIXED_PRIOR, PSI_HOST_CALLBACK, PSI_HINGE_SDF_2D = 0, 1, 2, 3, 4
-PSI_HINGE_SDF_2D_BODY, PSI_HINGE_SDF_3D = 5, 6
+PSI_HINGE_SDF_2D_BODY, PSI_HINGE_SDF_3D, PSI_HINGE_SDF_3D_ARM = 5, 6, 7
 
 CONFIGS = {
     # name: (cfg#, T, n, p, prior kind)
@@ -186,8 +186,11 @@ def make_obstacle_chain(kind: str, T=9, p=3, seed=0x5EED + 41):
     state [x, z, phi, vx, vz, w], body of 5 check points, helpers/CudaOperation.h:565-606) and "pr3d" (3-D point
     robot, state [x, y, z, v], trilinear field, :650-683): minimum-acceleration priors (d = 12), one obstacle
     factor per state (d = 6) and two end anchors."""
-    rng = np.random.default_rng(seed + (0 if kind == "quad2d" else 1))
-    n, nd, K = 6, 3, T - 1
+    rng = np.random.default_rng(seed + {"quad2d": 0, "pr3d": 1, "arm7": 2}[kind])
+    nd = 7 if kind == "arm7" else 3
+    n, K = 2 * nd, T - 1
+    if kind == "arm7":
+        p = 3                                    # d = 28 priors: N(28,3) = 1625 sigma points (p = 2 is not exact for Vddmu)
     dt = 0.25
     Phi1, Qinv1 = _minacc(nd, QC, dt)
     Phi, Qinv = np.stack([Phi1] * K), np.stack([Qinv1] * K)
@@ -197,6 +200,12 @@ def make_obstacle_chain(kind: str, T=9, p=3, seed=0x5EED + 41):
         origin, cell = (-6.0, -5.0), 0.1
         field = circle_sdf(origin, cell, 101, 121, [(0.0, 2.2), (-1.0, -3.0)], [1.2, 0.9])
         obst = dict(kind=PSI_HINGE_SDF_2D_BODY, params=np.tile(np.array([[15.5, 0.5, 0.3, 5.0, 5.0, 1.0]]), (T, 1)))
+    elif kind == "arm7":
+        start = np.array([-0.8, 0.5, 0.3, 1.2, -0.4, 0.6, 0.0])
+        goal = np.array([0.7, 0.9, -0.2, 0.8, 0.3, 0.2, 0.4])
+        origin, cell = (-1.5, -1.5, -0.5), 0.05
+        field = sphere_sdf3d(origin, cell, 61, 61, 41, [(0.4, 0.2, 0.5), (-0.3, -0.4, 0.3)], [0.25, 0.2])
+        obst = dict(kind=PSI_HINGE_SDF_3D_ARM, params=np.tile(np.array([[15.5, 0.1]]), (T, 1)), arm=wam_like_arm())
     else:
         start, goal = np.array([-2.0, -0.5, 0.0]), np.array([2.0, 0.5, 0.6])
         origin, cell = (-4.0, -3.0, -2.0), 0.2
@@ -218,12 +227,23 @@ def make_obstacle_chain(kind: str, T=9, p=3, seed=0x5EED + 41):
     specs = [
         dict(kind=PSI_QUAD_PRIOR, d=2 * n, p=p, start=np.arange(K, dtype=np.int32),
              params=np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1), temperature=np.ones(K), Phi=Phi, Qinv=Qinv),
-        dict(d=n, p=p + 1, start=np.arange(T, dtype=np.int32), temperature=np.ones(T),
+        dict(d=n, p=p if kind == "arm7" else p + 1, start=np.arange(T, dtype=np.int32), temperature=np.ones(T),
              sdf_origin=origin, sdf_cell=cell, sdf_field=field, **obst),
         dict(kind=PSI_FIXED_PRIOR, d=n, p=p, start=np.array([0, T - 1], dtype=np.int32),
              params=np.concatenate([anchors, Kinv.reshape(2, -1)], axis=1), temperature=np.ones(2), mu0=anchors, Kinv=Kinv),
     ]
     return dict(name=kind, T=T, n=n, specs=specs, mu0=mu0, D0=D0, U0=U0)
+
+
+def wam_like_arm(nspheres=16):
+    """A 7-DOF arm in DH form (Barrett-WAM-like link lengths) with collision spheres on its frames -- the inputs of
+    the reference's CudaOperation_3dArm / ForwardKinematics (helpers/CudaOperation.h:325-399, 686-716)."""
+    rng = np.random.default_rng(0x5EED + 60)
+    h = np.pi / 2
+    frames = np.array([0, 1, 1, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 6, 6, 6][:nspheres], dtype=np.int32)
+    return dict(a=np.array([0.0, 0.0, 0.045, -0.045, 0.0, 0.0, 0.0]), alpha=np.array([-h, h, -h, h, -h, h, 0.0]),
+                d=np.array([0.0, 0.0, 0.55, 0.0, 0.3, 0.0, 0.06]), theta_bias=np.zeros(7), frames=frames,
+                centers=0.05 * rng.normal(size=(len(frames), 3)), radii=rng.uniform(0.05, 0.12, len(frames)))
 
 
 def random_marginals(rng, K, d, scale=1.0):

@@ -58,10 +58,15 @@ enum { GVI_F64 = 0, GVI_F32 = 1 };
  *   GVI_PSI_HINGE_SDF_3D  [sigma, epsilon, radius]                          d >= 3 (pose = x[0:3])
  *       3-D point robot on a trilinear signed-distance field (CudaOperation_3dpR, helpers/CudaOperation.h:650-683;
  *       SignedDistanceField :133-322); grid by gvi_factors_set_sdf3d
+ *   GVI_PSI_HINGE_SDF_3D_ARM [sigma, epsilon]                               any d >= ndof (joint angles = x[0:ndof])
+ *       arm in DH form with collision spheres on its frames (gvi_factors_set_arm) against a 3-D field
+ *       (gvi_factors_set_sdf3d): CudaOperation_3dArm::cost_obstacle + ForwardKinematics
+ *       (helpers/CudaOperation.h:325-399, 686-771); as there, n_balls = the factor dimension and the DH matrices
+ *       are built from single-precision cosf / sinf
  *   GVI_PSI_HOST_CALLBACK no parameters: psi is an opaque host function (the reference's
  *       std::function, ngd/NGDFactorizedBaseGH.h:30,46-48); use gvi_expand + gvi_moments_from_psi. */
 enum { GVI_PSI_RANGE_1D = 0, GVI_PSI_QUAD_PRIOR = 1, GVI_PSI_FIXED_PRIOR = 2, GVI_PSI_HOST_CALLBACK = 3,
-       GVI_PSI_HINGE_SDF_2D = 4, GVI_PSI_HINGE_SDF_2D_BODY = 5, GVI_PSI_HINGE_SDF_3D = 6 };
+       GVI_PSI_HINGE_SDF_2D = 4, GVI_PSI_HINGE_SDF_2D_BODY = 5, GVI_PSI_HINGE_SDF_3D = 6, GVI_PSI_HINGE_SDF_3D_ARM = 7 };
 
 const char* gvi_version(void);
 /* Message of the last failing call on this context (never NULL). */
@@ -117,6 +122,13 @@ gvi_status gvi_factors_set_sdf2d(gvi_ctx* ctx, int set_id, double origin_x, doub
  * data[r + c * rows + z * rows * cols] (helpers/CudaOperation.h:148-158, 304-306): row = y, col = x, slice = z. */
 gvi_status gvi_factors_set_sdf3d(gvi_ctx* ctx, int set_id, const double* origin, double cell_size, int rows, int cols,
                                  int nz, const double* data);
+/* Arm model of a GVI_PSI_HINGE_SDF_3D_ARM set: ForwardKinematics(a, alpha, d, theta_bias, num_spheres, frames, centers)
+ * + radii (helpers/CudaOperation.h:345-357, 688-716): DH parameters [ndof], sphere q on frame frames[q] (non-decreasing)
+ * with centre centers[q][3] in that frame and radius radii[q]; nspheres >= the factor dimension (the reference reads
+ * n_balls = theta.size() spheres, :753). */
+gvi_status gvi_factors_set_arm(gvi_ctx* ctx, int set_id, int ndof, const double* a, const double* alpha, const double* d,
+                               const double* theta_bias, int nspheres, const int32_t* frames, const double* centers,
+                               const double* radii);
 /* Closed-form route for a QUAD_PRIOR / FIXED_PRIOR set: NGDFactorizedLinear::calculate_partial_V and
  * fact_cost_value (ngd/NGDFactorizedLinear.h:93-129) instead of quadrature -- the factors the reference's
  * classify_factors sends to its linear branch (gvibase/GVI-GH-Cuda-impl.h:31-38).  No sigma points are

@@ -352,6 +352,59 @@ def psi_batch_hinge_sdf3d(params, origin, cell, field):
     return f
 
 
+def arm_sphere_centers(theta, a, alpha, dd, theta_bias, frames, centers):
+    """ForwardKinematics::compute_transformed_sphere_centers (helpers/CudaOperation.h:362-386): for sphere s the
+    chain T = prod_{i <= frames[s]} DH(i, theta_i + bias_i), position = T[:3,3] + T[:3,:3] @ centers[s].
+    dh_matrix (:388-395) evaluates every trig term with cosf / sinf -- SINGLE precision -- and stores the result in a
+    double matrix; restated as float32 trig on the float32-rounded angle.  theta [..., >= ndof] -> [..., ns, 3]."""
+    nd = len(a)
+    shp = theta.shape[:-1]
+    T = np.broadcast_to(np.eye(4), shp + (4, 4)).copy()
+    cum = []
+    # cosf / sinf: float argument, float result.  No two libm's agree on the last float bit (the reference's is CUDA's),
+    # so the representative used here and on the device is the correctly rounded one: double trig of the float
+    # argument, rounded to float.
+    f32 = lambda v: v.astype(np.float64)
+    cosf = lambda v: np.cos(f32(v)).astype(np.float32)
+    sinf = lambda v: np.sin(f32(v)).astype(np.float32)
+    ca = cosf(np.asarray(alpha, dtype=np.float32))
+    sa = sinf(np.asarray(alpha, dtype=np.float32))
+    for i in range(nd):
+        th = (theta[..., i] + theta_bias[i]).astype(np.float32)
+        c, s = cosf(th), sinf(th)                              # float32
+        M = np.zeros(shp + (4, 4))
+        # float * float products stay float32 (-sinf(theta)*cosf(alpha), ...); a(i)*cosf(theta) is double * float
+        M[..., 0, 0], M[..., 0, 1], M[..., 0, 2], M[..., 0, 3] = c, -s * ca[i], s * sa[i], a[i] * c.astype(np.float64)
+        M[..., 1, 0], M[..., 1, 1], M[..., 1, 2], M[..., 1, 3] = s, c * ca[i], -c * sa[i], a[i] * s.astype(np.float64)
+        M[..., 2, 1], M[..., 2, 2], M[..., 2, 3] = sa[i], ca[i], dd[i]
+        M[..., 3, 3] = 1.0
+        T = T @ M
+        cum.append(T)
+    out = np.zeros(shp + (len(frames), 3))
+    for s_, fr in enumerate(frames):
+        Tf = cum[int(fr)]
+        out[..., s_, :] = Tf[..., :3, 3] + np.einsum("...ij,j->...i", Tf[..., :3, :3], centers[s_])
+    return out
+
+
+def psi_batch_hinge_sdf3d_arm(params, arm, origin, cell, field):
+    """CudaOperation_3dArm::cost_obstacle (helpers/CudaOperation.h:752-771): n_balls = theta.size() (the factor
+    dimension), err_i = hinge(eps + radius_i - sdf(p_i)), cost = sigma sum err_i^2.  params [K,2] = (sigma, eps);
+    arm = dict(a, alpha, d, theta_bias, frames, centers [ns,3], radii [ns])."""
+    def f(X, sel=slice(None)):
+        P = params[sel]
+        nb = X.shape[-1]
+        pts = arm_sphere_centers(X, arm["a"], arm["alpha"], arm["d"], arm["theta_bias"], arm["frames"][:nb], arm["centers"][:nb])
+        cost = np.zeros(X.shape[:2])
+        for i in range(nb):
+            sd = sdf3d_lookup(pts[:, :, i, 0], pts[:, :, i, 1], pts[:, :, i, 2], origin, cell, field)
+            thr = P[:, 1][:, None] + arm["radii"][i]
+            err = np.where(sd > thr, 0.0, thr - sd)
+            cost = cost + err * err * P[:, 0][:, None]
+        return cost
+    return f
+
+
 def ltv_phi_q(A_list, B_list, delta_t: float):
     """(Phi, Q) of LTV_GP (gp/LTV_prior.h:123-197): Phi' = A(t) Phi, Q' = A Q + Q A^T + B B^T over
     [0, dt] with A, B piece-wise constant on 4 sub-intervals.  The reference integrates with GSL

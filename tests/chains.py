@@ -12,6 +12,8 @@ def oracle_psi_batch(spec):
         return o.psi_batch_quad_prior(spec["Phi"], spec["Qinv"])
     if spec["kind"] == syn.PSI_FIXED_PRIOR:
         return o.psi_batch_fixed_prior(spec["mu0"], spec["Kinv"])
+    if spec["kind"] == syn.PSI_HINGE_SDF_3D_ARM:
+        return o.psi_batch_hinge_sdf3d_arm(spec["params"], spec["arm"], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
     if spec["kind"] == syn.PSI_HINGE_SDF_2D_BODY:
         return o.psi_batch_hinge_sdf2d_body(spec["params"], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
     if spec["kind"] == syn.PSI_HINGE_SDF_3D:
@@ -39,6 +41,8 @@ def make_chain(name):
         ch = syn.make_planar_chain()
     elif name in ("quad2d", "pr3d"):
         ch = syn.make_obstacle_chain(name)
+    elif name == "arm7":
+        ch = syn.make_obstacle_chain(name, T=5)
     else:
         ch = syn.make_chain(name)
     for spec in ch["specs"]:

@@ -302,20 +302,22 @@ def test_moments_hinge_body_and_3d_vs_oracle(kind, d, p, variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["quad2d", "pr3d"])
+@pytest.mark.parametrize("name", ["quad2d", "pr3d", "arm7"])
 def test_obstacle_chains_vs_oracle(name):
-    """n = 6 planning graphs with the quadrotor-body / 3-D obstacle factors: NGD iterations against the oracle."""
+    """n = 6 planning graphs with the quadrotor-body / 3-D obstacle factors, and a 7-DOF arm graph (n = 14: d = 28
+    priors and d = 14 arm factors on the generic kernel, per-level BCR): NGD iterations against the oracle.  """
     ch = make_chain(name)
     ctx, ids = api.context_for_chain(ch)
     ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
     chain = o.ChainNGD(ch["T"], ch["n"], ch["oracle_sets"](), ch["mu0"], ch["D0"], ch["U0"])
+    ctol, stol = (1e-8, RTOL / 10) if name == "arm7" else (1e-9, RTOL / 10)
     for it in range(4):
         r = ctx.ngd_step(0.55, 10)
         ok, cost, ntr = chain.step()
         assert r["accepted"] == ok and r["ntrials"] == ntr
-        assert np.isclose(r["new_cost"], cost, rtol=1e-9)
+        assert np.isclose(r["new_cost"], cost, rtol=ctol)
     st = ctx.ngd_get_state()
-    assert rel(st["mu"], chain.mu) < RTOL / 10 and rel(st["D"], chain.D) < RTOL / 10 and rel(st["SigD"], chain.SigD) < RTOL / 10
+    assert rel(st["mu"], chain.mu) < stol and rel(st["D"], chain.D) < stol and rel(st["SigD"], chain.SigD) < stol
     assert ctx.ngd_factor_costs(ids[1]).max() > 0
     ctx.close()
 
