@@ -322,6 +322,37 @@ def test_obstacle_chains_vs_oracle(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("d,p", [(7, 2), (14, 2)])
+def test_moments_arm_obstacle_vs_oracle(d, p):
+    """7-DOF arm (DH forward kinematics, collision spheres on the frames, 3-D trilinear field; the reference's fourth
+    obstacle workload, helpers/CudaOperation.h:325-399, 686-771).  The reference builds its DH matrices from
+    single-precision cosf / sinf; device and oracle both use the correctly rounded float value (double trig of the float
+    argument rounded to float), so they agree far below the single-precision noise of the model itself."""
+    rng = np.random.default_rng(700 + d)
+    arm = syn.wam_like_arm()
+    origin, cell = (-1.5, -1.5, -0.5), 0.05
+    field = syn.sphere_sdf3d(origin, cell, 61, 61, 41, [(0.4, 0.2, 0.5), (-0.3, -0.4, 0.3)], [0.25, 0.2])
+    K = 4
+    params = np.column_stack([rng.uniform(5, 20, K), rng.uniform(0.05, 0.2, K)])
+    ctx, sid = single_set_ctx(api.PSI_HINGE_SDF_3D_ARM, d, d, p, K, params)
+    with pytest.raises(api.GviError):
+        ctx.moments(sid, np.zeros((K, d)), np.stack([np.eye(d)] * K))           # neither grid nor arm yet
+    ctx.factors_set_sdf3d(sid, origin, cell, field)
+    with pytest.raises(api.GviError):
+        ctx.factors_set_arm(sid, dict(arm, frames=arm["frames"][::-1]))          # frames must be non-decreasing
+    ctx.factors_set_arm(sid, arm)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.05)
+    mu[:, :7] = rng.uniform(-1.2, 1.2, (K, 7))
+    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == 1
+    Z, w = o.nwspgr(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_hinge_sdf3d_arm(params, arm, origin, cell, field), np.ones(K))
+    assert np.abs(r["E_phi"]).max() > 0.01
+    assert rel(Ephi, r["E_phi"]) < 1e-8 and rel(Vdmu, r["Vdmu"]) < 1e-8 and rel(Vddmu, r["Vddmu"]) < 1e-7
+    assert rel(ctx.costs(sid, mu, Sigma), r["cost"]) < 1e-8
+    ctx.close()
+
+
 def test_k9_golden_fixture(golden_dir):
     """Committed K9 vectors: device GH moments == oracle GH == closed form (ngd/NGDFactorizedLinear.h:93-129)."""
     g = np.load(os.path.join(golden_dir, "k9_moments.npz"))
