@@ -109,6 +109,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device):
+    # GVI_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges through gloo.  Timings of such a run mean nothing.
+    rehearsal = os.environ.get("GVI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
@@ -119,7 +124,10 @@ def main():
     use_pg = world > 1 or "RANK" in os.environ
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from gaussianvi_amd import _lib, build
     if not os.path.exists(_lib.LIB_PATH):          # checkout without build artefacts: build once (rank 0 first)
@@ -247,7 +255,7 @@ def main():
             "value": total_evals / elapsed, "unit": "psi-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, **({"rehearsal": "all ranks on cuda:0, gloo exchange: not a measurement"} if rehearsal else {}), "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {chain['T'] - 1}-factor prior chain, d={d0}, sparse-GH p={p0} (N={N0}), "
                                    f"T={chain['T']} n={chain['n']}, +{chain['T']} unary d={chain['n']} factors; one step = one device-resident NGD iteration "
                                    f"(state re-initialised inside the timed region every {args.restart_every} steps)",
