@@ -61,15 +61,19 @@ def build_examples(force: bool = False) -> str:
     build_lib()
     out_dir = os.path.join(ROOT, "examples", "bin")
     os.makedirs(out_dir, exist_ok=True)
-    src = os.path.join(ROOT, "examples", "1d_example.cpp")
-    exe = os.path.join(out_dir, "1d_example")
-    deps = [src, os.path.join(ROOT, "include", "gvi", "gvi_host.hpp"), os.path.join(ROOT, "include", "gvi_hip.h")]
-    if force or _stale(exe, deps):
-        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src,
-               "-L", HERE, "-lgvi_hip", "-Wl,-rpath," + HERE, "-o", exe]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("g++ failed:\n" + " ".join(cmd) + "\n" + r.stderr[-4000:])
+    first = None
+    for name in ("1d_example", "1d_example_prox"):
+        src = os.path.join(ROOT, "examples", name + ".cpp")
+        exe = os.path.join(out_dir, name)
+        deps = [src, os.path.join(ROOT, "include", "gvi", "gvi_host.hpp"), os.path.join(ROOT, "include", "gvi_hip.h")]
+        if force or _stale(exe, deps):
+            cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src,
+                   "-L", HERE, "-lgvi_hip", "-Wl,-rpath," + HERE, "-o", exe]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("g++ failed:\n" + " ".join(cmd) + "\n" + r.stderr[-4000:])
+        first = first or exe
+    exe = first
     return exe
 
 

@@ -534,4 +534,66 @@ class NGDGH : public GVIGH<Factor> {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Proximal (JKO) variant: proxgd/ProxGVI-GH.h, proxgd/ProxGVI-GH-impl.h, proxgd/ProxGVIFactorizedBaseGH.h.
+// The factor class carries the same constructor surface (ProxGVIFactorizedBaseGH.h:30-48); the update law lives
+// in the device rule GVI_RULE_PROX_JKO.
+// ------------------------------------------------------------------------------------------------
+template <typename CostClass>
+using ProxGVIFactorizedBaseGH = NGDFactorizedBaseGH<CostClass>;
+using ProxGVIFactorizedSimpleGH = ProxGVIFactorizedBaseGH<NoneType>;   // proxgd/ProxGVIFactorizedSimpleGH.h
+
+template <typename Factor>
+class ProxGVIGH : public GVIGH<Factor> {
+  using Base = GVIGH<Factor>;
+ public:
+  ProxGVIGH(const std::vector<std::shared_ptr<Factor>>& f, int dim_state, int num_states, int niterations = 5,
+            double temperature = 1.0, double high_temperature = 100.0, int device = 0)
+      : Base(f, dim_state, num_states, niterations, temperature, high_temperature, device) {
+    this->_dev->check(gvi_ngd_set_update_rule(this->_dev->get(), GVI_RULE_PROX_JKO));
+  }
+  // compute_gradients(step) (proxgd/ProxGVI-GH-impl.h:43-88): plain sums of the factor-level JKO increments
+  std::tuple<VectorXd, SpMat> compute_gradients(std::optional<double> step_size = std::nullopt) {
+    this->_dev->check(gvi_prox_gradients(this->_dev->get(), step_size.value_or(this->_step_size_base)));
+    const int T = this->_num_states, n = this->_dim_state;
+    VectorXd dmu(T * n);
+    std::vector<double> VD((size_t)T * n * n), VU((size_t)(T > 1 ? T - 1 : 0) * n * n);
+    this->_dev->check(gvi_ngd_get_gradients(this->_dev->get(), nullptr, nullptr, nullptr, dmu.data(), VD.data(), VU.data()));
+    return std::make_tuple(dmu, this->to_spmat(VD, VU));
+  }
+  double onestep_linesearch(double step_size) {                 // :24-41, trial kept on the device
+    double c = 0.0;
+    this->_dev->check(gvi_prox_trial(this->_dev->get(), step_size, &c));
+    return c;
+  }
+  void update_proposal() {
+    this->_dev->check(gvi_ngd_accept(this->_dev->get()));
+    this->pull_state();
+  }
+  // ProxGVIGH::optimize (proxgd/ProxGVI-GH-impl.h:121-202)
+  void optimize(std::optional<bool> verbose = std::nullopt) override {
+    const bool is_verbose = verbose.value_or(true);
+    for (int i_iter = 0; i_iter < this->_niters; i_iter++) {
+      if (i_iter == this->_niters_lowtemp) this->switch_to_high_temperature();
+      const double cost_iter = this->cost_value();
+      if (is_verbose) std::printf("========= iteration %d ========= \n--- cost_iter ---\n%.15g\n", i_iter, cost_iter);
+      VectorXd fact_costs = this->factor_cost_vector();
+      this->record(cost_iter, fact_costs);
+      int cnt = 0, B = 1;
+      this->_dev->check(gvi_prox_gradients(this->_dev->get(), std::pow(this->_step_size_base, B)));
+      while (true) {
+        const double new_cost = onestep_linesearch(std::pow(this->_step_size_base, B));
+        if (new_cost < cost_iter) { update_proposal(); break; }
+        B += 1; cnt += 1;
+        if (cnt > this->_niters_backtrack) {
+          if (is_verbose) std::printf("Reached the maximum backtracking steps.\n");
+          update_proposal();
+          break;
+        }
+      }
+    }
+    if (!this->_prefix.empty()) this->save_data(is_verbose);
+  }
+};
+
 }  // namespace gvi

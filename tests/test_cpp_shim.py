@@ -43,3 +43,20 @@ def test_1d_example_reproduces_reference_trace(tmp_path, golden_dir):
     # time_test prints the reference's "% GPU average/min/max" lines and leaves the state untouched
     avg = [l for l in r.stdout.splitlines() if l.startswith("% GPU average:")]
     assert len(avg) == 1 and float(avg[0].split(":")[1].split()[0]) > 0
+
+
+@pytest.mark.gpu
+def test_1d_prox_example_reproduces_reference_trace(tmp_path, golden_dir):
+    """SURVEY 8(f)4 through the C++ host path: gvi::ProxGVIGH on the shim writes the CSVs the reference committed
+    under data/1d_proxgvi/ (src/1d_example_proxGVI.cpp)."""
+    build.build_examples()
+    exe = os.path.join(os.path.dirname(build.build_examples()), "1d_example_prox")
+    out = str(tmp_path) + "/"
+    r = subprocess.run([exe, out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for name, tol in [("mean", 1e-9), ("precision", 1e-10), ("cov", 1e-9), ("cost", 1e-10), ("factor_costs", 1e-10)]:
+        got = np.loadtxt(out + name + ".csv", delimiter=",").ravel()
+        ref = np.loadtxt(os.path.join(golden_dir, "ref_1d_proxgvi", name + ".csv"), delimiter=",").ravel()
+        assert got.shape == ref.shape == (10,)
+        assert np.abs(got - ref).max() < tol, name
+
