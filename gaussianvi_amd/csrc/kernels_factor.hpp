@@ -974,7 +974,8 @@ typedef const double __attribute__((address_space(4))) cdouble_t;
 // would need 2 m D / 4 SGPRs and spill) nor merged into one burst.
 template <int D, int R>
 __device__ __forceinline__ double split_psi_rows(cdouble_t* hq, const double* u0s, const double* sgs, const double (&z)[D]) {
-  constexpr int GC = (D % 4 == 0 && R <= 3) ? 4 : (D % 2 == 0 && R <= 6 ? 2 : 1);   // <= 12 doubles (24 SGPRs) per group
+  // columns per group: 12-18 doubles (24-36 SGPRs) in flight, two groups live at a time
+  constexpr int GC = (D % 4 == 0 && R <= 3) ? 4 : (D % 3 == 0 && R == 6 ? 3 : (D % 2 == 0 && R <= 6 ? 2 : 1));
   constexpr int NG = D / GC, GS = GC * R;
   double u[R];
 #pragma unroll
