@@ -729,6 +729,36 @@ def test_prox_jko_chain_vs_oracle(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("env,mode", [({}, (1, 0)), ({"GVI_NO_PAIR": "1"}, (1, 0)), ({"GVI_NO_FUSE_GATHER": "1"}, (1, 0)),
+                                      ({"GVI_SIDE_SOLVE": "0"}, (1, 0)), ({"GVI_NO_SCOST": "1"}, (1, 0)), ({}, (1, 1)),
+                                      ({}, (0, 0)), ({"GVI_NO_PAIR": "1", "GVI_SIDE_SOLVE": "0", "GVI_NO_FUSE_GATHER": "1"}, (0, 0))])
+def test_headline_shape_scheduling_and_fusion_switches(monkeypatch, env, mode):
+    """The d = 12 / d = 6 chain shape takes every fused path of the resident iteration (pair launches, gather inside
+    prep, side-stream solve, two-factor cost kernel, cost tail).  Each switch and scheduling mode must leave the
+    accept decisions unchanged and the iterates equal to rounding; one huge base step forces rejected trials."""
+    ch = make_chain("c3small")
+    ref_ctx, _ = api.context_for_chain(ch)
+    ref_ctx.ngd_set_mode(1, 0)
+    ref_ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    steps = [0.55, 0.55, 40.0, 0.55, 0.55]
+    ref_log = [ref_ctx.ngd_step(s, 10) for s in steps]
+    ref = ref_ctx.ngd_get_state()
+    ref_ctx.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx, _ = api.context_for_chain(ch)
+    ctx.ngd_set_mode(*mode)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    log = [ctx.ngd_step(s, 10) for s in steps]
+    st = ctx.ngd_get_state()
+    ctx.close()
+    assert any(r["ntrials"] > 1 for r in ref_log)
+    for a, b in zip(log, ref_log):
+        assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"]
+        assert np.isclose(a["new_cost"], b["new_cost"], rtol=1e-12)
+    assert rel(st["mu"], ref["mu"]) < 1e-10 and rel(st["D"], ref["D"]) < 1e-10 and rel(st["SigD"], ref["SigD"]) < 1e-10
+
+
 def test_linesearch_rejects_nan_and_backtracks():
     """A huge base step makes the trial precision indefinite: log-det NaN -> rejected -> backtrack
     (gvibase/GVI-GH-impl.h:92-117 with the NaN rule of section 3.1)."""
