@@ -148,7 +148,7 @@ def main():
     ngd = ShardedNGD(engine, world=world)
     ngd.group_forced = use_pg and world == 1
     ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
-    ctx.profile_enable(True)
+    ctx.profile_enable(3)       # HIP events around every 8th dominant launch (a pair costs ~14 us of queue gaps)
 
     def barrier():
         if use_pg:
@@ -177,7 +177,8 @@ def main():
         r = step_fn()
         log.append(r)
         passes += 1 + r["ntrials"]
-        kern_ms.append(ctx.profile_last(ids[0], 0))
+        if i % 8 == 7 or i == args.steps - 1:
+            kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch (sampled: every 8th)
     barrier()
     elapsed = time.perf_counter() - t0
 

@@ -136,6 +136,8 @@ struct gvi_ctx {
   int bcr_variant = 0;                // 0 auto (segmented where instantiated), 1 per-level kernels
   bool profile = false;
   bool profile_all = false;           // events around every moments / cost launch (else: set 0, full pass only)
+  int profile_every = 1;              // on = 3: bracket only every 8th dominant launch (an event pair costs ~14 us of queue gaps)
+  long profile_count = 0;
   int target_waves = 2048;
   bool no_scost = false;              // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
@@ -489,7 +491,8 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   a.f = s.dev(); a.mu = mu; a.psi_ext = psi_ext; a.partial = s.partial.d();
   a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full;
   const int which = full ? 0 : 1;
-  const bool prof = !c->defer && c->profile && (c->profile_all || (full && &s == c->sets[0].get()));
+  bool prof = !c->defer && c->profile && (c->profile_all || (full && &s == c->sets[0].get()));
+  if (prof && !c->profile_all && (c->profile_count++ % c->profile_every) != 0) prof = false;
   if (prof) {
     for (int e = 0; e < 2; ++e)
       if (!s.ev[which][e]) HIPCK(c, hipEventCreate(&s.ev[which][e]));
@@ -1703,7 +1706,7 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
       const int want = full ? 0 : 1;
       if (d0.kind == want && d1.kind == want) {
         const int nb0 = (int)(d0.grid.x * d0.grid.y), nb1 = (int)(d1.grid.x * d1.grid.y);
-        const bool prof = ctx->profile && full;
+        const bool prof = ctx->profile && full && (ctx->profile_count++ % ctx->profile_every) == 0;
         if (prof) {
           for (int e = 0; e < 2; ++e)
             if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
@@ -2079,7 +2082,9 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on) {
   if (!ctx) return GVI_ERR_ARG;
   ctx->profile = on != 0;
-  ctx->profile_all = on > 1;
+  ctx->profile_all = on == 2;
+  ctx->profile_every = on == 3 ? 8 : 1;
+  ctx->profile_count = 0;
   for (auto& s : ctx->sets) s->ev_set[0] = s->ev_set[1] = false;
   return GVI_OK;
 }

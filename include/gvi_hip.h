@@ -249,7 +249,8 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
 /* ---- measurement hooks (bench.py): HIP-event time of the last moments / cost kernel launch of a
  *      set, in milliseconds, measured on the context stream; enable before the launches.
  *      on = 1: only the dominant launch (set 0, full moments pass) is bracketed -- an event pair costs
- *      ~10 us of queue gaps; on = 2: every moments / cost launch of every set. ---- */
+ *      ~14 us of queue gaps; on = 2: every moments / cost launch of every set; on = 3: like 1 but only every 8th
+ *      dominant launch is bracketed (sampling keeps the measurement out of the measured iteration time). ---- */
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on);
 gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kernel, 1 cost kernel*/, float* ms);
 /* Launch geometry of the set's last moments/cost launch: variant (0 closed form, 1 generic, 2 register, 3 split = four waves per factor, d = 16/20/24,
