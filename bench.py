@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default, BASELINE configs[3]): the same 1024-factor chain over N GPUs; "
                          "weak: 1024 factors per GPU, i.e. a (1024 N)-factor chain (config c3xN)")
-    ap.add_argument("--restart-every", type=int, default=16,
+    ap.add_argument("--restart-every", type=int, default=30,
                     help="re-initialise (mu0, precision0) inside the timed region every R steps so that every step is a "
                          "descending iteration with one accepted trial (the chain converges after ~35 steps)")
     args = ap.parse_args()
