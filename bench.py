@@ -194,19 +194,22 @@ def main():
     if world == 1 and not ngd.group_forced:
         ctx.ngd_set_mode(True, True)
         ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
-        for _ in range(args.warmup):
-            ctx.ngd_step(0.55, 10)
+        fpos = 0
+        for _ in range(max(1, args.warmup)):
+            if fpos == args.restart_every:
+                ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"]); fpos = 0
+            ctx.ngd_step(0.55, 10); fpos += 1
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
         flog = []
         for i in range(args.steps):
-            if i and i % args.restart_every == 0:
-                ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
-            flog.append(ctx.ngd_step(0.55, 10))
+            if fpos == args.restart_every:
+                ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"]); fpos = 0
+            flog.append(ctx.ngd_step(0.55, 10)); fpos += 1
         torch.cuda.synchronize()
         tf = time.perf_counter() - tf0
         fused = {"ms_per_step": 1e3 * tf / args.steps, "ngd_iters_per_s": args.steps / tf,
-                 "final_cost": flog[-1]["new_cost"],
+                 "final_cost": flog[-1]["new_cost"], "trials_per_step": float(np.mean([r["ntrials"] for r in flog])),
                  "note": "gvi_ngd_set_mode(fuse_trial=1): one psi pass per accepted iteration (trial cost = m0 of the "
                          "full moments pass that is also the next gradient pass); identical iterates"}
         ctx.ngd_set_mode(True, False)
