@@ -156,6 +156,7 @@ struct gvi_ctx {
   hipEvent_t ev_grad = nullptr, ev_solve[2] = {nullptr, nullptr};
   bool solve_pending[2] = {false, false};
   DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
+  DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
   hipStream_t chain_stream = nullptr; // stream of the chain launches being queued (null: ctx->stream)
   int chain_ws = 0;
   double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
@@ -1575,8 +1576,15 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
   GVICK(ngd_prep_all(ctx, i));
   GVICK(ngd_moments_launch(ctx, i, 0));
   if (publish) ctx->seq += 1.0;
-  hipLaunchKernelGGL(cost_tail_kernel, dim3(1), dim3(1024), 0, ctx->stream, make_epi_list(ctx, 0, nullptr), g.exch1.d(),
-                     g.hld[i].d(), publish ? ctx->host_slot_dev : nullptr, ctx->seq);
+  if (!ctx->tail_counter.p) {
+    HIPCK(ctx, ctx->tail_counter.ensure(8));
+    HIPCK(ctx, hipMemsetAsync(ctx->tail_counter.p, 0, 8, ctx->stream));
+  }
+  int64_t nfac = 0;
+  for (auto& s : ctx->sets) nfac = std::max<int64_t>(nfac, s->K);
+  const unsigned nblk = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, (nfac + 255) / 256));
+  hipLaunchKernelGGL(cost_tail_kernel, dim3(nblk), dim3(256), 0, ctx->stream, make_epi_list(ctx, 0, nullptr), g.exch1.d(),
+                     g.hld[i].d(), publish ? ctx->host_slot_dev : nullptr, ctx->seq, (unsigned*)ctx->tail_counter.p);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }

@@ -1504,13 +1504,15 @@ struct EpiList {
 // sum over all factors (same order as cost_sum_all_kernel: thread-strided partial sums, then a fixed 256-leaf tree
 // per set) into acc[0], and -- single-process iteration only -- the publish into host-mapped memory
 // ({cost_sum, half_logdet, sequence}).  Replaces epilogue_all_kernel(full = 0) -> cost_sum_all_kernel -> publish_kernel.
-__global__ __launch_bounds__(1024) void cost_tail_kernel(EpiList L, double* acc, const double* half_logdet, double* host_out,
-                                                         double seq) {
+__global__ __launch_bounds__(256) void cost_tail_kernel(EpiList L, double* acc, const double* half_logdet, double* host_out,
+                                                        double seq, unsigned* counter) {
   __shared__ double sh[256];
-  // phase 1 (all 1024 threads): per-factor costs to global
+  __shared__ int last;
+  // phase 1 (all blocks): per-factor costs to global, one factor per thread
+  const int gtid = (int)blockIdx.x * 256 + threadIdx.x, gthreads = (int)gridDim.x * 256;
   for (int si = 0; si < L.nsets; ++si) {
     const EpiArgs& e = L.e[si];
-    for (int k = threadIdx.x; k < e.f.K; k += 1024) {
+    for (int k = gtid; k < e.f.K; k += gthreads) {
       const double* P = e.partial + (size_t)k * e.nchunk;
       double m0 = 0.0;
       for (int c0 = 0; c0 < e.nchunk; c0 += 8) {                   // eight loads in flight, then the ordered sum
@@ -1523,16 +1525,21 @@ __global__ __launch_bounds__(1024) void cost_tail_kernel(EpiList L, double* acc,
       e.cost[k] = m0 / e.f.temperature[k];
     }
   }
-  __syncthreads();                       // workgroup-scope release/acquire: the costs written above are visible below
-  // phase 2 (threads 0..255): the summation order of cost_sum_all_kernel
+  // the block that arrives last does the (deterministic, fixed-order) reduction over all factors
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(counter, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // phase 2: the summation order of cost_sum_all_kernel (thread-strided partial sums, 256-leaf tree per set)
   double total = 0.0;
   for (int si = 0; si < L.nsets; ++si) {
     const EpiArgs& e = L.e[si];
-    if (threadIdx.x < 256) {
-      double s = 0.0;
-      for (int k = threadIdx.x; k < e.f.K; k += 256) s += e.cost[k];
-      sh[threadIdx.x] = s;
-    }
+    const volatile double* cost = e.cost;
+    double s = 0.0;
+    for (int k = threadIdx.x; k < e.f.K; k += 256) s += cost[k];
+    sh[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
       if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
@@ -1542,6 +1549,7 @@ __global__ __launch_bounds__(1024) void cost_tail_kernel(EpiList L, double* acc,
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    *counter = 0u;                       // ready for the next launch (stream-ordered)
     acc[0] = total;
     if (host_out) {
       host_out[0] = total;
