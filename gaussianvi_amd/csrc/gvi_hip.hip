@@ -157,6 +157,8 @@ struct gvi_ctx {
   bool solve_pending[2] = {false, false};
   DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
   DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
+  // trial precision formed inside the first BCR pass of the next run_seg call (see SegArgs::mix*)
+  struct Mix { const double* VD = nullptr; const double* VU = nullptr; double* outD = nullptr; double* outU = nullptr; double step = 0.0; } mix;
   hipStream_t chain_stream = nullptr; // stream of the chain launches being queued (null: ctx->stream)
   int chain_ws = 0;
   double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
@@ -743,6 +745,7 @@ gvi_status run_seg(gvi_ctx* c, const double* D, const double* U, const double* r
   a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.w = w;
   a.SigD = SigD; a.SigU = SigU; a.x = x; a.hld = hld;
   a.level0 = a.m = a.S = a.prev0 = a.top = 0;
+  a.mixVD = c->mix.VD; a.mixVU = c->mix.VU; a.mixOutD = c->mix.outD; a.mixOutU = c->mix.outU; a.mix_step = c->mix.step;
   const SegPlan pl = seg_plan(c);
   return pivot ? launch_seg_n<true>(c, a, pl) : launch_seg_n<false>(c, a, pl);
 }
@@ -1834,9 +1837,21 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
   g.cost_valid[t] = false;
   if (ctx->solve_pending[g.gcur]) {
     // precision part first (needs no dmu), factorise, then join the side-stream solve and form mu_trial
-    hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)0, (int64_t)bt,
-                       step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
-    GVICK(ngd_refresh_factor(ctx, t));
+    if (seg_supported(ctx->n) && ctx->bcr_variant != 1 && ctx->T > 1) {
+      // Lam_trial = Lam + step (V - Lam) is formed by the first BCR pass while it loads the chain (and written to
+      // Lam[t] there): factorise "Lam[c] mixed with V" instead of launching trial_kernel first
+      const size_t Tnn = (size_t)ctx->T * nn_(ctx);
+      const double* V = g.exch0[g.gcur].d() + Tn;
+      ctx->mix.VD = V; ctx->mix.VU = V + Tnn; ctx->mix.outD = g.Lam[t].d(); ctx->mix.outU = g.Lam[t].d() + Tnn; ctx->mix.step = step;
+      double* sD = g.Sig[t].d();
+      const gvi_status fs = run_bt_factor(ctx, g.Lam[c].d(), g.Lam[c].d() + Tnn, sD, sD + Tnn, g.hld[t].d());
+      ctx->mix = gvi_ctx::Mix();
+      GVICK(fs);
+    } else {
+      hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)0, (int64_t)bt,
+                         step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
+      GVICK(ngd_refresh_factor(ctx, t));
+    }
     GVICK(ngd_join_solve(ctx, g.gcur));
     ctx->defer_gather = true;               // mu_trial and the gather ride in the prep launch of the cost pass
     const gvi_status gs = ngd_refresh_gather(ctx, t, g.mu[c].d(), g.dmu2[g.gcur].d(), step);

@@ -46,6 +46,13 @@ struct SegArgs {
   double* SigU;      // [T-1][n][n]
   double* x;         // [T][n]      (solve)
   double* hld;       // [1]
+  // optional fused trial precision (first pass only): the chain operated on is D + mix_step (mixV - D), and it is
+  // written to mix_out ([D | U] layouts like D / U) -- replaces the separate trial_kernel launch
+  const double* mixVD;
+  const double* mixVU;
+  double* mixOutD;
+  double* mixOutU;
+  double mix_step;
 };
 
 // forward kernel LDS: 5 block arrays (+3 factor arrays in the top pass), rhs vectors, one elimination tile
@@ -249,6 +256,10 @@ __device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int le
 __device__ inline double seg_fold_D(const SegArgs& a, int x, int el) {
   const int nn = a.n * a.n;
   double v = (a.level0 == 0 ? a.D : a.w.Deff)[(size_t)x * nn + el];
+  if (a.level0 == 0 && a.mixVD) {
+    v = v + a.mix_step * (a.mixVD[(size_t)x * nn + el] - v);      // same arithmetic as trial_kernel
+    a.mixOutD[(size_t)x * nn + el] = v;
+  }
   // at most 5 levels per pass (seg_plan): a fixed-trip, fully unrolled loop keeps the (independent)
   // loads in flight together instead of one global round trip per level
   double cr[5], cl[5];
@@ -313,7 +324,14 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
     const double v = seg_fold_D(a, x, el);
     Dl[e] = v;
     if (j == 0 && !a.top) a.w.Deff[(size_t)x * nn + el] = v;      // the survivor's base for the next pass
-    if (x + st < T) Cl[e] = (a.level0 == 0 ? a.U + (size_t)x * nn : a.w.NU + (size_t)(x + st / 2) * nn)[el];
+    if (x + st < T) {
+      double cu = (a.level0 == 0 ? a.U + (size_t)x * nn : a.w.NU + (size_t)(x + st / 2) * nn)[el];
+      if (a.level0 == 0 && a.mixVU) {
+        cu = cu + a.mix_step * (a.mixVU[(size_t)x * nn + el] - cu);
+        a.mixOutU[(size_t)x * nn + el] = cu;
+      }
+      Cl[e] = cu;
+    }
   }
   if (rhs) {
     for (int e = tid; e < cnt * N; e += blockDim.x) {
