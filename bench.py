@@ -15,9 +15,10 @@ marginals, gather, cost pass) until the first accepted one.  Inputs are resident
 timed region.  `value` = every psi evaluation executed in the timed region (one per (factor, sigma
 point) per pass, counted once) / wall time, whole job.
 
-N > 1: the factor list is sharded contiguously over the ranks (strong scaling, BASELINE configs[3]);
-the assembled [g | D | U] partials and the trial cost are all-reduced over RCCL; the chain recursions
-are replicated.
+N > 1: the factor list is sharded contiguously over the ranks; the assembled [g | D | U] partials and the trial
+cost are all-reduced over RCCL; the chain recursions are replicated.  Default --scaling weak: 1024 factors per
+GPU (a 1024 N-factor chain, "c3xN"), per-GPU work fixed; --scaling strong: BASELINE configs[3], the same
+1024-factor chain over N GPUs (latency-bound: 128 factors per GPU at N = 8).
 """
 from __future__ import annotations
 
@@ -98,9 +99,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 register (LDS operands), 3 operand-resident, 5 register (SGPR operands)")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
-                    help="strong (default, BASELINE configs[3]): the same 1024-factor chain over N GPUs; "
-                         "weak: 1024 factors per GPU, i.e. a (1024 N)-factor chain (config c3xN)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
+                    help="weak (default): 1024 factors PER GPU, i.e. a (1024 N)-factor chain (config c3xN) sharded over the N "
+                         "ranks -- per-GPU work fixed; strong (BASELINE configs[3]): the same 1024-factor chain over N GPUs "
+                         "(128 factors per GPU at N = 8: bounded by the replicated chain recursions and two collectives)")
     ap.add_argument("--restart-every", type=int, default=30,
                     help="re-initialise (mu0, precision0) inside the timed region every R steps so that every step is a "
                          "descending iteration with one accepted trial (the chain converges after ~35 steps)")
