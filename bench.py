@@ -163,7 +163,7 @@ def main():
     step_fn = (lambda: ctx.ngd_step(0.55, 10)) if (world == 1 and not ngd.group_forced) else (lambda: ngd.step(0.55, 10))
     def restart():
         ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
-        ngd._cost = None
+        ngd.reset()
 
     # one-time costs (buffer growth on the first cost pass, side stream / event creation, kernel attribute calls, the
     # cold Jacobi start) are primed outside the contract's W warm-up steps as well, so a small W does not time them

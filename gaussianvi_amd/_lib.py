@@ -30,6 +30,11 @@ SIGNATURES = {
     "gvi_table_file_list": [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "gvi_table_file_read": [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "gvi_table_file_write": [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p],
+    "gvi_ngd_trial_publish": [C.c_void_p],
+    "gvi_ngd_trial_wait": [C.c_void_p, C.c_void_p],
+    "gvi_ngd_spec_gradients_local": [C.c_void_p],
+    "gvi_ngd_spec_gradients_finish": [C.c_void_p],
+    "gvi_ngd_accept_spec": [C.c_void_p],
     "gvi_ngd_set_update_rule": [C.c_void_p, C.c_int],
     "gvi_prox_gradients": [C.c_void_p, C.c_double],
     "gvi_prox_trial": [C.c_void_p, C.c_double, C.c_void_p],

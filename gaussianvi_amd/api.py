@@ -327,6 +327,24 @@ class Context:
         self._ck(self.lib.gvi_profile_geometry(self.h, sid, C.byref(v), C.byref(nch), C.byref(ch)))
         return dict(variant=v.value, nchunk=nch.value, chunk=ch.value)
 
+    # ---- speculative halves (sharded driver) ----
+    def ngd_trial_publish(self):
+        self._ck(self.lib.gvi_ngd_trial_publish(self.h))
+
+    def ngd_trial_wait(self):
+        c = C.c_double()
+        self._ck(self.lib.gvi_ngd_trial_wait(self.h, C.byref(c)))
+        return c.value
+
+    def ngd_spec_gradients_local(self):
+        self._ck(self.lib.gvi_ngd_spec_gradients_local(self.h))
+
+    def ngd_spec_gradients_finish(self):
+        self._ck(self.lib.gvi_ngd_spec_gradients_finish(self.h))
+
+    def ngd_accept_spec(self):
+        self._ck(self.lib.gvi_ngd_accept_spec(self.h))
+
     # ---- proximal (JKO) rule ----
     def ngd_set_update_rule(self, rule):
         self._ck(self.lib.gvi_ngd_set_update_rule(self.h, int(rule)))

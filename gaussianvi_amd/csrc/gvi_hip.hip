@@ -112,6 +112,7 @@ struct NgdState {
   bool cost_valid[2] = {false, false};
   double cost[2] = {0, 0};
   bool have_trial = false;
+  bool spec_ready = false;            // gradients at the TRIAL state sit in exch0[1 - gcur] / dmu2[1 - gcur]
   // gather of slot i deferred into the next prep launch of that slot (ngd_prep_all) -- see PrepList
   struct GatherPending { bool on = false; const double* mu_from = nullptr; const double* dmu = nullptr; double step = 0.0; };
   GatherPending gpend[2];
@@ -1835,6 +1836,7 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
   const size_t Tn = (size_t)ctx->T * ctx->n, bt = bt_count(ctx);
   const int c = g.cur, t = 1 - c;
   g.cost_valid[t] = false;
+  g.spec_ready = false;
   if (ctx->solve_pending[g.gcur]) {
     // precision part first (needs no dmu), factorise, then join the side-stream solve and form mu_trial
     if (seg_supported(ctx->n) && ctx->bcr_variant != 1 && ctx->T > 1) {
@@ -1885,6 +1887,47 @@ gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost) {
 gvi_status gvi_ngd_trial(gvi_ctx* ctx, double step, double* new_cost) {
   GVICK(gvi_ngd_trial_local(ctx, step));
   return gvi_ngd_trial_finish(ctx, new_cost);
+}
+
+// ---- split / speculative forms for the sharded driver: publish the (all-reduced) trial cost without waiting, queue the
+// NEXT iteration's gradients at the trial state into the other gradient buffer behind it, then wait and decide ----
+gvi_status gvi_ngd_trial_publish(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  return ngd_cost_publish(ctx, 1 - ctx->ngd.cur);
+}
+
+gvi_status gvi_ngd_trial_wait(gvi_ctx* ctx, double* new_cost) {
+  GVICK(ngd_check(ctx));
+  if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
+  return ngd_cost_wait(ctx, 1 - ctx->ngd.cur, new_cost);
+}
+
+gvi_status gvi_ngd_spec_gradients_local(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  ctx->ngd.spec_ready = false;
+  return ngd_grad_local(ctx, 1 - ctx->ngd.cur, 1 - ctx->ngd.gcur);
+}
+
+gvi_status gvi_ngd_spec_gradients_finish(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  if (!ctx->ngd.have_trial) return fail(ctx, GVI_ERR_STATE, "no trial pending");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(ngd_grad_finish(ctx, 1 - ctx->ngd.gcur));
+  ctx->ngd.spec_ready = true;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_accept_spec(gvi_ctx* ctx) {
+  GVICK(ngd_check(ctx));
+  if (!ctx->ngd.spec_ready) return fail(ctx, GVI_ERR_STATE, "no speculative gradients at the trial state");
+  GVICK(gvi_ngd_accept(ctx));
+  NgdState& g = ctx->ngd;
+  g.gcur = 1 - g.gcur; g.grad_valid = true; g.grad_slot = g.cur; g.spec_ready = false;
+  return GVI_OK;
 }
 
 gvi_status gvi_ngd_accept(gvi_ctx* ctx) {
@@ -2058,7 +2101,8 @@ gvi_status gvi_ngd_exchange(gvi_ctx* ctx, int which, void** dev_ptr, int64_t* co
   if (!dev_ptr || !count) return fail(ctx, GVI_ERR_ARG, "NULL argument");
   if (which == 0) { *dev_ptr = ctx->ngd.exch0[ctx->ngd.gcur].p; *count = (int64_t)((size_t)ctx->T * ctx->n + bt_count(ctx)); }
   else if (which == 1) { *dev_ptr = ctx->ngd.exch1.p; *count = 1; }
-  else return fail(ctx, GVI_ERR_ARG, "which must be 0 or 1");
+  else if (which == 2) { *dev_ptr = ctx->ngd.exch0[1 - ctx->ngd.gcur].p; *count = (int64_t)((size_t)ctx->T * ctx->n + bt_count(ctx)); }
+  else return fail(ctx, GVI_ERR_ARG, "which must be 0, 1 or 2");
   return GVI_OK;
 }
 

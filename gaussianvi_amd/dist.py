@@ -83,6 +83,12 @@ class HipEngine:
     def trial_local(self, step): self.ctx.ngd_trial_local(step)
     def trial_finish(self): return self.ctx.ngd_trial_finish()
     def accept(self): self.ctx.ngd_accept()
+    # speculative pipeline (see include/gvi_hip.h): present only on engines that can queue work behind the publish
+    def trial_publish(self): self.ctx.ngd_trial_publish()
+    def trial_wait(self): return self.ctx.ngd_trial_wait()
+    def spec_gradients_local(self): self.ctx.ngd_spec_gradients_local()
+    def spec_gradients_finish(self): self.ctx.ngd_spec_gradients_finish()
+    def accept_spec(self): self.ctx.ngd_accept_spec()
 
 
 class ShardedNGD:
@@ -92,6 +98,13 @@ class ShardedNGD:
         self.e, self.group, self.world = engine, group, world
         self.group_forced = False      # bench.py sets it when a size-1 process group exists (plumbing test)
         self._cost = None
+        self._grads_ready = False      # gradients of the current proposal already computed (speculatively)
+        self.speculate = True
+
+    def reset(self):
+        """Forget cached cost / speculative gradients (call after the engine's state was re-initialised)."""
+        self._cost = None
+        self._grads_ready = False
 
     def _allreduce(self, which):
         import os
@@ -121,14 +134,34 @@ class ShardedNGD:
 
     def step(self, step_size_base=0.55, max_backtrack=10):
         c0 = self.cost()
-        self.gradients()
+        if not self._grads_ready:
+            self.gradients()
+        self._grads_ready = False
+        speculate = self.speculate and hasattr(self.e, "spec_gradients_local")
         step, cnt, ok, c1 = step_size_base, 0, False, c0
         while True:
             step *= 0.75                       # gvibase/GVI-GH-impl.h:83
-            c1 = self.trial(step)
+            spec = speculate and cnt == 0
+            if spec:
+                # the first trial is accepted in the common case: queue the next iteration's gradients at the trial
+                # state (other gradient buffer) behind the publish of the trial cost, THEN wait for the cost -- the
+                # device never idles while the host reads the scalar and decides (same numbers either way)
+                self.e.trial_local(step)
+                self._allreduce(1)
+                self.e.trial_publish()
+                self.e.spec_gradients_local()
+                self._allreduce(2)
+                self.e.spec_gradients_finish()
+                c1 = self.e.trial_wait()
+            else:
+                c1 = self.trial(step)
             cnt += 1
             if c1 < c0:                        # NaN compares false -> rejected
-                self.e.accept()
+                if spec:
+                    self.e.accept_spec()
+                    self._grads_ready = True
+                else:
+                    self.e.accept()
                 self._cost = c1
                 ok = True
                 break

@@ -238,8 +238,19 @@ gvi_status gvi_ngd_cost_finish(gvi_ctx* ctx, double* cost);   /* split the same 
 gvi_status gvi_ngd_trial_local(gvi_ctx* ctx, double step);
 gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost);
 /* which = 0: packed [g | D | U] partial sums (count = T n + (2T-1) n^2) written by gradients_local;
- * which = 1: the trial's partial sum of factor costs (count = 1) written by trial_local. */
+ * which = 1: the trial's partial sum of factor costs (count = 1) written by trial_local;
+ * which = 2: the packed partial sums written by spec_gradients_local (the other gradient buffer). */
 gvi_status gvi_ngd_exchange(gvi_ctx* ctx, int which, void** dev_ptr, int64_t* count);
+/* Speculative pipeline of the sharded driver (what gvi_ngd_step does inside one process): after trial_local and the
+ * all-reduce of exchange 1, trial_publish queues the publish of the trial cost WITHOUT waiting; spec_gradients_local /
+ * _finish (all-reduce exchange 2 in between) queue the next iteration's gradients at the trial state behind it;
+ * trial_wait returns the cost; on acceptance accept_spec makes the trial current AND its gradients the current ones
+ * (the next iteration starts without a gradient pass).  A rejected trial simply leaves the speculative buffer unused. */
+gvi_status gvi_ngd_trial_publish(gvi_ctx* ctx);
+gvi_status gvi_ngd_trial_wait(gvi_ctx* ctx, double* new_cost);
+gvi_status gvi_ngd_spec_gradients_local(gvi_ctx* ctx);
+gvi_status gvi_ngd_spec_gradients_finish(gvi_ctx* ctx);
+gvi_status gvi_ngd_accept_spec(gvi_ctx* ctx);
 /* Copy state to host; any pointer may be NULL.  mu[T][n], D, U, SigD[T][n][n], SigU[T-1][n][n]. */
 gvi_status gvi_ngd_get_state(gvi_ctx* ctx, double* mu, double* D, double* U, double* SigD, double* SigU);
 /* Last gradients: dmu[T][n], dD, dU (dprecision) and the assembled Vdmu g / Vddmu (VD, VU). */

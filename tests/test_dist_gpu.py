@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, iters, q):
+def _worker(rank, world, port, name, iters, speculate, q):
     import torch.distributed as dist
     from gaussianvi_amd import api
     from gaussianvi_amd.dist import HipEngine, ShardedNGD, shard_chain
@@ -30,8 +30,9 @@ def _worker(rank, world, port, name, iters, q):
         ch = make_chain(name)
         ctx, ids = api.context_for_chain(shard_chain(ch, rank, world), device=0)
         ngd = ShardedNGD(HipEngine(ctx, 0), world=world)
+        ngd.speculate = speculate
         ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
-        log = [ngd.step(0.55, 10) for _ in range(iters)]
+        log = [ngd.step(40.0 if it == 1 else 0.55, 10) for it in range(iters)]     # one huge base step: rejected trials
         st = ctx.ngd_get_state()
         q.put((rank, log, st["mu"], st["D"], st["SigD"]))
         ctx.close()
@@ -39,19 +40,20 @@ def _worker(rank, world, port, name, iters, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("speculate", [True, False])
 @pytest.mark.parametrize("name,iters", [("c2", 4), ("c3small", 3)])
-def test_two_ranks_on_one_gpu_match_single_process(name, iters):
+def test_two_ranks_on_one_gpu_match_single_process(name, iters, speculate):
     from gaussianvi_amd import api
     ch = make_chain(name)
     ctx, ids = api.context_for_chain(ch)
     ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
-    ref_log = [ctx.ngd_step(0.55, 10) for _ in range(iters)]
+    ref_log = [ctx.ngd_step(40.0 if it == 1 else 0.55, 10) for it in range(iters)]
     ref = ctx.ngd_get_state()
     ctx.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, 2, port, name, iters, q)) for r in range(2)]
+    procs = [mpc.Process(target=_worker, args=(r, 2, port, name, iters, speculate, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
