@@ -6,7 +6,15 @@
 //                     update_precision_from_joint, gvibase/GVIFactorizedBase.h:111-114]
 //   moments_*        c_i = w_i psi(mu + S z_i) and the z-space moments  sum_i c_i [1, z_i, z_i z_i^T]
 //                    [SparseGaussHermite::Integrate x3, quadrature/SparseGaussHermite.h:197-221;
-//                     closures ngd/NGDFactorizedBaseGH.h:46-48]
+//                     closures ngd/NGDFactorizedBaseGH.h:46-48].  Families:
+//                      sreg / sreg_pair  sum-of-squares psi, operands from SGPRs, accumulators in registers (dominant)
+//                      scost / _pair     cost pass (m0 only), two factors per wave
+//                      split             d = 16 / 20 / 24: four waves per factor, 8-bit coded table
+//                      reg / wide / tile policy-templated register kernels (other psi kinds; A/B variants)
+//                      generic           any d <= 32, any psi kind, host psi
+//                      closed            quadrature-free moments of a quadratic psi (NGDFactorizedLinear)
+//   cost_tail_kernel per-factor cost + ordered sum + publish for a cost pass, one launch
+//   jko_*            factor-level proximal (JKO) map around the prep kernel's Jacobi
 //   epilogue_kernel  ordered sum of the chunk partials, back-transform to x-space, Vdmu_k / Vddmu_k
 //                    [calculate_partial_V, ngd/NGDFactorizedBaseGH.h:53-74]
 //   expand_kernel    X = mu + S z for the host-callback psi route.
