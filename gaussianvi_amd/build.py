@@ -62,7 +62,7 @@ def build_examples(force: bool = False) -> str:
     out_dir = os.path.join(ROOT, "examples", "bin")
     os.makedirs(out_dir, exist_ok=True)
     first = None
-    for name in ("1d_example", "1d_example_prox"):
+    for name in ("1d_example", "1d_example_prox", "planar_example"):
         src = os.path.join(ROOT, "examples", name + ".cpp")
         exe = os.path.join(out_dir, name)
         deps = [src, os.path.join(ROOT, "include", "gvi", "gvi_host.hpp"), os.path.join(ROOT, "include", "gvi_hip.h")]

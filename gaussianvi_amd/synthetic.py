@@ -131,7 +131,7 @@ def circle_sdf(origin, cell, rows, cols, centers, radii):
     return f
 
 
-def make_planar_chain(T=17, p=3, seed=0x5EED + 40):
+def make_planar_chain(T=17, p=3, seed=0x5EED + 40, jitter=0.02):
     """Planar point-robot planning graph of the reference's own GPU workload: states
     [x, y, vx, vy] (n = 4), T-1 minimum-acceleration priors (d = 8), T hinge-on-SDF obstacle factors on
     every state (d = 4, helpers/CudaOperation.h:491-523) and two fixed-prior end anchors."""
@@ -145,7 +145,7 @@ def make_planar_chain(T=17, p=3, seed=0x5EED + 40):
     vel = (goal_xy - start_xy) / horizon
     t = np.arange(T)[:, None] * dt
     nominal = np.hstack([start_xy[None] + vel[None] * t, np.tile(vel, (T, 1))])
-    mu0 = nominal + 0.02 * rng.normal(size=nominal.shape)
+    mu0 = nominal + jitter * rng.normal(size=nominal.shape)
     origin, cell, rows, cols = (-5.0, -4.0), 0.1, 81, 101
     field = circle_sdf(origin, cell, rows, cols, [(0.0, 1.6), (-1.0, -2.2)], [1.2, 0.9])
     anchors = np.stack([nominal[0], nominal[-1]])

@@ -117,10 +117,54 @@ class Device {
   gvi_ctx* ctx_ = nullptr;
 };
 
-// Device-evaluable psi (include/gvi_hip.h, GVI_PSI_*): kind + the factor's parameter block.
+// Signed-distance fields and the arm model of the obstacle costs (helpers/CudaOperation.h: PlanarSDF :21-131,
+// SignedDistanceField :133-322, ForwardKinematics :325-399).  Shared by the factors that reference them.
+struct PlanarSDF {
+  double origin_x = 0, origin_y = 0, cell_size = 1;
+  MatrixXd field;                        // field(r, c) at (origin_x + c cell, origin_y + r cell)
+};
+struct SignedDistanceField {
+  double origin[3] = {0, 0, 0}, cell_size = 1;
+  int rows = 0, cols = 0, nz = 0;
+  std::vector<double> data;              // data[r + c rows + z rows cols]
+};
+struct ArmModel {
+  std::vector<double> a, alpha, d, theta_bias;      // DH parameters [ndof]
+  std::vector<int32_t> frames;                      // sphere -> frame (non-decreasing)
+  std::vector<double> centers, radii;               // [ns][3], [ns]
+};
+
+// Device-evaluable psi (include/gvi_hip.h, GVI_PSI_*): kind + the factor's parameter block (+ shared field / arm).
 struct DevicePsi {
   int kind = GVI_PSI_HOST_CALLBACK;
   std::vector<double> params;
+  std::shared_ptr<const PlanarSDF> sdf2d;
+  std::shared_ptr<const SignedDistanceField> sdf3d;
+  std::shared_ptr<const ArmModel> arm;
+  // CudaOperation_PlanarPR / _Quad / _3dpR / _3dArm cost_obstacle* (helpers/CudaOperation.h:491-523, 565-606, 650-683, 752-771)
+  static DevicePsi HingeSdf2D(double sigma, double epsilon, double radius, std::shared_ptr<const PlanarSDF> sdf) {
+    DevicePsi p{GVI_PSI_HINGE_SDF_2D, {sigma, epsilon, radius}};
+    p.sdf2d = std::move(sdf);
+    return p;
+  }
+  static DevicePsi HingeSdf2DBody(double sigma, double epsilon, double radius, double slope, int n_balls, double L,
+                                  std::shared_ptr<const PlanarSDF> sdf) {
+    DevicePsi p{GVI_PSI_HINGE_SDF_2D_BODY, {sigma, epsilon, radius, slope, (double)n_balls, L}};
+    p.sdf2d = std::move(sdf);
+    return p;
+  }
+  static DevicePsi HingeSdf3D(double sigma, double epsilon, double radius, std::shared_ptr<const SignedDistanceField> sdf) {
+    DevicePsi p{GVI_PSI_HINGE_SDF_3D, {sigma, epsilon, radius}};
+    p.sdf3d = std::move(sdf);
+    return p;
+  }
+  static DevicePsi HingeSdf3DArm(double sigma, double epsilon, std::shared_ptr<const SignedDistanceField> sdf,
+                                 std::shared_ptr<const ArmModel> arm_model) {
+    DevicePsi p{GVI_PSI_HINGE_SDF_3D_ARM, {sigma, epsilon}};
+    p.sdf3d = std::move(sdf);
+    p.arm = std::move(arm_model);
+    return p;
+  }
   static DevicePsi Range1D(double y, double mu_p, double fb, double sig_r_sq, double sig_p_sq) {
     return {GVI_PSI_RANGE_1D, {y, mu_p, fb, sig_r_sq, sig_p_sq}};
   }
@@ -433,9 +477,14 @@ class GVIGH {
         throw GviError(GVI_ERR_UNSUPPORTED,
                        "GVIGH: the device-resident optimiser needs a DevicePsi per factor; opaque host psi is "
                        "served by SparseGaussHermite / gvi_expand + gvi_moments_from_psi");
+      const DevicePsi& dp = f->device_psi();
       size_t s = 0;
-      for (; s < _sets.size(); ++s)
-        if (_sets[s].d == f->_dim && _sets[s].p == f->gh_degree() && _sets[s].kind == kind) break;
+      for (; s < _sets.size(); ++s) {
+        const DevicePsi& q = _vec_factors[_sets[s].members[0]]->device_psi();
+        if (_sets[s].d == f->_dim && _sets[s].p == f->gh_degree() && _sets[s].kind == kind && q.sdf2d == dp.sdf2d &&
+            q.sdf3d == dp.sdf3d && q.arm == dp.arm)
+          break;
+      }
       if (s == _sets.size()) _sets.push_back({f->_dim, f->gh_degree(), kind, {}});
       _sets[s].members.push_back((int)i);
     }
@@ -454,6 +503,22 @@ class GVIGH {
       int id = -1;
       _dev->check(gvi_factors_add(_dev->get(), (int)K, st.d, st.p, start.data(), st.kind, params.data(), (int64_t)per,
                                   temp.data(), &id));
+      const DevicePsi& dp = _vec_factors[st.members[0]]->device_psi();
+      if (dp.sdf2d) {                                   // column-major rows x cols, like Eigen's MatrixXd
+        const MatrixXd& fld = dp.sdf2d->field;
+        std::vector<double> cm((size_t)fld.rows() * fld.cols());
+        for (int c = 0; c < fld.cols(); ++c)
+          for (int r = 0; r < fld.rows(); ++r) cm[(size_t)c * fld.rows() + r] = fld(r, c);
+        _dev->check(gvi_factors_set_sdf2d(_dev->get(), id, dp.sdf2d->origin_x, dp.sdf2d->origin_y, dp.sdf2d->cell_size,
+                                          fld.rows(), fld.cols(), cm.data()));
+      }
+      if (dp.sdf3d)
+        _dev->check(gvi_factors_set_sdf3d(_dev->get(), id, dp.sdf3d->origin, dp.sdf3d->cell_size, dp.sdf3d->rows,
+                                          dp.sdf3d->cols, dp.sdf3d->nz, dp.sdf3d->data.data()));
+      if (dp.arm)
+        _dev->check(gvi_factors_set_arm(_dev->get(), id, (int)dp.arm->a.size(), dp.arm->a.data(), dp.arm->alpha.data(),
+                                        dp.arm->d.data(), dp.arm->theta_bias.data(), (int)dp.arm->frames.size(),
+                                        dp.arm->frames.data(), dp.arm->centers.data(), dp.arm->radii.data()));
     }
   }
   void push_temperatures() {

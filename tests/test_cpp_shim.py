@@ -60,3 +60,28 @@ def test_1d_prox_example_reproduces_reference_trace(tmp_path, golden_dir):
         assert got.shape == ref.shape == (10,)
         assert np.abs(got - ref).max() < tol, name
 
+
+@pytest.mark.gpu
+def test_planar_example_matches_python_binding():
+    """examples/planar_example.cpp: a planning graph with obstacle factors built from the shim's reference-shaped
+    constructors + DevicePsi descriptors (PlanarSDF shared by the factors).  Same problem through the Python binding."""
+    import re
+    from gaussianvi_amd import api, synthetic as syn
+    build.build_examples()
+    exe = os.path.join(os.path.dirname(build.build_examples()), "planar_example")
+    r = subprocess.run([exe, "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("iter ")]
+    assert len(lines) == 5
+    ch = syn.make_planar_chain(jitter=0.0)
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    for it, line in enumerate(lines):
+        res = ctx.ngd_step(0.55, 10)
+        cost = float(line.split("cost")[1].split("->")[0])
+        pts = np.array([[float(a), float(b)] for a, b in re.findall(r"\(([-0-9.e]+), ([-0-9.e]+)\)", line)])
+        mu = ctx.ngd_get_state()["mu"]
+        assert res["accepted"] and abs(cost - res["new_cost"]) < 1e-9 * abs(cost)
+        assert np.abs(pts - mu[::4, :2]).max() < 1e-8
+    ctx.close()
+
