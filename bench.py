@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
 """Benchmark of the NGD Gauss-Hermite hot path on MI355X (contract: see the round prompt).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5|c3lit]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the synthetic
-1024-factor LTV-prior chain, d = 12, sparse-GH p = 5 (N = 17 217 sigma points per factor), T = 1025
-states of size 6, fp64, plus one unary d = 6 measurement factor per state (see
-gaussianvi_amd/synthetic.py for why).  One STEP = one NGD iteration of GVIGH::optimize
-(gvibase/GVI-GH-impl.h:39-118) entirely on the device: moments pass of every factor, ordered
-assemble, block-tridiagonal solve, then line-search trials (axpy, chain factorisation = log-det +
-marginals, gather, cost pass) until the first accepted one.  Inputs are resident in HBM before the
-timed region.  `value` = every psi evaluation executed in the timed region (one per (factor, sigma
-point) per pass, counted once) / wall time, whole job.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): the synthetic 1024-factor LTV-prior
+chain, d = 12, sparse-GH p = 5 (N = 17 217 sigma points per factor), T = 1025 states of size 6, fp64, plus one unary
+d = 6 measurement factor per state (gaussianvi_amd/synthetic.py says why).  One STEP = one NGD iteration of
+GVIGH::optimize (gvibase/GVI-GH-impl.h:39-118) entirely on the device: moments pass of every factor, ordered assemble,
+block-tridiagonal solve, then line-search trials (axpy, chain factorisation = log-det + marginals, gather, cost) until the
+first accepted one.  Inputs are resident in HBM before the timed region.
 
-N > 1: the factor list is sharded contiguously over the ranks; the assembled [g | D | U] partials and the trial
-cost are all-reduced over RCCL; the chain recursions are replicated.  Default --scaling weak: 1024 factors per
-GPU (a 1024 N-factor chain, "c3xN"), per-GPU work fixed; --scaling strong: BASELINE configs[3], the same
-1024-factor chain over N GPUs (latency-bound: 128 factors per GPU at N = 8).
+What the JSON line reports
+  value                      every psi evaluation executed in the timed region / wall time, whole job.  The passes are
+                             COUNTED BY THE LIBRARY (gvi_ngd_counters): `full` passes accumulate all moments, `cost`
+                             passes only m0.  With the default adaptive scheduling an accepted iteration runs ONE full
+                             pass (its m0 is the trial cost, its moments are the next gradients), so value ~ the
+                             moments-pass rate; both rates are given separately as well.
+  roofline.frac              EXECUTED fp64 VALU issue slots of the dominant launch (each v_fma/v_mul/v_add_f64 counted
+                             as one FMA = 2 flop) / the 78.6 TF fp64 peak -- the fraction of the pipe that is used.
+                             The SURVEY 8(d) algorithmic figure (638 flop per evaluation for the reference's x-space
+                             formulation) is kept as roofline.algorithmic.
+  N > 1                      default --scaling strong = BASELINE configs[3]: the SAME 1024-factor chain, factor list
+                             sharded contiguously over the ranks; --scaling weak runs a (1024 N)-factor chain ("c3xN")
+                             and says so in `metric`.
 """
 from __future__ import annotations
 
@@ -31,12 +37,26 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_PEAK = 78.6e12        # FLOP/s, AMD public spec sheet (vector = matrix fp64 on MI355X); not in the guide
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+
+
+def ensure_library(rank: int) -> None:
+    """Build the in-tree C-ABI library if the checkout has none -- BEFORE anything touches the GPU or a process group
+    (hipcc must not be spawned from a process that has initialised HIP, and every rank has to take the same path):
+    rank 0 builds into a temporary file and renames it into place (atomic), the other ranks wait for the file."""
+    from gaussianvi_amd import _lib, build
+    if os.path.exists(_lib.LIB_PATH):
+        return
+    if rank == 0:
+        build.build_lib()
+        return
+    t0 = time.time()
+    while not os.path.exists(_lib.LIB_PATH):
+        if time.time() - t0 > 900:
+            raise SystemExit(f"rank {rank}: {_lib.LIB_PATH} did not appear (rank 0 builds it)")
+        time.sleep(0.5)
 
 
 def api_count(d, p):
@@ -49,6 +69,7 @@ def cpu_baseline(chain, seconds):
     Integrate passes with psi re-evaluated through a function pointer, OpenMP over factors) timed on
     this box's host cores on a bounded sample of the SAME workload: the first factors of the prior set
     at their start-state marginals (as many as ~`seconds` of CPU work allow, at most 256), repeated."""
+    import numpy as np  # noqa: F401
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     import gvi_oracle as o
@@ -90,27 +111,56 @@ def cpu_baseline(chain, seconds):
             "fused_single_pass_value": out["fused"]}
 
 
+def exec_ops(d: int, m: int, full: bool) -> int:
+    """fp64 VALU instructions per evaluation of a sum-of-squares psi with m residual rows in the z-space formulation
+    (DESIGN section 2): u = u0 + H z (m d FMA), psi = sum s_r u_r^2 (m MUL + m FMA), c = w psi (1), m0 (1); the full
+    pass adds t = c z (d), m1 (d) and the packed upper triangle of M2 (d (d + 1) / 2 FMA)."""
+    ops = m * d + 2 * m + 2
+    if full:
+        ops += 2 * d + d * (d + 1) // 2
+    return ops
+
+
+def alg_flops(d: int, m: int) -> int:
+    """expand d^2 + residual + quadratic form (m^2 + m each) + accumulate 1 + d + d (d + 1) / 2 FMA."""
+    return 2 * (d * d + 2 * (m * m + m) + 1 + d + d * (d + 1) // 2)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="c3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 register (LDS operands), 3 operand-resident, 5 register (SGPR operands)")
-    ap.add_argument("--scaling", choices=["strong", "weak"], default="weak",
-                    help="weak (default): 1024 factors PER GPU, i.e. a (1024 N)-factor chain (config c3xN) sharded over the N "
-                         "ranks -- per-GPU work fixed; strong (BASELINE configs[3]): the same 1024-factor chain over N GPUs "
-                         "(128 factors per GPU at N = 8: bounded by the replicated chain recursions and two collectives)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default, BASELINE configs[3]): the same chain over N GPUs (128 factors per GPU at N = 8: bounded "
+                         "by the replicated chain recursions and the exchange); weak: 1024 factors PER GPU, i.e. a (1024 N)-factor "
+                         "chain (config c3xN) -- the metric string then names c3xN")
+    ap.add_argument("--fuse-trial", type=int, default=2, choices=[0, 1, 2],
+                    help="gvi_ngd_set_mode: 0 the reference's pass order (gradient pass + one cost pass per trial), 1 fused, "
+                         "2 adaptive (library default)")
     ap.add_argument("--restart-every", type=int, default=30,
                     help="re-initialise (mu0, precision0) inside the timed region every R steps so that every step is a "
                          "descending iteration with one accepted trial (the chain converges after ~35 steps)")
     args = ap.parse_args()
+    big = args.config.startswith("c5") and args.config != "c5mini"
+    if args.steps is None:
+        args.steps = 3 if big else 200
+    if args.warmup is None:
+        args.warmup = 1 if big else 20
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ensure_library(rank)                               # before torch.cuda / the process group (see docstring)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     # rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device):
     # GVI_BENCH_REHEARSAL=1 puts every rank on cuda:0 and exchanges through gloo.  Timings of such a run mean nothing.
     rehearsal = os.environ.get("GVI_BENCH_REHEARSAL") == "1"
@@ -124,19 +174,17 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     use_pg = world > 1 or "RANK" in os.environ
+    rccl_ranks = None
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            probe = torch.ones(1, dtype=torch.float64, device="cuda")
+            dist.all_reduce(probe)                     # an actual RCCL collective: how many ranks took part
+            rccl_ranks = int(round(float(probe.item())))
 
-    from gaussianvi_amd import _lib, build
-    if not os.path.exists(_lib.LIB_PATH):          # checkout without build artefacts: build once (rank 0 first)
-        if rank == 0:
-            build.build_lib()
-        if use_pg:
-            dist.barrier()
     from gaussianvi_amd import api, synthetic
     from gaussianvi_amd.dist import HipEngine, ShardedNGD, shard_chain
 
@@ -146,6 +194,7 @@ def main():
     local = shard_chain(chain, rank, world)
     ctx, ids = api.context_for_chain(local, device=local_rank)
     ctx.set_variant(args.variant)
+    ctx.ngd_set_mode(True, args.fuse_trial)
     engine = HipEngine(ctx, local_rank)
     ngd = ShardedNGD(engine, world=world)
     ngd.group_forced = use_pg and world == 1
@@ -157,17 +206,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    evals_moments = sum(K * N for (K, d, p, N) in ctx.sets)       # local, per pass
+    evals_pass = sum(K * N for (K, d, p, N) in ctx.sets)          # local, per pass over every set
     # one process: the whole iteration (backtracking loop included) is one C-ABI call; sharded: the
     # Python driver interleaves the two all-reduces between the *_local / *_finish halves
-    step_fn = (lambda: ctx.ngd_step(0.55, 10)) if (world == 1 and not ngd.group_forced) else (lambda: ngd.step(0.55, 10))
+    single = world == 1 and not ngd.group_forced
+    step_fn = (lambda: ctx.ngd_step(0.55, 10)) if single else (lambda: ngd.step(0.55, 10))
+
     def restart():
         ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
         ngd.reset()
 
     # one-time costs (buffer growth on the first cost pass, side stream / event creation, kernel attribute calls, the
     # cold Jacobi start) are primed outside the contract's W warm-up steps as well, so a small W does not time them
-    for i in range(max(0, 8 - args.warmup)):
+    for i in range(0 if big else max(0, 8 - args.warmup)):
         step_fn()
     # the W warm-up steps start from the initial state; the timed steps continue from there, so the timed region
     # begins with the iteration pipeline warm (a restart costs one cold step: synchronous upload + chain refresh)
@@ -178,23 +229,28 @@ def main():
             restart(); pos = 0
         step_fn(); pos += 1
     barrier()
+    ctx.ngd_counters(reset=True)
     t0 = time.perf_counter()
-    passes, kern_ms, log = 0, [], []
+    kern_ms, log = [], []
     for i in range(args.steps):
         if pos == args.restart_every:
             restart(); pos = 0                          # timed: host upload + one refresh of the chain products
         r = step_fn(); pos += 1
         log.append(r)
-        passes += 1 + r["ntrials"]
         if i % 8 == 7 or i == args.steps - 1:
-            kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch (sampled: every 8th)
+            try:
+                kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch (sampled: every 8th)
+            except api.GviError:
+                pass
     barrier()
     elapsed = time.perf_counter() - t0
+    n_full, n_cost = ctx.ngd_counters()
 
-    # extra (not part of `value`): the fused single-pass scheduling of the same iteration
-    fused = None
-    if world == 1 and not ngd.group_forced:
-        ctx.ngd_set_mode(True, True)
+    # A/B leg (not part of `value`): the reference's pass order -- a cost-only pass per trial and a separate
+    # gradient pass per iteration (gvi_ngd_set_mode fuse_trial = 0); same iterates, one more psi pass per iteration
+    ab = None
+    if single and not big and args.fuse_trial != 0:
+        ctx.ngd_set_mode(True, 0)
         ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
         fpos = 0
         for _ in range(max(1, args.warmup)):
@@ -202,6 +258,7 @@ def main():
                 ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"]); fpos = 0
             ctx.ngd_step(0.55, 10); fpos += 1
         torch.cuda.synchronize()
+        ctx.ngd_counters(reset=True)
         tf0 = time.perf_counter()
         flog = []
         for i in range(args.steps):
@@ -210,98 +267,122 @@ def main():
             flog.append(ctx.ngd_step(0.55, 10)); fpos += 1
         torch.cuda.synchronize()
         tf = time.perf_counter() - tf0
-        fused = {"ms_per_step": 1e3 * tf / args.steps, "ngd_iters_per_s": args.steps / tf,
-                 "final_cost": flog[-1]["new_cost"], "trials_per_step": float(np.mean([r["ntrials"] for r in flog])),
-                 "note": "gvi_ngd_set_mode(fuse_trial=1): one psi pass per accepted iteration (trial cost = m0 of the "
-                         "full moments pass that is also the next gradient pass); identical iterates"}
-        ctx.ngd_set_mode(True, False)
+        f_full, f_cost = ctx.ngd_counters()
+        ab = {"ms_per_step": 1e3 * tf / args.steps, "ngd_iters_per_s": args.steps / tf,
+              "final_cost": flog[-1]["new_cost"], "trials_per_step": float(np.mean([r["ntrials"] for r in flog])),
+              "full_passes": f_full, "cost_passes": f_cost,
+              "all_pass_evals_per_s": (f_full + f_cost) * evals_pass / tf,
+              "note": "gvi_ngd_set_mode(fuse_trial=0): the reference's pass order (one gradient pass per iteration + one "
+                      "m0-only cost pass per trial); identical iterates"}
+        ctx.ngd_set_mode(True, args.fuse_trial)
 
-    stats = torch.tensor([elapsed, float(passes * evals_moments)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, float(n_full * evals_pass), float(n_cost * evals_pass)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        elapsed, total_evals = float(tmax[0]), float(stats[1])
+        elapsed, evals_full, evals_cost = float(tmax[0]), float(stats[1]), float(stats[2])
     else:
-        total_evals = float(stats[1])
+        evals_full, evals_cost = float(stats[1]), float(stats[2])
 
     if rank == 0:
         K0, d0, p0, N0 = ctx.sets[0]
+        m0 = d0 // 2
         geo = ctx.profile_geometry(ids[0])
-        km = float(np.mean(kern_ms)) * 1e-3
-        alg_bytes = K0 * N0 * (d0 + 1) * 8                      # (d+1) s bytes per eval
-        n_half = d0 // 2
-        f_alg = 2 * (d0 * d0 + 2 * n_half * n_half + 2 * n_half + 1 + d0 + d0 * (d0 + 1) // 2)
+        km = float(np.mean(kern_ms)) * 1e-3 if kern_ms else float("nan")
         sreg_shapes = (4, 8, 12)
         if geo["variant"] == 5:
-            kernel_name = f"moments_sreg_pair_kernel<{d0}, {d0 // 2}, {d0 // 2}, {d0 // 2}, full>"
+            kernel_name = f"moments_sreg_pair_kernel<{d0}, {m0}, {m0}, {m0}, full>"
         elif geo["variant"] == 2:
-            kernel_name = {0: f"moments_sreg_kernel<{d0}, {d0 // 2}, full>" if d0 in sreg_shapes else f"moments_reg_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>",
-                           5: f"moments_sreg_kernel<{d0}, {d0 // 2}, full>", 2: f"moments_reg_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>",
-                           3: f"moments_wide_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>",
-                           4: f"moments_tile_kernel<{d0}, PsiQuad<{d0},{d0 // 2}>, full>"}.get(args.variant, "moments_reg_kernel")
+            kernel_name = {0: f"moments_sreg_kernel<{d0}, {m0}, full>" if d0 in sreg_shapes else f"moments_reg_kernel<{d0}, PsiQuad<{d0},{m0}>, full>",
+                           5: f"moments_sreg_kernel<{d0}, {m0}, full>", 2: f"moments_reg_kernel<{d0}, PsiQuad<{d0},{m0}>, full>",
+                           3: f"moments_wide_kernel<{d0}, PsiQuad<{d0},{m0}>, full>",
+                           4: f"moments_tile_kernel<{d0}, PsiQuad<{d0},{m0}>, full>"}.get(args.variant, "moments_reg_kernel")
         elif geo["variant"] == 3:
-            kernel_name = f"moments_split_kernel<{d0}, {(d0 // 2 + 3) // 4}, full>"
+            kernel_name = f"moments_split_kernel<{d0}, {(m0 + 3) // 4}, full>"
         else:
             kernel_name = "moments_generic_kernel"
-        flop_launch, evals_launch = f_alg * K0 * N0, K0 * N0
-        exec_ops = n_half * d0 + 2 * n_half + 2 + 2 * d0 + d0 * (d0 + 1) // 2   # psi rows (+ square, sign), c = w psi, m0, t = c z, m1, packed M2
+        # work of the bracketed launch: the prior set, plus the unary set when both ride in one launch
+        sets_in_launch = [(K0, d0, m0, N0)]
         fused_pair = geo["variant"] == 5 and len(ctx.sets) == 2
         if fused_pair:
-            # the timed launch also carries the unary set (d = n, psi = (x-mu0)^T Kinv (x-mu0): d^2 + d for psi):
-            # SURVEY 8(d) formula with the unary residual count
             K1, d1, p1, N1 = ctx.sets[1]
-            f_alg1 = 2 * (d1 * d1 + d1 * d1 + d1 + 1 + d1 + d1 * (d1 + 1) // 2)
-            flop_launch += f_alg1 * K1 * N1
-            evals_launch += K1 * N1
-            alg_bytes += K1 * N1 * (d1 + 1) * 8
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
+            sets_in_launch.append((K1, d1, d1, N1))            # unary: psi = (x - mu0)^T Kinv (x - mu0), m = d
+        evals_launch = sum(K * N for K, d, m, N in sets_in_launch)
+        exec_flop = sum(2 * exec_ops(d, m, True) * K * N for K, d, m, N in sets_in_launch)
+        alg_flop = sum(alg_flops(d, m) * K * N for K, d, m, N in sets_in_launch)
+        alg_bytes = sum(K * N * (d + 1) * 8 for K, d, m, N in sets_in_launch)   # (d+1) s bytes per eval
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, TRAFFIC_FILE)
+        if args.config == "c3" and world == 1 and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_source = TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
             except Exception:
                 traffic = None
+        base_metric = "sigma-point psi-evals/sec + NGD iters/sec, 1024-factor d=12 p=5 chain"
+        if args.config == "c3":
+            metric = base_metric
+        else:
+            metric = f"sigma-point psi-evals/sec + NGD iters/sec, {chain['T'] - 1}-factor d={d0} p={p0} chain ({args.config})"
         out = {
-            "metric": "sigma-point psi-evals/sec + NGD iters/sec, 1024-factor d=12 p=5 chain" if args.config.startswith("c3")
-                      else f"sigma-point psi-evals/sec + NGD iters/sec, {chain['T'] - 1}-factor d={d0} p={p0} chain",
-            "value": total_evals / elapsed, "unit": "psi-evals/s",
+            "metric": metric,
+            "value": (evals_full + evals_cost) / elapsed, "unit": "psi-evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, **({"rehearsal": "all ranks on cuda:0, gloo exchange: not a measurement"} if rehearsal else {}), "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
+            **({"rehearsal": "all ranks on cuda:0, gloo exchange: not a measurement"} if rehearsal else {}),
+            **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {}),
+            "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {chain['T'] - 1}-factor prior chain, d={d0}, sparse-GH p={p0} (N={N0}), "
                                    f"T={chain['T']} n={chain['n']}, +{chain['T']} unary d={chain['n']} factors; one step = one device-resident NGD iteration "
                                    f"(state re-initialised inside the timed region every {args.restart_every} steps)",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": f"factors/{world} contiguous, all-reduce [g|D|U] + trial cost (RCCL)" if world > 1 else "none",
-                       "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"]},
+                       "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"],
+                       "fuse_trial": args.fuse_trial},
             "ngd_iters_per_s": args.steps / elapsed,
+            # `value` split by pass kind (SURVEY 8(d) defines an evaluation "in one moments pass")
+            "passes": {"full": n_full, "cost_only": n_cost, "evals_per_pass": evals_pass * world if world > 1 else evals_pass,
+                       "moments_pass_evals_per_s": evals_full / elapsed, "cost_pass_evals_per_s": evals_cost / elapsed,
+                       "all_pass_evals_per_s": (evals_full + evals_cost) / elapsed},
             "accepted_steps": int(sum(r["accepted"] for r in log)),
             "trials_per_step": float(np.mean([r["ntrials"] for r in log])),
             "final_cost": log[-1]["new_cost"],
-            "fused_trial_mode": fused,
+            "reference_pass_order": ab,
             "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": evals_launch / km,
                                "launch": "prior set + unary set in one launch" if fused_pair else "prior set"},
-            # The dominant kernel streams only the (d,p) table, which is L2-resident (profiles/r01_traffic.json:
-            # HBM traffic ~0.5 % of the algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.
-            # The schema's compute label is "mfma"; fp64 MFMA and fp64 VALU share one pipe on MI355X and the
-            # VALU form is the faster one (profiles/r01_fp64_pipes.txt), so the kernel uses v_fma_f64.
-            "roofline": {"bound": "mfma", "achieved": flop_launch / km / 1e12, "peak": FP64_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": flop_launch / km / FP64_PEAK, "traffic": traffic,
-                         "kernel": kernel_name,
-                         "note": "achieved/frac use SURVEY 8(d)'s ALGORITHMIC count (the reference's x-space expand + psi + three "
-                                 "moment passes = 638 flop per evaluation).  The kernel's z-space formulation executes 188 fp64 "
-                                 "FMA/MUL (376 flop) per evaluation, so frac can exceed 1; executed_tflops / 78.6 is the "
-                                 "fraction of the pipe actually used.",
-                         "algorithmic_flop_per_eval": f_alg, "executed_fp64_ops_per_eval": exec_ops,
-                         "executed_tflops": 2 * exec_ops * K0 * N0 / km / 1e12,   # prior set only
+            # The dominant kernel streams only the (d,p) table, which is L2-resident (HBM traffic ~0.5 % of the
+            # algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.  The contract's compute label is
+            # "mfma"; the kernel issues NO MFMA instruction: fp64 MFMA and fp64 VALU share one pipe on MI355X and
+            # v_fma_f64 is the faster form (profiles/r01_fp64_pipes.txt), hence "pipe".
+            "roofline": {"bound": "mfma", "pipe": "valu_f64 (v_fma_f64; zero MFMA instructions)",
+                         "achieved": exec_flop / km / 1e12, "peak": FP64_PEAK / 1e12,
+                         "unit": "TFLOP/s", "frac": exec_flop / km / FP64_PEAK,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name, "kernel_ms": km * 1e3, "evals_per_launch": evals_launch,
+                         "executed_fp64_ops_per_eval": {f"d={d},m={m}": exec_ops(d, m, True) for K, d, m, N in sets_in_launch},
+                         "note": "achieved/frac = EXECUTED fp64 VALU instructions of the bracketed launch (every set in it), each "
+                                 "counted as one FMA (2 flop), / HIP-event time / 78.6 TF",
+                         "algorithmic": {"flop_per_eval": alg_flops(d0, m0), "tflops": alg_flop / km / 1e12,
+                                         "frac_of_peak": alg_flop / km / FP64_PEAK,
+                                         "note": "SURVEY 8(d) count of the reference's x-space algorithm (expand GEMM + psi + three "
+                                                 "moment passes); exceeds the executed figure because the z-space reformulation "
+                                                 "removes the expand -- a statement about the algorithm, not about the pipe"},
                          "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "
-                                        "Measured on this box (tools/ubench/fp64_pipes.hip): 70 TF v_fma_f64, 48 TF v_mfma_f64_16x16x4",
+                                        "Measured on this pool (tools/ubench/fp64_pipes.hip): 70 TF v_fma_f64, 48 TF v_mfma_f64_16x16x4",
                          "hbm_algorithmic": {"bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / km / 1e9,
                                              "peak_GBps": HBM_PEAK / 1e9, "frac": alg_bytes / km / HBM_PEAK,
                                              "note": "BASELINE's '>= 60 % of HBM roofline' figure: (d+1)*8 B per eval over 8 TB/s; "
                                                      "exceeds 1 because the table is served from L2"}},
         }
+        if world > 1:
+            # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU kernel times of this round
+            # (profiles/): factor work W shards, the chain recursions R are replicated, two exchanges X are added.
+            W, R, X = 0.165, 0.085, 0.040                     # ms, DESIGN section 5
+            out["strong_scaling_model"] = {"W_ms_sharded": W, "R_ms_replicated": R, "X_ms_exchange": X,
+                                           "expected_speedup_at_n": (W + R) / (W / world + R + X),
+                                           "note": "t(N) = W / N + R + X; the ceiling as N grows is (W + R) / (R + X)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -119,7 +119,7 @@ class Context:
     def factors_add(self, d, p, start, kind, params=None, temperature=None):
         start = np.ascontiguousarray(start, dtype=np.int32)
         K = len(start)
-        params = None if params is None else _f64(params).reshape(K, -1)
+        params = None if params is None else (_f64(params).reshape(K, -1) if K else np.zeros((0, int(np.prod(np.shape(params)[1:])) or 1)))
         temperature = None if temperature is None else _f64(temperature)
         sid = C.c_int()
         self._ck(self.lib.gvi_factors_add(self.h, K, d, p, _p(start), kind, _p(params),
@@ -290,8 +290,15 @@ class Context:
                                        C.byref(c1), C.byref(ntr)))
         return dict(cost_iter=c0.value, accepted=bool(ok.value), new_cost=c1.value, ntrials=ntr.value)
 
-    def ngd_set_mode(self, speculate=True, fuse_trial=False):
+    def ngd_set_mode(self, speculate=True, fuse_trial=2):
+        """fuse_trial: 0 separate cost pass, 1 fused (full pass at the trial point), 2 adaptive (default)."""
         self._ck(self.lib.gvi_ngd_set_mode(self.h, int(speculate), int(fuse_trial)))
+
+    def ngd_counters(self, reset=False):
+        """(full psi passes, cost-only psi passes) launched by the resident iteration since the last reset."""
+        a, b = C.c_int64(), C.c_int64()
+        self._ck(self.lib.gvi_ngd_counters(self.h, C.byref(a), C.byref(b), int(reset)))
+        return a.value, b.value
 
     def ngd_exchange(self, which):
         ptr, cnt = C.c_void_p(), C.c_int64()

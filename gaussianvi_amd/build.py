@@ -41,18 +41,22 @@ def lib_sources():
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale(LIB, lib_sources()):
         return LIB
+    tmp = LIB + f".tmp{os.getpid()}"          # written aside and renamed: a concurrent reader never sees a partial file
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"),
            os.path.join(CSRC, "gvi_hip.hip"), "-x", "hip", os.path.join(CSRC, "spgh.cpp"), os.path.join(CSRC, "table_io.cpp"),
-           "-o", LIB]
+           "-o", tmp]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose:
         sys.stderr.write(r.stderr)
     if r.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stderr[-8000:])
+    os.replace(tmp, LIB)
     return LIB
 
 
@@ -62,7 +66,7 @@ def build_examples(force: bool = False) -> str:
     out_dir = os.path.join(ROOT, "examples", "bin")
     os.makedirs(out_dir, exist_ok=True)
     first = None
-    for name in ("1d_example", "1d_example_prox", "planar_example"):
+    for name in ("1d_example", "1d_example_prox", "planar_example", "factorwise_example"):
         src = os.path.join(ROOT, "examples", name + ".cpp")
         exe = os.path.join(out_dir, name)
         deps = [src, os.path.join(ROOT, "include", "gvi", "gvi_host.hpp"), os.path.join(ROOT, "include", "gvi_hip.h")]

@@ -4,12 +4,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_linalg.hpp"
@@ -132,7 +135,12 @@ struct gvi_ctx {
   std::string err;
   int variant = 0;
   bool warm_start = true;             // resident NGD: Jacobi warm start from the previous eigenvectors
-  bool fuse_trial = false;            // gvi_ngd_step: trial cost from the full moments pass (one psi pass per iteration)
+  // gvi_ngd_step: trial cost from the full moments pass at the trial point (one psi pass per accepted iteration).
+  // 0 never, 1 always (first trial), 2 adaptive (default): fused while first trials keep being accepted, the m0-only
+  // cost pass after a rejection (a rejected fused trial wastes the moment accumulation)
+  int fuse_trial = 2;
+  bool last_first_accepted = true;
+  int64_t n_full_pass = 0, n_cost_pass = 0;   // psi passes launched over all sets (gvi_ngd_counters)
   bool speculate = true;              // gvi_ngd_step: queue the next gradients behind the first trial
   int bcr_variant = 0;                // 0 auto (segmented where instantiated), 1 per-level kernels
   bool profile = false;
@@ -163,7 +171,11 @@ struct gvi_ctx {
   hipStream_t chain_stream = nullptr; // stream of the chain launches being queued (null: ctx->stream)
   int chain_ws = 0;
   double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
+  // kernels whose dynamic-LDS limit was raised on THIS context's device (the attribute is per device, and a
+  // process may hold contexts on several devices)
+  std::set<const void*> lds_attr_done;
   double seq = 0.0;
+  int spin_ms = 2;                    // wall-time bound of the host spin on the publish word (GVI_SPIN_MS)
   double* host_slot_dev = nullptr;
 };
 
@@ -187,6 +199,14 @@ gvi_status fail(gvi_ctx* c, gvi_status s, const std::string& msg) {
     gvi_status s__ = (expr);                 \
     if (s__ != GVI_OK) return s__;           \
   } while (0)
+
+// raise a kernel's dynamic-LDS limit once per context (= per device)
+gvi_status allow_lds(gvi_ctx* c, const void* func, int bytes) {
+  if (c->lds_attr_done.count(func)) return GVI_OK;
+  HIPCK(c, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  c->lds_attr_done.insert(func);
+  return GVI_OK;
+}
 
 size_t bt_count(const gvi_ctx* c) { return (size_t)(2 * c->T - 1) * c->n * c->n; }   // [D | U]
 size_t nn_(const gvi_ctx* c) { return (size_t)c->n * c->n; }
@@ -281,12 +301,8 @@ bool split_supported(const FactorSet& s) {
 template <int D, int R>
 gvi_status launch_split(gvi_ctx* c, const MomArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)SPLIT_LDS_DOUBLES(D) * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCK(c, hipFuncSetAttribute((const void*)moments_split_kernel<D, R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  GVICK(allow_lds(c, (const void*)moments_split_kernel<D, R, true>, (int)lds));
+  GVICK(allow_lds(c, (const void*)moments_split_kernel<D, R, false>, (int)lds));
   if (a.full) hipLaunchKernelGGL((moments_split_kernel<D, R, true>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((moments_split_kernel<D, R, false>), grid, dim3(256), lds, st, a);
   return GVI_OK;
@@ -447,6 +463,7 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
   if (!st) st = c->stream;
   if (slot >= 0 && s.prep_slot == slot) return GVI_OK;     // products of this slot are still resident
   s.prep_slot = slot;
+  if (s.K == 0) return GVI_OK;
   const int d = s.d, dp = d + (d & 1);
   const size_t lds = (size_t)(4 * d * d + 2 * dp + 3 * d) * 8 + (size_t)dp * 4 + 16;
   if (d <= 8) hipLaunchKernelGGL(prep_kernel<1>, dim3(s.K), dim3(64), lds, st, s.dev(), mu, Sigma);
@@ -461,6 +478,7 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
 gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full,
                        hipStream_t st = nullptr) {
   if (!st) st = c->stream;
+  if (s.K == 0) { s.nchunk = 1; s.chunk = s.table->Np; s.use_reg = s.use_split = false; return GVI_OK; }   // empty shard
   if (s.kind == KIND_HINGE_SDF_3D_ARM && !psi_ext && !s.arm.p)
     return fail(c, GVI_ERR_STATE, "HINGE_SDF_3D_ARM set without an arm model: call gvi_factors_set_arm");
   if (s.kind >= KIND_HINGE_SDF_2D && !psi_ext && s.sdf_rows == 0)
@@ -539,12 +557,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     const int d = s.d, m = s.m;
     const size_t lds = (size_t)(2 * GEN_BS * (d + 1) + GEN_BS + d * d + d + m * d + 2 * m) * 8;
     if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIPCK(c, hipFuncSetAttribute((const void*)moments_generic_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    GVICK(allow_lds(c, (const void*)moments_generic_kernel, 160 * 1024));
     hipLaunchKernelGGL(moments_generic_kernel, dim3(s.K, s.nchunk), dim3(GEN_BS), lds, st, a);
   }
   HIPCK(c, hipGetLastError());
@@ -558,6 +571,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
 gvi_status run_epilogue(gvi_ctx* c, FactorSet& s, int full, double* Ephi, double* cost, double* Vdmu,
                         double* Vddmu, double* Ex, double* Exx, hipStream_t st = nullptr) {
   if (!st) st = c->stream;
+  if (s.K == 0) return GVI_OK;
   EpiArgs e;
   e.f = s.dev(); e.partial = s.partial.d(); e.nchunk = s.nchunk; e.full = full;
   e.Ephi = Ephi; e.cost = cost; e.Vdmu = Vdmu; e.Vddmu = Vddmu; e.E_xmuphi = Ex; e.E_xxphi = Exx;
@@ -624,12 +638,7 @@ gvi_status launch_bcr_forward(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
   }
   a.tail_from = pl.tail_from;
   const size_t lds = unit * pl.waves;
-  static bool attr = false;
-  if (!attr) {
-    HIPCK(c, hipFuncSetAttribute((const void*)bcr_forward_tail_kernel<PIVOT, NMAX>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  GVICK(allow_lds(c, (const void*)bcr_forward_tail_kernel<PIVOT, NMAX>, 160 * 1024));
   hipLaunchKernelGGL((bcr_forward_tail_kernel<PIVOT, NMAX>), dim3(1), dim3(64 * pl.waves), lds, c->stream, a);
   HIPCK(c, hipGetLastError());
   return GVI_OK;
@@ -691,14 +700,8 @@ SegPlan seg_plan(const gvi_ctx* c) {
 
 template <bool PIVOT, int N>
 gvi_status launch_seg(gvi_ctx* c, SegArgs a, const SegPlan& pl) {
-  static bool attr = false;
-  if (!attr) {
-    HIPCK(c, hipFuncSetAttribute((const void*)bcr_seg_forward_kernel<PIVOT, N>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCK(c, hipFuncSetAttribute((const void*)bcr_seg_backward_kernel<N>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  GVICK(allow_lds(c, (const void*)bcr_seg_forward_kernel<PIVOT, N>, 160 * 1024));
+  GVICK(allow_lds(c, (const void*)bcr_seg_backward_kernel<N>, 160 * 1024));
   const bool rhs = a.rhs != nullptr;
   hipStream_t st = c->chain_stream ? c->chain_stream : c->stream;
   for (const SegPass& ps : pl.passes) {
@@ -761,12 +764,7 @@ gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* S
   hipLaunchKernelGGL(bcr_logdet_kernel, dim3(1), dim3(256), 0, c->stream, c->T, w.logp, w.bad, hld);
   if (SigD) {
     const size_t unit = (size_t)7 * c->n * c->n * 8;
-    static bool attr = false;
-    if (!attr) {
-      HIPCK(c, hipFuncSetAttribute((const void*)bcr_back_marginals_head_kernel,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
+    GVICK(allow_lds(c, (const void*)bcr_back_marginals_head_kernel, 160 * 1024));
     hipLaunchKernelGGL(bcr_back_marginals_head_kernel, dim3(1), dim3(64 * pl.waves), unit * pl.waves, c->stream,
                        c->T, c->n, pl.nlevels, pl.tail_from, w, SigD, SigU);
     for (int l = pl.tail_from - 1; l >= 0; --l)
@@ -809,6 +807,7 @@ gvi_status run_scatter(gvi_ctx* c, FactorSet& s, const double* Vdmu, const doubl
 gvi_status run_gather(gvi_ctx* c, FactorSet& s, const double* mu, const double* SigD, const double* SigU,
                       double* mu_k, double* Sigma_k) {
   const int64_t total = (int64_t)s.K * (s.d + s.d * s.d);
+  if (total == 0) return GVI_OK;
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, s.K, s.d, c->n,
                      s.dstart.i(), mu, SigD, SigU, mu_k, Sigma_k);
   HIPCK(c, hipGetLastError());
@@ -856,9 +855,10 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
   if (const char* w = getenv("GVI_SPECULATE")) c->speculate = atoi(w) != 0;
   if (const char* w = getenv("GVI_WARM_START")) c->warm_start = atoi(w) != 0;
-  if (const char* w = getenv("GVI_FUSE_TRIAL")) c->fuse_trial = atoi(w) != 0;
+  if (const char* w = getenv("GVI_FUSE_TRIAL")) c->fuse_trial = std::min(2, std::max(0, atoi(w)));
+  if (const char* w = getenv("GVI_SPIN_MS")) c->spin_ms = std::max(0, atoi(w));
   if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
-      hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
     return fail(nullptr, GVI_ERR_HIP, "event / host-mapped slot allocation failed");
   c->host_slot[0] = c->host_slot[1] = c->host_slot[2] = 0.0;
@@ -956,7 +956,9 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
                            int* set_id) {
   if (!ctx) return GVI_ERR_ARG;
   if (ctx->T < 1) return fail(ctx, GVI_ERR_STATE, "call gvi_chain_set first");
-  if (K < 1 || !start) return fail(ctx, GVI_ERR_ARG, "K < 1 or start is NULL");
+  // K == 0 is a valid EMPTY set: the shard of a rank that received none of a small set's factors (set ids stay
+  // aligned across ranks); every launch skips it
+  if (K < 0 || (K > 0 && !start)) return fail(ctx, GVI_ERR_ARG, "K < 0 or start is NULL");
   const int n = ctx->n;
   if (d != n && d != 2 * n) return fail(ctx, GVI_ERR_ARG, "factor dimension must be n or 2n");
   for (int k = 0; k < K; ++k)
@@ -981,7 +983,7 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
 
   std::unique_ptr<FactorSet> s(new FactorSet);
   s->K = K; s->d = d; s->p = p; s->m = m; s->kind = psi_kind;
-  s->start.assign(start, start + K);
+  if (K > 0) s->start.assign(start, start + K);
   // quadrature table: shared between sets with the same (d, p)
   for (auto& t : ctx->tables) if (t->d == d && t->p == p) s->table = t;
   if (!s->table) {
@@ -1087,6 +1089,10 @@ gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const doub
   auto t = std::make_shared<Table>();
   GVICK(upload_table(ctx, *t, s->d, -1, N, Z, w));
   s->table = t;
+  s->prep_slot = -1;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;   // cost / gradients of the old table are stale
+  ctx->ngd.grad_valid = false;
+  ctx->ngd.spec_ready = false;
   return GVI_OK;
 }
 
@@ -1261,6 +1267,7 @@ gvi_status gvi_expand(gvi_ctx* ctx, int set_id, const double* mu, const double* 
   FactorSet* s = get_set(ctx, set_id);
   GVICK(check_pass_args(ctx, s, mu, Sigma));
   if (!X) return fail(ctx, GVI_ERR_ARG, "X is NULL");
+  if (s->K == 0) return GVI_OK;
   HIPCK(ctx, hipSetDevice(ctx->device));
   GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
   const size_t bytes = (size_t)s->K * s->d * s->table->N * 8;
@@ -1475,6 +1482,7 @@ static gvi_status ngd_prep_all(gvi_ctx* ctx, int i) {
   const int dp = dmax + (dmax & 1);
   const size_t lds = (size_t)(4 * dmax * dmax + 2 * dp + 3 * dmax + (dp + 1) / 2 + 1 + dmax * dmax + dmax) * 8 + 16;
   const dim3 grid(L.koff[L.nsets] + extra);
+  if (grid.x == 0) return GVI_OK;                                     // only empty shards
   if (dmax <= 8) hipLaunchKernelGGL(prep_all_kernel<1>, grid, dim3(64), lds, ctx->stream, L);
   else if (dmax <= 16) hipLaunchKernelGGL(prep_all_kernel<4>, grid, dim3(64), lds, ctx->stream, L);
   else if (dmax <= 32) hipLaunchKernelGGL(prep_all_kernel<16>, grid, dim3(64), lds, ctx->stream, L);
@@ -1507,6 +1515,7 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full) {
   int dmax = 0;
   const EpiList L = make_epi_list(ctx, full, &dmax);
   const size_t lds = (size_t)(npairs(dmax) + 2 * dmax * dmax) * 8;
+  if (L.koff[L.nsets] == 0) return GVI_OK;
   hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
@@ -1547,7 +1556,7 @@ static gvi_status ngd_refresh_gather(gvi_ctx* ctx, int i, const double* mu_from,
     if (s->prep_slot == i) s->prep_slot = -1;
     maxwork = std::max<int64_t>(maxwork, (int64_t)s->K * (s->d + s->d * s->d));
   }
-  hipLaunchKernelGGL(gather_all_kernel, dim3((unsigned)((maxwork + 255) / 256), (unsigned)ctx->sets.size() + (dmu ? 1u : 0u)),
+  hipLaunchKernelGGL(gather_all_kernel, dim3((unsigned)std::max<int64_t>(1, (maxwork + 255) / 256), (unsigned)ctx->sets.size() + (dmu ? 1u : 0u)),
                      dim3(256), 0, ctx->stream, make_set_list(ctx, i), ctx->n, dmu ? mu_from : g.mu[i].d(), sD, sU, dmu, step,
                      g.mu[i].d(), nmu);
   HIPCK(ctx, hipGetLastError());
@@ -1573,6 +1582,7 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
     if (publish) {
       ctx->seq += 1.0;
       hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev, ctx->seq);
+      HIPCK(ctx, hipGetLastError());
     }
     return GVI_OK;
   }
@@ -1602,18 +1612,44 @@ static gvi_status ngd_cost_publish(gvi_ctx* ctx, int i) {
   return GVI_OK;
 }
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  asm volatile("" ::: "memory");
+#endif
+}
+
 static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
   NgdState& g = ctx->ngd;
-  // spin on the host-mapped sequence word (a blocking stream sync costs tens of us of wake-up latency and
-  // would also wait for speculative work queued behind the publish); bounded: falls back to the stream sync
-  {
-    volatile double* slot = ctx->host_slot;
-    bool seen = false;
-    for (long spins = 0; spins < 20000000L; ++spins) {
+  // Spin on the host-mapped sequence word: a blocking stream sync costs tens of us of wake-up latency and would
+  // also wait for the speculative work queued behind the publish.  The spin is bounded by WALL TIME (2 ms -- an
+  // iteration is < 1 ms); past that the wait sleeps between polls (below).
+  volatile double* slot = ctx->host_slot;
+  bool seen = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 0;; ++spins) {
+    if (slot[2] == ctx->seq) { seen = true; break; }
+    cpu_relax();
+    if ((spins & 1023) == 1023 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(ctx->spin_ms)) break;
+  }
+  if (!seen) {
+    // long passes (config 5: seconds per pass): sleep-poll the word and, every millisecond, the stream itself, so a
+    // device fault or a drained stream without a publish ends the wait with an error instead of spinning
+    for (long polls = 0;; ++polls) {
       if (slot[2] == ctx->seq) { seen = true; break; }
-      __builtin_ia32_pause();
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+      if ((polls & 63) == 63) {
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) break;                       // everything queued has run
+        if (q != hipErrorNotReady) return fail(ctx, GVI_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+      }
     }
-    if (!seen) GVICK(sync(ctx));
+    if (!seen && slot[2] != ctx->seq)
+      return fail(ctx, GVI_ERR_STATE, "cost publish did not arrive (sequence word stale after the stream drained)");
   }
   __sync_synchronize();
   const double v = ctx->host_slot[0] + ctx->host_slot[1];     // cost_value = sum of factor costs + 1/2 log det
@@ -1703,11 +1739,12 @@ gvi_status gvi_ngd_factor_costs(gvi_ctx* ctx, int set_id, double* costs) {
 // All sets' moments (full = 1) or cost (full = 0) launches at slot.  The chain pattern -- set 0 binary priors (d = 2n,
 // m = n), set 1 unary factors (d = m = n), both on the SGPR-operand kernels -- goes out as ONE launch.
 static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
+  if (full) ++ctx->n_full_pass; else ++ctx->n_cost_pass;
   if (ctx->pair_fuse && ctx->sets.size() == 2 && !ctx->profile_all) {
     FactorSet& s0 = *ctx->sets[0];
     FactorSet& s1 = *ctx->sets[1];
     const bool shape = s0.kind == KIND_QUAD_PRIOR && s1.kind == KIND_FIXED_PRIOR && s0.d == 12 && s1.d == 6 &&
-                       !s0.closed_form && !s1.closed_form;
+                       !s0.closed_form && !s1.closed_form && s0.K > 0 && s1.K > 0;
     if (shape) {
       gvi_ctx::Deferred d0, d1;
       ctx->defer = &d0;
@@ -1852,6 +1889,7 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
     } else {
       hipLaunchKernelGGL(trial_kernel, dim3((unsigned)((bt + 255) / 256)), dim3(256), 0, ctx->stream, (int64_t)0, (int64_t)bt,
                          step, g.mu[c].d(), g.dmu2[g.gcur].d(), g.Lam[c].d(), g.exch0[g.gcur].d() + Tn, g.mu[t].d(), g.Lam[t].d());
+      HIPCK(ctx, hipGetLastError());
       GVICK(ngd_refresh_factor(ctx, t));
     }
     GVICK(ngd_join_solve(ctx, g.gcur));
@@ -1957,7 +1995,8 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
     const int t = 1 - g.cur;
     const bool spec = cnt == 0 && ctx->speculate;
     GVICK(ngd_trial_state(ctx, step));
-    if (spec && ctx->fuse_trial) {
+    const bool fuse = spec && (ctx->fuse_trial == 1 || (ctx->fuse_trial == 2 && ctx->last_first_accepted));
+    if (fuse) {
       // Fused form: ONE full moments pass at the trial point serves both the trial cost (its m0 column)
       // and -- if the trial is accepted -- the next iteration's gradients.  Same numbers, one psi pass
       // less per accepted iteration; a rejected first trial wasted the moment accumulation.
@@ -1980,6 +2019,7 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
     }
     GVICK(ngd_cost_wait(ctx, t, &c1));
     ++cnt;
+    if (cnt == 1) ctx->last_first_accepted = c1 < c0;
     if (c1 < c0) {                                 // NaN compares false -> rejected
       GVICK(gvi_ngd_accept(ctx));
       if (spec) { g.gcur = 1 - g.gcur; g.grad_valid = true; g.grad_slot = g.cur; }
@@ -2018,6 +2058,7 @@ gvi_status gvi_prox_gradients(gvi_ctx* ctx, double h) {
   GVICK(ngd_moments_full(ctx, g.cur));                    // Vdmu = b, Vddmu = S at unit temperature; f.Lam = Lam_k
   for (auto& sp : ctx->sets) {
     FactorSet& s = *sp;
+    if (s.K == 0) continue;
     const size_t K = s.K, d = s.d, dd = d * d;
     HIPCK(ctx, s.jko_half.ensure(K * dd * 8));
     HIPCK(ctx, s.jko_S.ensure(K * dd * 8));
@@ -2091,8 +2132,18 @@ gvi_status gvi_prox_step(gvi_ctx* ctx, double step_size_base, int max_backtrack,
 
 gvi_status gvi_ngd_set_mode(gvi_ctx* ctx, int speculate, int fuse_trial) {
   if (!ctx) return GVI_ERR_ARG;
+  if (fuse_trial < 0 || fuse_trial > 2) return fail(ctx, GVI_ERR_ARG, "fuse_trial must be 0, 1 or 2");
   ctx->speculate = speculate != 0;
-  ctx->fuse_trial = fuse_trial != 0;
+  ctx->fuse_trial = fuse_trial;
+  ctx->last_first_accepted = true;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_counters(gvi_ctx* ctx, int64_t* full_passes, int64_t* cost_passes, int reset) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (full_passes) *full_passes = ctx->n_full_pass;
+  if (cost_passes) *cost_passes = ctx->n_cost_pass;
+  if (reset) ctx->n_full_pass = ctx->n_cost_pass = 0;
   return GVI_OK;
 }
 

@@ -207,8 +207,13 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
  *              device does not idle while the host reads the cost; 0: strictly trial-then-decide;
  *   fuse_trial 1: the first trial's cost is taken from a FULL moments pass at the trial point, which is
  *              also the next iteration's gradient pass (one psi pass per accepted iteration instead of
- *              the reference's cost pass + gradient pass); 0 (default): separate passes as the reference. */
+ *              the reference's cost pass + gradient pass); 0: separate passes as the reference;
+ *              2 (default): adaptive -- fused while first trials keep being accepted, the cost-only pass for the
+ *              step after a rejected first trial (a rejected fused trial wastes the moment accumulation). */
 gvi_status gvi_ngd_set_mode(gvi_ctx* ctx, int speculate, int fuse_trial);
+/* psi passes launched by the resident iteration since the last reset: full (all moments) and cost-only (m0);
+ * one pass = every factor of every set once.  bench.py derives its evaluation counts from these. */
+gvi_status gvi_ngd_counters(gvi_ctx* ctx, int64_t* full_passes, int64_t* cost_passes, int reset);
 
 /* ---- proximal (JKO / Bures-Wasserstein) update rule: ProxGVIGH + ProxGVIFactorizedBaseGH
  *      (proxgd/ProxGVI-GH-impl.h:24-60, 121-202; proxgd/ProxGVIFactorizedBaseGH.h:64-113, 152-160).  Same quadrature

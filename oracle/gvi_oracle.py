@@ -997,6 +997,37 @@ class ChainNGD:
 
 
 # --------------------------------------------------------------------------------------------
+# VIMPResults (helpers/DataRecorder.h:25-225): what the nine CSV files hold.  `iterations` is a list of
+# (mean [T n], joint_cov [Tn, Tn], joint_precision [Tn, Tn], cost, factor_costs [K]) recorded by update_data (:88-112);
+# compress3d flattens a matrix with Eigen's reshaped(), i.e. COLUMN-major (helpers/EigenWrapper.h:228-232), one column
+# per iteration; columns of iterations that never ran stay zero (the arrays are preallocated with niters columns).
+# --------------------------------------------------------------------------------------------
+def vimp_results_files(iterations, niters, dim_state, nstates):
+    n, T = dim_state, nstates
+    Tn = n * T
+    nf = len(iterations[0][4]) if iterations else 0
+    out = dict(mean=np.zeros((Tn, niters)), cov=np.zeros((n * n * T, niters)), precision=np.zeros((n * n * T, niters)),
+               joint_cov=np.zeros((Tn * Tn, niters)), joint_precision=np.zeros((Tn * Tn, niters)), cost=np.zeros(niters),
+               factor_costs=np.zeros((nf, niters)))
+
+    def joint2marginals(J):                               # :120-127
+        return np.concatenate([J[t * n:(t + 1) * n, t * n:(t + 1) * n].reshape(-1, order="F") for t in range(T)])
+
+    for it, (mean, jc, jp, cost, fc) in enumerate(iterations[:niters]):
+        out["mean"][:, it] = np.asarray(mean).reshape(-1)
+        out["cov"][:, it] = joint2marginals(jc)
+        out["precision"][:, it] = joint2marginals(jp)
+        out["joint_cov"][:, it] = jc.reshape(-1, order="F")
+        out["joint_precision"][:, it] = jp.reshape(-1, order="F")
+        out["cost"][it] = cost
+        out["factor_costs"][:, it] = fc
+    last = min(len(iterations), niters) - 1               # save_data :203-218: decomp3d of the last recorded column
+    out["zk_sdf"] = out["mean"][:, last].reshape((n, T), order="F")
+    out["Sk_sdf"] = out["cov"][:, last].reshape((n * n, T), order="F")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # Proximal (JKO / Bures-Wasserstein) update -- SURVEY 8(f)4.  Same quadrature moments as the NGD path; the
 # factor-level map and the joint loop follow proxgd/ProxGVIFactorizedBaseGH.h and proxgd/ProxGVI-GH-impl.h.
 # --------------------------------------------------------------------------------------------

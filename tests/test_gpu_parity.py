@@ -641,10 +641,11 @@ def test_ngd_iterations_vs_oracle(name, iters):
     ctx.close()
 
 
-@pytest.mark.parametrize("speculate,fuse", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("speculate,fuse", [(0, 0), (1, 0), (1, 1), (1, 2)])
 def test_step_scheduling_modes_give_identical_iterates(speculate, fuse):
     """gvi_ngd_set_mode only changes what is queued when: plain trial-then-decide, speculative next
-    gradients, and the fused single-pass form all produce the same costs and (to rounding) iterates."""
+    gradients, the fused single-pass form and the adaptive default (fused until a first trial is rejected) all
+    produce the same costs and (to rounding) iterates -- including across a step with rejected trials."""
     ch = make_chain("c2")
     ref = None
     out = []
@@ -652,10 +653,17 @@ def test_step_scheduling_modes_give_identical_iterates(speculate, fuse):
         ctx, ids = api.context_for_chain(ch)
         ctx.ngd_set_mode(*mode)
         ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
-        log = [ctx.ngd_step(0.55, 10) for _ in range(6)]
-        out.append((log, ctx.ngd_get_state()))
+        ctx.ngd_counters(reset=True)
+        log = [ctx.ngd_step(40.0 if it == 2 else 0.55, 10) for it in range(7)]
+        out.append((log, ctx.ngd_get_state(), ctx.ngd_counters()))
         ctx.close()
-    (l0, s0), (l1, s1) = out
+    (l0, s0, c0), (l1, s1, c1) = out
+    assert any(r["ntrials"] > 1 for r in l0)
+    ntr = sum(r["ntrials"] for r in l0)
+    # reference order: one gradient pass per iteration that moved + one cost pass per trial (+ the initial cost)
+    assert c0[1] == 1 + ntr and c0[0] == 1 + sum(r["accepted"] for r in l0[:-1])
+    if fuse == 1:
+        assert c1[0] + c1[1] < c0[0] + c0[1]       # fused first trials: fewer psi passes, same iterates
     for a, b in zip(l0, l1):
         assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"]
         assert np.isclose(a["new_cost"], b["new_cost"], rtol=1e-12)
@@ -888,3 +896,39 @@ def test_c3_full_size_ngd_step_vs_oracle(c3):
     st = ctx.ngd_get_state()
     assert rel(st["mu"], chain.mu) < RTOL / 10 and rel(st["D"], chain.D) < RTOL / 10
     assert rel(st["SigD"], chain.SigD) < RTOL / 10
+
+
+def test_empty_shards_keep_set_ids_aligned():
+    """A set with fewer factors than ranks (the two end anchors of the planar graph over 4 ranks) leaves some ranks with
+    an EMPTY shard of that set (K = 0, gaussianvi_amd.dist.shard_chain).  Every rank still holds every set id, the
+    launches skip the empty ones, and the ranks' partial [g | D | U] sums add up to the unsharded assemble."""
+    import torch
+    from gaussianvi_amd.dist import HipEngine, shard_chain
+    ch = make_chain("planar")
+    full_ctx, _ = api.context_for_chain(ch)
+    full_ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    full_ctx.ngd_gradients()
+    G = full_ctx.ngd_get_gradients()
+    c_full = full_ctx.ngd_cost()
+    full = np.concatenate([G["g"].ravel(), G["VD"].ravel(), G["VU"].ravel()])
+    world, total, cost_sum, empties = 4, 0.0, 0.0, 0
+    for rank in range(world):
+        local = shard_chain(ch, rank, world)
+        empties += sum(len(s["start"]) == 0 for s in local["specs"])
+        ctx, ids = api.context_for_chain(local)
+        assert len(ids) == len(ch["specs"])
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        eng = HipEngine(ctx, 0)
+        ctx.ngd_gradients_local()
+        ctx.sync()
+        total = total + eng.exchange_tensor(0).cpu().numpy().copy()
+        ctx.ngd_cost_local()
+        ctx.sync()
+        cost_sum += float(eng.exchange_tensor(1).cpu().numpy()[0])
+        ctx.close()
+        del eng
+    assert empties == 2
+    assert rel(total, full) < 1e-12
+    half_logdet = o.logdet_half(o.bt_ldlt_pivots(ch["D0"], ch["U0"]))
+    assert abs(cost_sum + half_logdet - c_full) < 1e-9 * abs(c_full)
+    full_ctx.close()
