@@ -148,6 +148,7 @@ struct gvi_ctx {
   int profile_every = 1;              // on = 3: bracket only every 8th dominant launch (an event pair costs ~14 us of queue gaps)
   long profile_count = 0;
   int target_waves = 2048;
+  bool sreg_pipe = true;              // GVI_SREG_PIPE=0: full pass on the compiler-scheduled body (A/B; bit-identical results)
   bool no_scost = false;              // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
@@ -353,8 +354,9 @@ bool dispatch_tile(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t 
 }
 
 template <int D, int M>
-void launch_sreg(const MomArgs& a, dim3 grid, hipStream_t st) {
-  if (a.full) hipLaunchKernelGGL((moments_sreg_kernel<D, M, true>), grid, dim3(256), 0, st, a);
+void launch_sreg(const MomArgs& a, dim3 grid, hipStream_t st, bool pipe) {
+  if (a.full && pipe) hipLaunchKernelGGL((moments_sreg_kernel<D, M, true, true>), grid, dim3(256), 0, st, a);
+  else if (a.full) hipLaunchKernelGGL((moments_sreg_kernel<D, M, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((moments_sreg_kernel<D, M, false>), grid, dim3(256), 0, st, a);
 }
 
@@ -377,18 +379,18 @@ bool sreg_supported(const FactorSet& s) {
 }
 
 // scalar-operand register kernel (variant 5)
-bool dispatch_sreg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
+bool dispatch_sreg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st, bool pipe) {
   if (s.kind == KIND_QUAD_PRIOR) {
     switch (s.d) {
-      case 4: launch_sreg<4, 2>(a, grid, st); return true;
-      case 8: launch_sreg<8, 4>(a, grid, st); return true;
-      case 12: launch_sreg<12, 6>(a, grid, st); return true;
+      case 4: launch_sreg<4, 2>(a, grid, st, pipe); return true;
+      case 8: launch_sreg<8, 4>(a, grid, st, pipe); return true;
+      case 12: launch_sreg<12, 6>(a, grid, st, pipe); return true;
     }
   }
   if (s.kind == KIND_FIXED_PRIOR) {
     switch (s.d) {
-      case 6: launch_sreg<6, 6>(a, grid, st); return true;
-      case 12: launch_sreg<12, 12>(a, grid, st); return true;
+      case 6: launch_sreg<6, 6>(a, grid, st, pipe); return true;
+      case 12: launch_sreg<12, 12>(a, grid, st, pipe); return true;
     }
   }
   return false;
@@ -549,7 +551,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
       c->defer->kind = 0; c->defer->a = a; c->defer->grid = grid; c->defer->d = s.d; c->defer->m = s.m;
       return GVI_OK;
     }
-    if (!done && (c->variant == 5 || c->variant == 0)) done = dispatch_sreg(s, a, grid, st);
+    if (!done && (c->variant == 5 || c->variant == 0)) done = dispatch_sreg(s, a, grid, st, c->sreg_pipe);
     if (!done && (c->variant == 3 || (c->variant == 0 && !full))) done = dispatch_wide(s, a, grid, st);
     if (!done && !dispatch_reg(s, a, grid, st)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
@@ -847,6 +849,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
+  if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
   if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
   if (const char* w = getenv("GVI_NO_FUSE_GATHER")) c->fuse_gather = atoi(w) == 0;
   if (const char* w = getenv("GVI_SIDE_SOLVE")) c->side_solve = atoi(w) != 0;
@@ -1761,7 +1764,10 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
             if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
           HIPCK(ctx, hipEventRecord(s0.ev[0][0], ctx->stream));
         }
-        if (full)
+        if (full && ctx->sreg_pipe)
+          hipLaunchKernelGGL((moments_sreg_pair_kernel<12, 6, 6, 6, true, true>), dim3(nb0 + nb1), dim3(256), 0, ctx->stream, d0.a,
+                             d1.a, (int)d0.grid.x, nb0, (int)d1.grid.x);
+        else if (full)
           hipLaunchKernelGGL((moments_sreg_pair_kernel<12, 6, 6, 6, true>), dim3(nb0 + nb1), dim3(256), 0, ctx->stream, d0.a,
                              d1.a, (int)d0.grid.x, nb0, (int)d1.grid.x);
         else

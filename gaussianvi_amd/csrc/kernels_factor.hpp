@@ -1209,24 +1209,191 @@ __device__ __forceinline__ void sreg_body(const MomArgs& a, const int bx, const 
   }
 }
 
-template <int D, int M, bool FULL>
+// ---------------------------------------------------------------------------------------------
+// sreg_pipe_body<D, M>: the full-moments body of sreg_body with the sigma-point loads SOFTWARE-PIPELINED by hand.
+//
+// In sreg_body the 13 global_load_dwordx2 of a 64-point step are issued at the loop head and the wave then sits on
+// s_waitcnt until the first one returns from L2 (23 % of wave-cycles in SQ_WAIT_INST_ANY, profiles/r01_i_pmc_*): the
+// 91 accumulators leave no room for a second copy of z, and the compiler will not reuse z's registers in place.
+// Here the loads are inline asm, which the compiler's waitcnt pass does not track, so the schedule is explicit:
+//   * row c of the packed M2 update is the LAST reader of z[c]; right behind it the load of the NEXT step's z[c] is
+//     issued into the same register pair (w's load goes out as soon as c = w psi is formed);
+//   * the psi phase of the next step waits column by column: loads return in order, so "z[c] has landed" is
+//     s_waitcnt vmcnt(D - 1 - c) (the younger z[c+1..D-1] may still be in flight);
+//   * every z column therefore has the rest of the accumulation plus part of the psi phase (260-310 issue cycles of
+//     this wave, twice that with the SIMD's other wave interleaved) to cover the L2 latency.
+// Addressing is the saddr form: wave-uniform row pointer (SALU adds) + ONE 32-bit per-lane byte offset that advances
+// by 512 per step -- the 14 v_lshl_add_u64 per step of the 64-bit-VGPR-address form disappear as well.
+// The asm waits carry z[c] / w as "+v" operands so the compiler can neither hoist a use above its wait nor retire the
+// register while a load is in flight; __builtin_amdgcn_sched_barrier pins each issue point behind its row.
+// Results are bit-identical to sreg_body (same operations in the same order on the same values).
+// ---------------------------------------------------------------------------------------------
+#define GVI_ZLOAD(dst, voff, base) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+
+template <int D, int M>
+__device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
+  constexpr int NP = (D + 1) * (D + 2) / 2;
+  constexpr int NB = (NP + 15) / 16;
+  // columns per SGPR operand group: the grouping of split_psi_rows (same operand traffic, same SGPR budget)
+  constexpr int GC = (D % 4 == 0 && M <= 3) ? 4 : (D % 3 == 0 && M == 6 ? 3 : (D % 2 == 0 && M <= 6 ? 2 : 1));
+  constexpr int NG = D / GC, GS = GC * M;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  double* us_w = usb + wave * 2 * M;               // [2 M] u0 | sgn of this wave's factor
+  double (*red_w)[65] = (double (*)[65])(redb + wave * 16 * 65);
+  const int kq = bx * 4 + wave;
+  const bool active = kq < a.f.K;
+  const int k = __builtin_amdgcn_readfirstlane(active ? kq : a.f.K - 1);   // inactive waves redo the last factor
+  if (lane < M) {
+    us_w[lane] = a.f.u0[(size_t)k * M + lane];
+    us_w[M + lane] = a.f.sgn[(size_t)k * M + lane];
+  }
+  __syncthreads();
+  const uint64_t hbase = (uint64_t)(a.f.H + (size_t)k * M * D);
+  cdouble_t* hq = (cdouble_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(hbase >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase));
+  double acc[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+  const int64_t Np = a.f.Np;
+  const int64_t i0 = (int64_t)by * a.chunk;
+  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
+  const int ntiles = (int)((i1 - i0) >> 6);          // chunks are whole 64-point tiles (Np is a multiple of 256)
+  const char* const Zb = (const char*)a.f.Zt;
+  const char* const wb = (const char*)a.f.w;
+  const uint64_t rowb = (uint64_t)Np * 8;
+  unsigned voff = (unsigned)(i0 + lane) * 8u;        // per-lane byte offset inside a row (tables < 4 GiB per row)
+  unsigned idx = (unsigned)(i0 + lane);
+  const unsigned nvalid = (unsigned)a.f.N;
+  double z[D], wi;
+  if (ntiles > 0) {
+    // prologue: the first step's loads, in the order the psi phase waits for them (w first)
+    GVI_ZLOAD(wi, voff, wb);
+    const char* rp = Zb;
+#pragma unroll
+    for (int c = 0; c < D; ++c) { GVI_ZLOAD(z[c], voff, rp); rp += rowb; }
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    // ---- psi phase: u = u0 + H z, operands from SGPRs one group ahead (as split_psi_rows) ----
+    double u[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) u[r] = us_w[r];
+    double h[GS], hn[GS];
+    int off = 0;
+    asm volatile("" : "+s"(off));
+#pragma unroll
+    for (int j = 0; j < GS; ++j) h[j] = hq[off + j];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) {
+        int o2 = (g + 1) * GS;
+        asm volatile("" : "+s"(o2));
+#pragma unroll
+        for (int j = 0; j < GS; ++j) hn[j] = hq[o2 + j];
+      }
+#pragma unroll
+      for (int cc = 0; cc < GC; ++cc) {
+        const int c = g * GC + cc;
+        // z[c] has landed once at most the D - 1 - c younger loads are outstanding.  u[0] rides along as an in/out
+        // operand: the wait then sits between column c-1's and column c's update of u[0] and cannot be hoisted above
+        // the previous columns' FMAs (a hoisted wait would wait for the youngest load far too early).
+        switch (D - 1 - c) {
+          case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 5: asm volatile("s_waitcnt vmcnt(5)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 7: asm volatile("s_waitcnt vmcnt(7)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 9: asm volatile("s_waitcnt vmcnt(9)" : "+v"(z[c]), "+v"(u[0])); break;
+          case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(z[c]), "+v"(u[0])); break;
+          default: asm volatile("s_waitcnt vmcnt(11)" : "+v"(z[c]), "+v"(u[0])); break;
+        }
+#pragma unroll
+        for (int rr = 0; rr < M; ++rr) u[rr] = fma(h[cc * M + rr], z[c], u[rr]);
+      }
+#pragma unroll
+      for (int j = 0; j < GS; ++j) h[j] = hn[j];
+    }
+    double psi = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < M; ++rr) psi = fma(us_w[M + rr] * u[rr], u[rr], psi);
+    asm volatile("" : "+v"(wi));                       // w was issued before z[0]: it has landed with z[0]'s wait
+    const double cw = idx < nvalid ? wi * psi : 0.0;   // pad rows carry w = 0, z = 0; the select keeps a NaN psi out
+    // next step (the last step re-reads its own tile: no out-of-range address, the values are never used)
+    const unsigned step = t + 1 < ntiles ? 512u : 0u;
+    voff += step;
+    idx += step >> 3;
+    __builtin_amdgcn_sched_barrier(0);
+    GVI_ZLOAD(wi, voff, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0] += cw;
+    const char* rp = Zb;
+    uint64_t rb = rowb;
+    asm volatile("" : "+s"(rb));                        // opaque: the D row pointers are re-formed by SALU adds every step
+    int q = 1 + D;                                      // instead of living in 2 D SGPRs (which spill to VGPR lanes)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const double tc = cw * z[c];
+      acc[1 + c] += tc;
+#pragma unroll
+      for (int e = c; e < D; ++e) { acc[q] = fma(tc, z[e], acc[q]); ++q; }
+      __builtin_amdgcn_sched_barrier(0);
+      GVI_ZLOAD(z[c], voff, rp);                       // row c was the last reader of z[c]
+      __builtin_amdgcn_sched_barrier(0);
+      rp += rb;
+    }
+  }
+  // drain: nothing below may reuse z / w registers while the (unused) loads of the last step are in flight
+  if (ntiles > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(wi));
+#pragma unroll
+    for (int c = 0; c < D; ++c) asm volatile("" : "+v"(z[c]));
+  }
+  double* out = a.partial + ((size_t)k * a.nchunk + by) * NP;
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (bb * 16 + j < NP) red_w[j][lane] = acc[bb * 16 + j];
+    wave_lds_sync();
+    const int j = lane & 15, part = lane >> 4;
+    double s = 0.0;
+#pragma unroll
+    for (int t2 = 0; t2 < 16; ++t2) s += red_w[j][part * 16 + t2];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
+    wave_lds_sync();
+  }
+}
+
+// PIPE selects the hand-pipelined body for the full pass (the cost pass has its own kernels)
+template <int D, int M, bool FULL, bool PIPE = false>
 __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
   __shared__ double us[4 * 2 * M];
   __shared__ double red[4 * 16 * 65];
-  sreg_body<D, M, FULL>(a, blockIdx.x, blockIdx.y, us, red);
+  if constexpr (FULL && PIPE) sreg_pipe_body<D, M>(a, blockIdx.x, blockIdx.y, us, red);
+  else sreg_body<D, M, FULL>(a, blockIdx.x, blockIdx.y, us, red);
 }
 
 // Two sets in one launch (the chain pattern: binary priors d = 2n and unary factors d = n).  The launches are
 // independent, so fusing them removes one dependent-launch boundary (~6 us on this part) and lets the small set's
 // blocks fill the tail of the large one.  Blocks [0, nb0) belong to set 0 (x fastest), the rest to set 1.
-template <int D0, int M0, int D1, int M1, bool FULL>
+template <int D0, int M0, int D1, int M1, bool FULL, bool PIPE = false>
 __global__ __launch_bounds__(256) void moments_sreg_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
   constexpr int MM = M0 > M1 ? M0 : M1;
   __shared__ double us[4 * 2 * MM];
   __shared__ double red[4 * 16 * 65];
   const int b = blockIdx.x;
-  if (b < nb0) sreg_body<D0, M0, FULL>(a0, b % nbx0, b / nbx0, us, red);
-  else sreg_body<D1, M1, FULL>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us, red);
+  if constexpr (FULL && PIPE) {
+    if (b < nb0) sreg_pipe_body<D0, M0>(a0, b % nbx0, b / nbx0, us, red);
+    else sreg_pipe_body<D1, M1>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us, red);
+  } else {
+    if (b < nb0) sreg_body<D0, M0, FULL>(a0, b % nbx0, b / nbx0, us, red);
+    else sreg_body<D1, M1, FULL>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us, red);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

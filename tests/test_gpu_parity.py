@@ -932,3 +932,36 @@ def test_empty_shards_keep_set_ids_aligned():
     half_logdet = o.logdet_half(o.bt_ldlt_pivots(ch["D0"], ch["U0"]))
     assert abs(cost_sum + half_logdet - c_full) < 1e-9 * abs(c_full)
     full_ctx.close()
+
+
+@pytest.mark.parametrize("kind,d,p,K", [("quad", 12, 5, 9), ("quad", 12, 3, 5), ("quad", 8, 4, 6), ("quad", 4, 3, 7),
+                                        ("fixed", 6, 5, 5), ("fixed", 12, 3, 4)])
+def test_hand_pipelined_body_is_bit_identical(monkeypatch, kind, d, p, K):
+    """sreg_pipe_body (inline-asm loads issued behind their last reader, explicit s_waitcnt per column) runs the same
+    operations in the same order as the compiler-scheduled sreg_body: outputs must be BIT-identical (GVI_SREG_PIPE=0/1),
+    also with K not a multiple of 4 (idle waves) and tables that are not a whole number of chunks."""
+    rng = np.random.default_rng(77 + d + p)
+    if kind == "quad":
+        n = d // 2
+        Phi, Qinv = quad_params(rng, K, n)
+        params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+        psi_kind, n_state = api.PSI_QUAD_PRIOR, n
+    else:
+        mu0 = rng.normal(size=(K, d))
+        Kh = rng.normal(size=(K, d, d))
+        Kinv = Kh @ np.transpose(Kh, (0, 2, 1)) + 0.5 * np.eye(d)
+        params = np.concatenate([mu0, Kinv.reshape(K, -1)], axis=1)
+        psi_kind, n_state = api.PSI_FIXED_PRIOR, d
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.4)
+    outs = []
+    for pipe in ("0", "1"):
+        monkeypatch.setenv("GVI_SREG_PIPE", pipe)
+        ctx, sid = single_set_ctx(psi_kind, d, n_state, p, K, params)
+        outs.append(ctx.moments(sid, mu, Sigma) + (ctx.costs(sid, mu, Sigma),))
+        ctx.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    Z, w = oracle_table(d, p)
+    psi = o.psi_batch_quad_prior(Phi, Qinv) if kind == "quad" else o.psi_batch_fixed_prior(mu0, Kinv)
+    ref = o.batched_moments(Z, w, mu, Sigma, psi, np.ones(K))
+    assert rel(outs[1][1], ref["Vdmu"]) < TIGHT and rel(outs[1][2], ref["Vddmu"]) < 10 * TIGHT
