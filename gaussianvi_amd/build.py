@@ -42,7 +42,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale(LIB, lib_sources()):
         return LIB
     tmp = LIB + f".tmp{os.getpid()}"          # written aside and renamed: a concurrent reader never sees a partial file
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"),
            os.path.join(CSRC, "gvi_hip.hip"), "-x", "hip", os.path.join(CSRC, "spgh.cpp"), os.path.join(CSRC, "table_io.cpp"),

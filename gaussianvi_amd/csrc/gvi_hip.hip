@@ -48,6 +48,7 @@ struct Table {
   int d = 0, p = 0;
   int64_t N = 0, Np = 0;
   DevMem Zt, w;
+  DevMem Zq;               // tile-major copy [Np / 64][d + 1][64] (row d = w) read by the hand-pipelined kernels
   DevMem codes, lut;       // 8-bit node codes [d/4][Np] + value look-up (moments_split_kernel); empty when not coded
   bool coded = false;
 };
@@ -74,6 +75,7 @@ struct FactorSet {
   bool use_split = false;
   bool fused_pair = false;            // last resident launch went out fused with the other set
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
+  bool all_pos = false;               // every residual row has sgn = +1 (positive-definite weight)
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
   hipEvent_t done = nullptr;
@@ -92,6 +94,7 @@ struct FactorSet {
     f.K = K; f.d = d; f.m = m; f.kind = kind;
     f.N = table->N; f.Np = table->Np;
     f.Zt = table->Zt.d(); f.w = table->w.d();
+    f.Zq = table->Zq.p ? table->Zq.d() : nullptr; f.all_pos = all_pos ? 1 : 0;
     f.codes = table->coded ? (const uint32_t*)table->codes.p : nullptr; f.lut = table->coded ? table->lut.d() : nullptr;
     f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
     f.temperature = unit_temperature ? ones.d() : temperature.d();
@@ -237,6 +240,17 @@ gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const dou
   HIPCK(c, t.w.ensure(wp.size() * 8));
   HIPCK(c, hipMemcpy(t.Zt.p, zt.data(), zt.size() * 8, hipMemcpyHostToDevice));
   HIPCK(c, hipMemcpy(t.w.p, wp.data(), wp.size() * 8, hipMemcpyHostToDevice));
+  if (d <= 12) {                          // shapes of the sreg kernels
+    const size_t ntile = (size_t)t.Np / 64, rows = (size_t)d + 1;
+    std::vector<double> zq(ntile * rows * 64, 0.0);
+    for (int64_t i = 0; i < N; ++i) {
+      const size_t base = ((size_t)i / 64) * rows * 64 + (size_t)i % 64;
+      for (int a = 0; a < d; ++a) zq[base + (size_t)a * 64] = Z[(size_t)i * d + a];
+      zq[base + (size_t)d * 64] = w[i];
+    }
+    HIPCK(c, t.Zq.ensure(zq.size() * 8));
+    HIPCK(c, hipMemcpy(t.Zq.p, zq.data(), zq.size() * 8, hipMemcpyHostToDevice));
+  }
   // 8-bit node codes for the split kernel: a Smolyak table has a few dozen distinct node values
   t.coded = false;
   if (d >= 16 && d % 4 == 0) {
@@ -551,7 +565,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
       c->defer->kind = 0; c->defer->a = a; c->defer->grid = grid; c->defer->d = s.d; c->defer->m = s.m;
       return GVI_OK;
     }
-    if (!done && (c->variant == 5 || c->variant == 0)) done = dispatch_sreg(s, a, grid, st, c->sreg_pipe);
+    if (!done && (c->variant == 5 || c->variant == 0)) done = dispatch_sreg(s, a, grid, st, c->sreg_pipe && s.table->Zq.p);
     if (!done && (c->variant == 3 || (c->variant == 0 && !full))) done = dispatch_wide(s, a, grid, st);
     if (!done && !dispatch_reg(s, a, grid, st)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
@@ -1037,6 +1051,7 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   GVICK(up(s->A, A.data(), A.size() * 8));
   GVICK(up(s->b, b.data(), b.size() * 8));
   GVICK(up(s->sgn, sg.data(), sg.size() * 8));
+  s->all_pos = std::all_of(sg.begin(), sg.end(), [](double v) { return v == 1.0; });
   if (psi_kind == GVI_PSI_RANGE_1D || psi_kind >= GVI_PSI_HINGE_SDF_2D) {
     const int np = (int)need;
     std::vector<double> raw((size_t)K * np);
@@ -1764,9 +1779,9 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
             if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
           HIPCK(ctx, hipEventRecord(s0.ev[0][0], ctx->stream));
         }
-        if (full && ctx->sreg_pipe)
-          hipLaunchKernelGGL((moments_sreg_pair_kernel<12, 6, 6, 6, true, true>), dim3(nb0 + nb1), dim3(256), 0, ctx->stream, d0.a,
-                             d1.a, (int)d0.grid.x, nb0, (int)d1.grid.x);
+        if (full && ctx->sreg_pipe && s0.table->Zq.p && s1.table->Zq.p)    // every block: one prior item + strided unary items
+          hipLaunchKernelGGL((moments_sreg_pair_kernel<12, 6, 6, 6, true, true>), dim3(std::max(nb0, nb1)), dim3(256), 0, ctx->stream,
+                             d0.a, d1.a, (int)d0.grid.x, nb0, (int)d1.grid.x);
         else if (full)
           hipLaunchKernelGGL((moments_sreg_pair_kernel<12, 6, 6, 6, true>), dim3(nb0 + nb1), dim3(256), 0, ctx->stream, d0.a,
                              d1.a, (int)d0.grid.x, nb0, (int)d1.grid.x);

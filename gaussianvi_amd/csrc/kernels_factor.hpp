@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 #include "device_common.hpp"
 
 namespace gvi {
@@ -49,6 +51,8 @@ struct FactorDev {
   int64_t N, Np;            // points, padded to a multiple of 64 (pad: z = 0, w = 0)
   const double* Zt;         // [d][Np] dimension-major: lane-over-points loads are coalesced
   const double* w;          // [Np]
+  const double* Zq;         // [Np / 64][d + 1][64] tile-major copy (row d = w): one contiguous block per 64-point step
+  int all_pos;              // 1: every sgn entry is +1 (sum-of-squares kinds with a positive-definite weight)
   const uint32_t* codes;    // [d/4][Np] four 8-bit node codes per word (tables with <= 256 distinct values) or null
   const double* lut;        // [256] code -> node value
   const double* A;          // [K][m][d]   sum-of-squares kinds
@@ -1210,33 +1214,104 @@ __device__ __forceinline__ void sreg_body(const MomArgs& a, const int bx, const 
 }
 
 // ---------------------------------------------------------------------------------------------
-// sreg_pipe_body<D, M>: the full-moments body of sreg_body with the sigma-point loads SOFTWARE-PIPELINED by hand.
+// sreg_pipe_body<D, M, SIGNED>: the full-moments body of sreg_body, scheduled by hand.
 //
-// In sreg_body the 13 global_load_dwordx2 of a 64-point step are issued at the loop head and the wave then sits on
-// s_waitcnt until the first one returns from L2 (23 % of wave-cycles in SQ_WAIT_INST_ANY, profiles/r01_i_pmc_*): the
-// 91 accumulators leave no room for a second copy of z, and the compiler will not reuse z's registers in place.
-// Here the loads are inline asm, which the compiler's waitcnt pass does not track, so the schedule is explicit:
-//   * row c of the packed M2 update is the LAST reader of z[c]; right behind it the load of the NEXT step's z[c] is
-//     issued into the same register pair (w's load goes out as soon as c = w psi is formed);
-//   * the psi phase of the next step waits column by column: loads return in order, so "z[c] has landed" is
-//     s_waitcnt vmcnt(D - 1 - c) (the younger z[c+1..D-1] may still be in flight);
-//   * every z column therefore has the rest of the accumulation plus part of the psi phase (260-310 issue cycles of
-//     this wave, twice that with the SIMD's other wave interleaved) to cover the L2 latency.
-// Addressing is the saddr form: wave-uniform row pointer (SALU adds) + ONE 32-bit per-lane byte offset that advances
-// by 512 per step -- the 14 v_lshl_add_u64 per step of the 64-bit-VGPR-address form disappear as well.
-// The asm waits carry z[c] / w as "+v" operands so the compiler can neither hoist a use above its wait nor retire the
-// register while a load is in flight; __builtin_amdgcn_sched_barrier pins each issue point behind its row.
-// Results are bit-identical to sreg_body (same operations in the same order on the same values).
+// What limits sreg_body (profiles/r01_i_pmc_*: VALU pipe 68 % busy, 23 % of wave-cycles waiting): (i) the 13
+// global_load_dwordx2 of a 64-point step are issued at the loop head and waited on -- the 91 accumulators leave no room for
+// a second copy of z and the compiler will not reuse z's registers in place; (ii) a wave issues at most one instruction
+// per 4-cycle slot, so every non-VALU instruction (64-bit VGPR address arithmetic, SALU address arithmetic of the operand
+// loads, LDS reads of u0 / sgn) takes a slot in which the SIMD's only other wave must have a VALU instruction ready;
+// (iii) the scalar operand loads of the next group are issued right before the wait of the current one (SMEM returns out
+// of order, the wait is lgkmcnt(0)), so two scalar-cache latencies per step are exposed.  Here:
+//   * the table is read from its TILE-MAJOR copy Zq[tile][row][64] (row D = weights): ONE wave-uniform base, ONE 32-bit
+//     per-lane offset that advances by a tile per step, rows addressed by the instruction's immediate offset -- no address
+//     arithmetic at all, every load still one coalesced 512-byte line;
+//   * the loads are inline asm (the compiler's waitcnt pass does not track them), so the schedule is explicit: row c of
+//     the packed M2 update is the LAST reader of z[c]; right behind it the NEXT step's z[c] is loaded into the same
+//     register pair (w goes out as soon as c = w psi is formed).  Loads return in order, so "z[c] has landed" is
+//     s_waitcnt vmcnt(D - 1 - c), placed in front of column c of the psi phase: every column has the rest of the
+//     accumulation plus part of the psi phase to cover the L2 latency;
+//   * psi operands: H is addressed through one opaque base per step (immediate offsets, no SALU arithmetic); the first two
+//     operand groups of the NEXT step are requested during the accumulation phase, and inside the psi phase the request of
+//     group g+1 sits behind the first column of group g, i.e. behind the wait, so it has a full group of FMAs to land;
+//   * u0 stays in registers and rides in as src2 of the first column's v_fma; the sign multiply disappears when every
+//     residual row has positive weight (SIGNED = false: the usual positive-definite Q^-1 / K^-1).
+// The asm waits carry the registers they guard as in/out operands, so the compiler can neither hoist a use above its wait
+// nor reuse a register while a load is in flight; sched_barriers pin the issue points.  Same operations in the same order
+// on the same values as sreg_body: results are bit-identical (tests/test_gpu_parity.py).
 // ---------------------------------------------------------------------------------------------
-#define GVI_ZLOAD(dst, voff, base) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#define GVI_ZLOAD(dst, voff, base, imm) \
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(imm) : "memory")
 
-template <int D, int M>
+// compile-time recursion instead of unrolled loops: the asm statements need their immediates as constant expressions
+template <int D, int BIAS, int C = 0>
+__device__ __forceinline__ void pipe_zload_all(double (&z)[D], const unsigned voff, const char* const Zq) {
+  if constexpr (C < D) {
+    GVI_ZLOAD(z[C], voff, Zq, C * 512 - BIAS);
+    pipe_zload_all<D, BIAS, C + 1>(z, voff, Zq);
+  }
+}
+
+// psi phase, column C: u += H[:, C] z[C].  Operand group g = C / GC lives in hA (g even) or hB (g odd); the request of
+// group g + 1 goes out behind the first column of group g (g >= 1), i.e. behind that group's wait, into the buffer
+// group g - 1 has left.
+template <int D, int M, int GC, int C = 0>
+__device__ __forceinline__ void pipe_psi_cols(double (&u)[M], double (&z)[D], double (&hA)[GC * M], double (&hB)[GC * M],
+                                              const double (&u0v)[M], cdouble_t* const hp) {
+  if constexpr (C < D) {
+    constexpr int g = C / GC, cc = C % GC, NG = D / GC, GS = GC * M;
+    double (&h)[GS] = (g % 2 == 0) ? hA : hB;
+    // z[C] has landed once at most the D - 1 - C younger loads are outstanding (loads return in order).  From column 1
+    // on u[0] rides along as an in/out operand: the wait then sits between column C-1's and column C's update of u[0]
+    // and cannot be hoisted above earlier FMAs (a hoisted wait would wait for the youngest load far too early).
+    if constexpr (C == 0) {
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(z[0]) : "n"(D - 1));
+#pragma unroll
+      for (int rr = 0; rr < M; ++rr) u[rr] = fma(h[rr], z[0], u0v[rr]);
+    } else {
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(z[C]), "+v"(u[0]) : "n"(D - 1 - C));
+#pragma unroll
+      for (int rr = 0; rr < M; ++rr) u[rr] = fma(h[cc * M + rr], z[C], u[rr]);
+    }
+    if constexpr (cc == 0 && g >= 1 && g + 1 < NG) {
+      double (&hnext)[GS] = (g % 2 == 0) ? hB : hA;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < GS; ++j) hnext[j] = hp[(g + 1) * GS + j];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pipe_psi_cols<D, M, GC, C + 1>(u, z, hA, hB, u0v, hp);
+  }
+}
+
+// accumulation phase, row C of the packed second moment; behind it the NEXT step's z[C] is loaded into the same register
+template <int D, int BIAS, int C = 0>
+__device__ __forceinline__ void pipe_acc_rows(double (&acc)[(D + 1) * (D + 2) / 2], double (&z)[D], const double cw,
+                                              const unsigned voff, const char* const Zq) {
+  if constexpr (C < D) {
+    constexpr int q0 = 1 + D + C * D - C * (C - 1) / 2;         // packed index of (C, C)
+    const double tc = cw * z[C];
+    acc[1 + C] += tc;
+#pragma unroll
+    for (int e = C; e < D; ++e) acc[q0 + e - C] = fma(tc, z[e], acc[q0 + e - C]);
+    __builtin_amdgcn_sched_barrier(0);
+    GVI_ZLOAD(z[C], voff, Zq, C * 512 - BIAS);                  // row C was the last reader of z[C]
+    __builtin_amdgcn_sched_barrier(0);
+    pipe_acc_rows<D, BIAS, C + 1>(acc, z, cw, voff, Zq);
+  }
+}
+
+template <int D, int M, bool SIGNED>
 __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
   constexpr int NP = (D + 1) * (D + 2) / 2;
   constexpr int NB = (NP + 15) / 16;
   // columns per SGPR operand group: the grouping of split_psi_rows (same operand traffic, same SGPR budget)
   constexpr int GC = (D % 4 == 0 && M <= 3) ? 4 : (D % 3 == 0 && M == 6 ? 3 : (D % 2 == 0 && M <= 6 ? 2 : 1));
   constexpr int NG = D / GC, GS = GC * M;
+  constexpr int TB = (D + 1) * 512;                  // bytes of one 64-point tile of Zq
+  constexpr int BIAS = (TB / 2) & ~7;                // centres the row offsets in the signed 13-bit immediate
+  static_assert(D * 512 - BIAS <= 4095 && -BIAS >= -4096, "row offsets must fit the immediate field");
+  static_assert(D <= 16, "vmcnt immediates");
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double* us_w = usb + wave * 2 * M;               // [2 M] u0 | sgn of this wave's factor
   double (*red_w)[65] = (double (*)[65])(redb + wave * 16 * 65);
@@ -1249,101 +1324,68 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
   }
   __syncthreads();
   const uint64_t hbase = (uint64_t)(a.f.H + (size_t)k * M * D);
-  cdouble_t* hq = (cdouble_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(hbase >> 32)) << 32) |
-                               (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase));
+  cdouble_t* const hq = (cdouble_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(hbase >> 32)) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase));
   double acc[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) acc[j] = 0.0;
+  double u0v[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) u0v[r] = us_w[r];
   const int64_t Np = a.f.Np;
   const int64_t i0 = (int64_t)by * a.chunk;
   const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
   const int ntiles = (int)((i1 - i0) >> 6);          // chunks are whole 64-point tiles (Np is a multiple of 256)
-  const char* const Zb = (const char*)a.f.Zt;
-  const char* const wb = (const char*)a.f.w;
-  const uint64_t rowb = (uint64_t)Np * 8;
-  unsigned voff = (unsigned)(i0 + lane) * 8u;        // per-lane byte offset inside a row (tables < 4 GiB per row)
+  const char* const Zq = (const char*)a.f.Zq;
+  unsigned voff = (unsigned)(i0 >> 6) * (unsigned)TB + (unsigned)lane * 8u + (unsigned)BIAS;
   unsigned idx = (unsigned)(i0 + lane);
   const unsigned nvalid = (unsigned)a.f.N;
   double z[D], wi;
+  double hA[GS], hB[GS];                             // operand groups of even / odd index (SGPRs)
   if (ntiles > 0) {
-    // prologue: the first step's loads, in the order the psi phase waits for them (w first)
-    GVI_ZLOAD(wi, voff, wb);
-    const char* rp = Zb;
+    // prologue: the first step's loads in the order the psi phase waits for them (w first), and its first two groups
+    GVI_ZLOAD(wi, voff, Zq, D * 512 - BIAS);
+    pipe_zload_all<D, BIAS>(z, voff, Zq);
+    cdouble_t* hp = hq;
+    asm volatile("" : "+s"(hp));
 #pragma unroll
-    for (int c = 0; c < D; ++c) { GVI_ZLOAD(z[c], voff, rp); rp += rowb; }
+    for (int j = 0; j < GS; ++j) hA[j] = hp[j];
+    if (NG > 1) {
+#pragma unroll
+      for (int j = 0; j < GS; ++j) hB[j] = hp[GS + j];
+    }
   }
   for (int t = 0; t < ntiles; ++t) {
-    // ---- psi phase: u = u0 + H z, operands from SGPRs one group ahead (as split_psi_rows) ----
+    cdouble_t* hp = hq;
+    asm volatile("" : "+s"(hp));                      // opaque per step: the operand loads stay inside the loop
     double u[M];
-#pragma unroll
-    for (int r = 0; r < M; ++r) u[r] = us_w[r];
-    double h[GS], hn[GS];
-    int off = 0;
-    asm volatile("" : "+s"(off));
-#pragma unroll
-    for (int j = 0; j < GS; ++j) h[j] = hq[off + j];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) {
-        int o2 = (g + 1) * GS;
-        asm volatile("" : "+s"(o2));
-#pragma unroll
-        for (int j = 0; j < GS; ++j) hn[j] = hq[o2 + j];
-      }
-#pragma unroll
-      for (int cc = 0; cc < GC; ++cc) {
-        const int c = g * GC + cc;
-        // z[c] has landed once at most the D - 1 - c younger loads are outstanding.  u[0] rides along as an in/out
-        // operand: the wait then sits between column c-1's and column c's update of u[0] and cannot be hoisted above
-        // the previous columns' FMAs (a hoisted wait would wait for the youngest load far too early).
-        switch (D - 1 - c) {
-          case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 1: asm volatile("s_waitcnt vmcnt(1)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 3: asm volatile("s_waitcnt vmcnt(3)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 5: asm volatile("s_waitcnt vmcnt(5)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 6: asm volatile("s_waitcnt vmcnt(6)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 7: asm volatile("s_waitcnt vmcnt(7)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 8: asm volatile("s_waitcnt vmcnt(8)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 9: asm volatile("s_waitcnt vmcnt(9)" : "+v"(z[c]), "+v"(u[0])); break;
-          case 10: asm volatile("s_waitcnt vmcnt(10)" : "+v"(z[c]), "+v"(u[0])); break;
-          default: asm volatile("s_waitcnt vmcnt(11)" : "+v"(z[c]), "+v"(u[0])); break;
-        }
-#pragma unroll
-        for (int rr = 0; rr < M; ++rr) u[rr] = fma(h[cc * M + rr], z[c], u[rr]);
-      }
-#pragma unroll
-      for (int j = 0; j < GS; ++j) h[j] = hn[j];
-    }
+    pipe_psi_cols<D, M, GC>(u, z, hA, hB, u0v, hp);
     double psi = 0.0;
+    if constexpr (SIGNED) {
 #pragma unroll
-    for (int rr = 0; rr < M; ++rr) psi = fma(us_w[M + rr] * u[rr], u[rr], psi);
+      for (int rr = 0; rr < M; ++rr) psi = fma(us_w[M + rr] * u[rr], u[rr], psi);
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < M; ++rr) psi = fma(u[rr], u[rr], psi);
+    }
     asm volatile("" : "+v"(wi));                       // w was issued before z[0]: it has landed with z[0]'s wait
     const double cw = idx < nvalid ? wi * psi : 0.0;   // pad rows carry w = 0, z = 0; the select keeps a NaN psi out
     // next step (the last step re-reads its own tile: no out-of-range address, the values are never used)
-    const unsigned step = t + 1 < ntiles ? 512u : 0u;
-    voff += step;
-    idx += step >> 3;
+    const bool more = t + 1 < ntiles;
+    voff += more ? (unsigned)TB : 0u;
+    idx += more ? 64u : 0u;
     __builtin_amdgcn_sched_barrier(0);
-    GVI_ZLOAD(wi, voff, wb);
+    GVI_ZLOAD(wi, voff, Zq, D * 512 - BIAS);
+    // the next step's first two operand groups: the whole accumulation phase to land
+#pragma unroll
+    for (int j = 0; j < GS; ++j) hA[j] = hp[j];
+    if (NG > 1) {
+#pragma unroll
+      for (int j = 0; j < GS; ++j) hB[j] = hp[GS + j];
+    }
     __builtin_amdgcn_sched_barrier(0);
     acc[0] += cw;
-    const char* rp = Zb;
-    uint64_t rb = rowb;
-    asm volatile("" : "+s"(rb));                        // opaque: the D row pointers are re-formed by SALU adds every step
-    int q = 1 + D;                                      // instead of living in 2 D SGPRs (which spill to VGPR lanes)
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-      const double tc = cw * z[c];
-      acc[1 + c] += tc;
-#pragma unroll
-      for (int e = c; e < D; ++e) { acc[q] = fma(tc, z[e], acc[q]); ++q; }
-      __builtin_amdgcn_sched_barrier(0);
-      GVI_ZLOAD(z[c], voff, rp);                       // row c was the last reader of z[c]
-      __builtin_amdgcn_sched_barrier(0);
-      rp += rb;
-    }
+    pipe_acc_rows<D, BIAS>(acc, z, cw, voff, Zq);
   }
   // drain: nothing below may reuse z / w registers while the (unused) loads of the last step are in flight
   if (ntiles > 0) {
@@ -1369,12 +1411,19 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
   }
 }
 
+// every residual row of the set has positive weight (sgn = +1): the sign multiply of psi is dropped
+template <int D, int M>
+__device__ __forceinline__ void sreg_pipe_dispatch(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
+  if (a.f.all_pos) sreg_pipe_body<D, M, false>(a, bx, by, usb, redb);
+  else sreg_pipe_body<D, M, true>(a, bx, by, usb, redb);
+}
+
 // PIPE selects the hand-pipelined body for the full pass (the cost pass has its own kernels)
 template <int D, int M, bool FULL, bool PIPE = false>
 __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
   __shared__ double us[4 * 2 * M];
   __shared__ double red[4 * 16 * 65];
-  if constexpr (FULL && PIPE) sreg_pipe_body<D, M>(a, blockIdx.x, blockIdx.y, us, red);
+  if constexpr (FULL && PIPE) sreg_pipe_dispatch<D, M>(a, blockIdx.x, blockIdx.y, us, red);
   else sreg_body<D, M, FULL>(a, blockIdx.x, blockIdx.y, us, red);
 }
 
@@ -1388,8 +1437,14 @@ __global__ __launch_bounds__(256) void moments_sreg_pair_kernel(MomArgs a0, MomA
   __shared__ double red[4 * 16 * 65];
   const int b = blockIdx.x;
   if constexpr (FULL && PIPE) {
-    if (b < nb0) sreg_pipe_body<D0, M0>(a0, b % nbx0, b / nbx0, us, red);
-    else sreg_pipe_body<D1, M1>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us, red);
+    // every block takes a prior item and then (strided) unary items, so the short unary blocks do not form a serial tail
+    // behind the single resident round of prior blocks; the grid is max(nb0, nb1)
+    if (b < nb0) sreg_pipe_dispatch<D0, M0>(a0, b % nbx0, b / nbx0, us, red);
+    const int nb1 = nbx1 * a1.nchunk;
+    for (int it = b; it < nb1; it += gridDim.x) {
+      __syncthreads();
+      sreg_pipe_dispatch<D1, M1>(a1, it % nbx1, it / nbx1, us, red);
+    }
   } else {
     if (b < nb0) sreg_body<D0, M0, FULL>(a0, b % nbx0, b / nbx0, us, red);
     else sreg_body<D1, M1, FULL>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us, red);
