@@ -111,11 +111,12 @@ def cpu_baseline(chain, seconds):
             "fused_single_pass_value": out["fused"]}
 
 
-def exec_ops(d: int, m: int, full: bool) -> int:
+def exec_ops(d: int, m: int, full: bool, signed: bool = False) -> int:
     """fp64 VALU instructions per evaluation of a sum-of-squares psi with m residual rows in the z-space formulation
-    (DESIGN section 2): u = u0 + H z (m d FMA), psi = sum s_r u_r^2 (m MUL + m FMA), c = w psi (1), m0 (1); the full
-    pass adds t = c z (d), m1 (d) and the packed upper triangle of M2 (d (d + 1) / 2 FMA)."""
-    ops = m * d + 2 * m + 2
+    (DESIGN section 2): u = u0 + H z (m d FMA), psi = sum s_r u_r^2 (m FMA; m more MUL for the signs when some residual
+    weight is negative -- `signed`), c = w psi (1), m0 (1); the full pass adds t = c z (d), m1 (d) and the packed upper
+    triangle of M2 (d (d + 1) / 2 FMA)."""
+    ops = m * d + (2 * m if signed else m) + 2
     if full:
         ops += 2 * d + d * (d + 1) // 2
     return ops
@@ -303,15 +304,19 @@ def main():
         else:
             kernel_name = "moments_generic_kernel"
         # work of the bracketed launch: the prior set, plus the unary set when both ride in one launch
-        sets_in_launch = [(K0, d0, m0, N0)]
+        def weights_signed(spec):                      # any negative eigenvalue of the residual weight (Q^-1 / K^-1)?
+            W = spec.get("Qinv", spec.get("Kinv"))
+            return bool(np.linalg.eigvalsh(0.5 * (W + np.transpose(W, (0, 2, 1)))).min() <= 0.0)
+        sg0 = weights_signed(local["specs"][0])
+        sets_in_launch = [(K0, d0, m0, N0, sg0)]
         fused_pair = geo["variant"] == 5 and len(ctx.sets) == 2
         if fused_pair:
             K1, d1, p1, N1 = ctx.sets[1]
-            sets_in_launch.append((K1, d1, d1, N1))            # unary: psi = (x - mu0)^T Kinv (x - mu0), m = d
-        evals_launch = sum(K * N for K, d, m, N in sets_in_launch)
-        exec_flop = sum(2 * exec_ops(d, m, True) * K * N for K, d, m, N in sets_in_launch)
-        alg_flop = sum(alg_flops(d, m) * K * N for K, d, m, N in sets_in_launch)
-        alg_bytes = sum(K * N * (d + 1) * 8 for K, d, m, N in sets_in_launch)   # (d+1) s bytes per eval
+            sets_in_launch.append((K1, d1, d1, N1, weights_signed(local["specs"][1])))   # unary: psi = (x - mu0)^T Kinv (x - mu0), m = d
+        evals_launch = sum(K * N for K, d, m, N, sg in sets_in_launch)
+        exec_flop = sum(2 * exec_ops(d, m, True, sg) * K * N for K, d, m, N, sg in sets_in_launch)
+        alg_flop = sum(alg_flops(d, m) * K * N for K, d, m, N, sg in sets_in_launch)
+        alg_bytes = sum(K * N * (d + 1) * 8 for K, d, m, N, sg in sets_in_launch)   # (d+1) s bytes per eval
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if args.config == "c3" and world == 1 and os.path.exists(tpath):
@@ -361,7 +366,7 @@ def main():
                          "unit": "TFLOP/s", "frac": exec_flop / km / FP64_PEAK,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "kernel_ms": km * 1e3, "evals_per_launch": evals_launch,
-                         "executed_fp64_ops_per_eval": {f"d={d},m={m}": exec_ops(d, m, True) for K, d, m, N in sets_in_launch},
+                         "executed_fp64_ops_per_eval": {f"d={d},m={m}": exec_ops(d, m, True, sg) for K, d, m, N, sg in sets_in_launch},
                          "note": "achieved/frac = EXECUTED fp64 VALU instructions of the bracketed launch (every set in it), each "
                                  "counted as one FMA (2 flop), / HIP-event time / 78.6 TF",
                          "algorithmic": {"flop_per_eval": alg_flops(d0, m0), "tflops": alg_flop / km / 1e12,
