@@ -200,7 +200,8 @@ def main():
     ngd = ShardedNGD(engine, world=world)
     ngd.group_forced = use_pg and world == 1
     ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
-    ctx.profile_enable(3)       # HIP events around every 8th dominant launch (a pair costs ~14 us of queue gaps)
+    # HIP events around every 8th dominant launch (a pair costs ~14 us of queue gaps); every launch for the seconds-long c5 passes
+    ctx.profile_enable(1 if big else 3)
 
     def barrier():
         if use_pg:
@@ -314,7 +315,12 @@ def main():
             K1, d1, p1, N1 = ctx.sets[1]
             sets_in_launch.append((K1, d1, d1, N1, weights_signed(local["specs"][1])))   # unary: psi = (x - mu0)^T Kinv (x - mu0), m = d
         evals_launch = sum(K * N for K, d, m, N, sg in sets_in_launch)
-        exec_flop = sum(2 * exec_ops(d, m, True, sg) * K * N for K, d, m, N, sg in sets_in_launch)
+        ops_of = lambda d, m, sg: exec_ops(d, m, True, sg)
+        if geo["variant"] == 3:
+            # four waves per factor (moments_split_kernel): psi rows always carry the sign multiply, every wave forms
+            # c = w psi and adds the four partial sums of psi (3 adds each)
+            ops_of = lambda d, m, sg: exec_ops(d, m, True, True) + 3 + 12
+        exec_flop = sum(2 * ops_of(d, m, sg) * K * N for K, d, m, N, sg in sets_in_launch)
         alg_flop = sum(alg_flops(d, m) * K * N for K, d, m, N, sg in sets_in_launch)
         alg_bytes = sum(K * N * (d + 1) * 8 for K, d, m, N, sg in sets_in_launch)   # (d+1) s bytes per eval
         traffic, traffic_source = None, None
@@ -366,7 +372,7 @@ def main():
                          "unit": "TFLOP/s", "frac": exec_flop / km / FP64_PEAK,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name, "kernel_ms": km * 1e3, "evals_per_launch": evals_launch,
-                         "executed_fp64_ops_per_eval": {f"d={d},m={m}": exec_ops(d, m, True, sg) for K, d, m, N, sg in sets_in_launch},
+                         "executed_fp64_ops_per_eval": {f"d={d},m={m}": ops_of(d, m, sg) for K, d, m, N, sg in sets_in_launch},
                          "note": "achieved/frac = EXECUTED fp64 VALU instructions of the bracketed launch (every set in it), each "
                                  "counted as one FMA (2 flop), / HIP-event time / 78.6 TF",
                          "algorithmic": {"flop_per_eval": alg_flops(d0, m0), "tflops": alg_flop / km / 1e12,

@@ -15,7 +15,10 @@
 // gvi_ngd_step through the Python binding.  A third block drives single factors directly (stand-alone objects, no
 // optimiser): E_Phi / E_xMuPhi / E_xMuxMuTPhi, and an opaque std::function psi against its DevicePsi twin.
 //
-//   Usage: factorwise_example <problem file> <iterations> <output file> [csv prefix]
+//   Usage: factorwise_example <problem file> <iterations> <output file> [csv prefix | -] [step base] [max backtrack]
+//                             [temperature] [high temperature]
+//   (the optional tail drives the backtrack-exhaustion -> switch_to_high_temperature branch of optimize(),
+//   gvibase/GVI-GH-impl.h:102-117)
 //   With a csv prefix the resident run also writes the reference's nine result files (VIMPResults::save_data,
 //   helpers/DataRecorder.h:177-224): <prefix>mean.csv, cov.csv, precision.csv, joint_cov.csv, joint_precision.csv, cost.csv,
 //   factor_costs.csv, zk_sdf.csv, Sk_sdf.csv.
@@ -45,7 +48,10 @@ int main(int argc, char** argv) {
   const std::vector<double> D0 = read((size_t)T * n * n), U0 = read((size_t)K * n * n);
   if (!in) { std::fprintf(stderr, "short problem file\n"); return 2; }
 
-  const double temperature = 1.0, high_temperature = 10.0;
+  const std::string csv_prefix = argc > 4 && std::string(argv[4]) != "-" ? argv[4] : "";
+  const double step_base = argc > 5 ? std::atof(argv[5]) : 0.55;
+  const int max_backtrack = argc > 6 ? std::atoi(argv[6]) : 10;
+  const double temperature = argc > 7 ? std::atof(argv[7]) : 1.0, high_temperature = argc > 8 ? std::atof(argv[8]) : 10.0;
   auto make_factors = [&]() {
     std::vector<std::shared_ptr<GVIFactorizedBase>> f;
     const MatrixXd Qc = MatrixXd::Identity(nd, nd) * qc;
@@ -78,7 +84,9 @@ int main(int argc, char** argv) {
     NGDGH<GVIFactorizedBase> opt{factors, n, T, iters, temperature, high_temperature};
     opt.set_execution(mode == 0 ? Execution::FactorWise : Execution::DeviceResident);
     opt.set_niter_low_temperature(iters + 1);
-    if (mode == 1 && argc > 4) opt.update_file_names(argv[4]);
+    opt.set_step_size_base(step_base);
+    opt.set_max_iter_backtrack(max_backtrack);
+    if (mode == 1 && !csv_prefix.empty()) opt.update_file_names(csv_prefix);
     opt.set_initial_values(init_mu, init_prec);
     opt.optimize(false);
     const char* name = mode == 0 ? "factorwise" : "resident";
@@ -92,6 +100,7 @@ int main(int argc, char** argv) {
     std::fprintf(out, "%s %d %.17g", name, r.recorded(), opt.cost_value());
     for (int i = 0; i < mu.size(); ++i) std::fprintf(out, " %.17g", mu(i));
     std::fprintf(out, "\n");
+    std::fprintf(out, "%s_final_temperature %.17g\n", name, factors[0]->temperature());
     if (mode == 0) {
       // one pass over K + T factors costs two device calls (one per homogeneous set), not K + T
       std::fprintf(out, "device_calls %ld factors %d\n", opt.factorwise_device_calls(), K + T);

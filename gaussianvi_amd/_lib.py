@@ -80,6 +80,7 @@ SIGNATURES = {
     "gvi_profile_last": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
     "gvi_profile_geometry": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)],
     "gvi_set_variant": [C.c_void_p, C.c_int],
+    "gvi_set_option": [C.c_void_p, C.c_char_p, C.c_int],
 }
 STRING_GETTERS = {"gvi_version": [], "gvi_last_error": [C.c_void_p]}
 

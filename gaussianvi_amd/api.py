@@ -373,6 +373,9 @@ class Context:
     def set_variant(self, v):
         self._ck(self.lib.gvi_set_variant(self.h, v))
 
+    def set_option(self, name, value):
+        self._ck(self.lib.gvi_set_option(self.h, name.encode(), int(value)))
+
 
 def context_for_chain(chain, device=0, specs=None):
     """Context with the chain of gaussianvi_amd.synthetic.make_chain loaded; returns (ctx, set ids)."""

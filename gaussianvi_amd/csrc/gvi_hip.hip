@@ -151,6 +151,7 @@ struct gvi_ctx {
   int profile_every = 1;              // on = 3: bracket only every 8th dominant launch (an event pair costs ~14 us of queue gaps)
   long profile_count = 0;
   int target_waves = 2048;
+  int split_flush = SPLIT_FLUSH;      // GVI_SPLIT_FLUSH=0: plain recursive sums in the split kernel (A/B of the (24,7) rounding)
   bool sreg_pipe = true;              // GVI_SREG_PIPE=0: full pass on the compiler-scheduled body (A/B; bit-identical results)
   bool no_scost = false;              // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
@@ -527,7 +528,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   HIPCK(c, s.partial.ensure(need));
   MomArgs a;
   a.f = s.dev(); a.mu = mu; a.psi_ext = psi_ext; a.partial = s.partial.d();
-  a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full;
+  a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full; a.flush = c->split_flush;
   const int which = full ? 0 : 1;
   bool prof = !c->defer && c->profile && (c->profile_all || (full && &s == c->sets[0].get()));
   if (prof && !c->profile_all && (c->profile_count++ % c->profile_every) != 0) prof = false;
@@ -864,6 +865,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
+  if (const char* w = getenv("GVI_SPLIT_FLUSH")) c->split_flush = std::max(0, atoi(w));
   if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
   if (const char* w = getenv("GVI_NO_FUSE_GATHER")) c->fuse_gather = atoi(w) == 0;
   if (const char* w = getenv("GVI_SIDE_SOLVE")) c->side_solve = atoi(w) != 0;
@@ -2243,6 +2245,25 @@ gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nch
   if (variant) *variant = s->closed_form ? 0 : (s->fused_pair ? 5 : (s->use_reg ? 2 : (s->use_split ? 3 : 1)));
   if (nchunk) *nchunk = s->nchunk;
   if (chunk) *chunk = s->chunk;
+  return GVI_OK;
+}
+
+gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return GVI_ERR_ARG;
+  const std::string n(name);
+  if (n == "split_flush") ctx->split_flush = std::max(0, value);
+  else if (n == "sreg_pipe") ctx->sreg_pipe = value != 0;
+  else if (n == "pair_fuse") ctx->pair_fuse = value != 0;
+  else if (n == "fuse_gather") ctx->fuse_gather = value != 0;
+  else if (n == "side_solve") ctx->side_solve = value != 0;
+  else if (n == "warm_start") ctx->warm_start = value != 0;
+  else if (n == "no_scost") ctx->no_scost = value != 0;
+  else if (n == "target_waves") ctx->target_waves = std::max(1, value);
+  else return fail(ctx, GVI_ERR_ARG, "unknown option: " + n);
+  for (auto& s : ctx->sets) s->prep_slot = -1;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
+  ctx->ngd.spec_ready = false;
   return GVI_OK;
 }
 

@@ -542,6 +542,7 @@ struct MomArgs {
   int64_t chunk;           // points per block (multiple of 256 for generic, 64 for register kernel)
   int nchunk;
   int full;                // 1: all moments, 0: m0 only (cost pass)
+  int flush;               // split kernel: steps between second-level flushes (SPLIT_FLUSH; 0 = plain recursive sums, A/B only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -975,6 +976,38 @@ __device__ __forceinline__ void split_reduce(const double* acc, double* rw, doub
   }
 }
 
+// Second level of the split kernel's accumulation.  At (24,7) sum |w_i| / sum w_i = 1.5e7 and a lane adds ~16 000 terms per
+// chunk, so plain recursive summation carries eps * |w|_1 * sqrt(terms) ~ 5e-6 relative (profiles/r01_g_c5_full.json) -- over
+// the 1e-6 bar.  Every SPLIT_FLUSH steps the wave's register accumulators are therefore reduced across the lanes (same LDS
+// tile transpose as split_reduce) and added, with Neumaier compensation, into a wave-private (sum, comp) pair per moment in
+// LDS; the registers restart from zero.  First level: 64 terms per lane; cross-lane: a tree; second level: compensated.
+constexpr int SPLIT_FLUSH = 64;
+constexpr int SPLIT_LVL2_SLOTS = 96;     // >= accumulators per wave (83 at D = 24)
+template <int NT>
+__device__ __forceinline__ void split_flush(double* acc, double* rw, double* s2, double* c2, int lane) {
+  constexpr int NB = (NT + 15) / 16;
+#pragma unroll
+  for (int bb = 0; bb < NB; ++bb) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (bb * 16 + j < NT) { rw[j * 65 + lane] = acc[bb * 16 + j]; acc[bb * 16 + j] = 0.0; }
+    wave_lds_sync();
+    const int j = lane & 15, part16 = lane >> 4;
+    double x = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) x += rw[j * 65 + part16 * 16 + t];
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    const int loc = bb * 16 + lane;
+    if (lane < 16 && loc < NT) {
+      const double sv = s2[loc], tv = sv + x;
+      c2[loc] += fabs(sv) >= fabs(x) ? (sv - tv) + x : (x - tv) + sv;
+      s2[loc] = tv;
+    }
+    wave_lds_sync();
+  }
+}
+
 // psi operands: H is wave-uniform and read-only for the whole launch, so it is addressed through the constant
 // address space -- the compiler then fetches it with s_load_dwordx* into SGPRs (scalar cache) and feeds it to
 // v_fma_f64 as the scalar source: no LDS traffic and no VGPRs for the psi operands.
@@ -1021,10 +1054,11 @@ __device__ __forceinline__ double split_psi_rows(cdouble_t* hq, const double* u0
 
 template <int D, int R, int V>
 __device__ __forceinline__ void split_body(const MomArgs& a, const int k, const int lane, const double* lut,
-                                           const double* hs, double* px, double* red) {
+                                           const double* hs, double* px, double* red, double* lvl2) {
   constexpr SplitRows RW = split_rows<D>(V);
   constexpr int NA1 = split_count<D>(RW.lo, RW.hi), NA = NA1 + split_count<D>(RW.lo2, RW.hi2);
   constexpr int NT = NA + (V == 0 ? 1 : 0);                      // wave 0 also carries m0
+  static_assert(NT <= SPLIT_LVL2_SLOTS, "second-level slots");
   double acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = 0.0;
@@ -1034,6 +1068,11 @@ __device__ __forceinline__ void split_body(const MomArgs& a, const int k, const 
   const uint32_t* __restrict__ codes = a.f.codes;
   const double* __restrict__ w = a.f.w;
   cdouble_t* hq = (cdouble_t*)(a.f.Hq + ((size_t)k * 4 + V) * D * R);
+  double* s2 = lvl2 + V * 2 * SPLIT_LVL2_SLOTS;          // wave-private second-level (sum | compensation)
+  double* c2 = s2 + SPLIT_LVL2_SLOTS;
+  for (int j = lane; j < 2 * SPLIT_LVL2_SLOTS; j += 64) s2[j] = 0.0;
+  wave_lds_sync();
+  int since_flush = 0;
   int buf = 0;
   uint32_t cn[D / 4];                                            // next step's codes / weight (prefetch)
 #pragma unroll
@@ -1075,15 +1114,21 @@ __device__ __forceinline__ void split_body(const MomArgs& a, const int k, const 
 #pragma unroll
       for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
     }
+    if (a.flush > 0 && ++since_flush == a.flush) {                  // wave-uniform; no block barrier inside
+      split_flush<NT>(acc, red + V * 16 * 65, s2, c2, lane);
+      since_flush = 0;
+    }
   }
+  split_flush<NT>(acc, red + V * 16 * 65, s2, c2, lane);
   constexpr int NPK = (D + 1) * (D + 2) / 2;
   double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * NPK;
-  split_reduce<NT>(acc, red + V * 16 * 65, out, lane, [](int loc) {
+  auto dst = [](int loc) {
     if (loc >= NA) return 0;                                       // m0
     int row = loc < NA1 ? RW.lo : RW.lo2, rem = loc < NA1 ? loc : loc - NA1;
     while (rem >= D - row + 1) { rem -= D - row + 1; ++row; }
     return rem == 0 ? 1 + row : pair_index(D, row, row + rem - 1);
-  });
+  };
+  for (int loc = lane; loc < NT; loc += 64) out[dst(loc)] = s2[loc] + c2[loc];
 }
 
 // cost pass: psi only, so nothing to share -- every wave takes its own 64 points of a 256-point step
@@ -1096,7 +1141,7 @@ __device__ __forceinline__ void split_cost_body(const MomArgs& a, const int k, c
   const uint32_t* __restrict__ codes = a.f.codes;
   const double* __restrict__ w = a.f.w;
   cdouble_t* hq = (cdouble_t*)(a.f.Hq + (size_t)k * 4 * D * R);
-  double acc = 0.0;
+  double acc = 0.0, comp = 0.0;                                   // compensated: same |w|_1 argument as split_flush
   for (int64_t i = i0 + wave * 64 + lane; i < i1; i += 256) {
     uint32_t cd[D / 4];
 #pragma unroll
@@ -1107,8 +1152,12 @@ __device__ __forceinline__ void split_cost_body(const MomArgs& a, const int k, c
     double psi = 0.0;
 #pragma unroll
     for (int v = 0; v < 4; ++v) psi += split_psi_rows<D, R>(hq + v * D * R, hs + v * R, hs + 4 * R + v * R, z);
-    acc += i < a.f.N ? wi * psi : 0.0;
+    const double x = i < a.f.N ? wi * psi : 0.0;
+    const double tv = acc + x;
+    comp += fabs(acc) >= fabs(x) ? (acc - tv) + x : (x - tv) + acc;
+    acc = tv;
   }
+  acc += comp;
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
   if (lane == 0) red[wave] = acc;
@@ -1116,7 +1165,7 @@ __device__ __forceinline__ void split_cost_body(const MomArgs& a, const int k, c
   if (threadIdx.x == 0) a.partial[(size_t)k * a.nchunk + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-constexpr int SPLIT_LDS_DOUBLES(int D) { return 256 + 2 * D + 8 + 2 * 4 * 64 + 4 * 16 * 65; }
+constexpr int SPLIT_LDS_DOUBLES(int D) { return 256 + 2 * D + 8 + 2 * 4 * 64 + 4 * 16 * 65 + 4 * 2 * SPLIT_LVL2_SLOTS; }
 
 template <int D, int R, bool FULL>
 __global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
@@ -1125,6 +1174,7 @@ __global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
   double* hs = lut + 256;                  // u0 [4 R] | sgn [4 R]  (rows >= m: 0)
   double* px = hs + 2 * D + 8;             // [2][4][64] partial psi
   double* red = px + 2 * 4 * 64;           // [4][16][65]
+  double* lvl2 = red + 4 * 16 * 65;        // [4][2][SPLIT_LVL2_SLOTS] second-level sums
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int k = blockIdx.x, m = a.f.m;
   lut[threadIdx.x] = a.f.lut[threadIdx.x];
@@ -1136,10 +1186,10 @@ __global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
   __syncthreads();
   if (!FULL) { split_cost_body<D, R>(a, k, wave, lane, lut, hs, red); return; }
   switch (wave) {
-    case 0: split_body<D, R, 0>(a, k, lane, lut, hs, px, red); break;
-    case 1: split_body<D, R, 1>(a, k, lane, lut, hs, px, red); break;
-    case 2: split_body<D, R, 2>(a, k, lane, lut, hs, px, red); break;
-    default: split_body<D, R, 3>(a, k, lane, lut, hs, px, red); break;
+    case 0: split_body<D, R, 0>(a, k, lane, lut, hs, px, red, lvl2); break;
+    case 1: split_body<D, R, 1>(a, k, lane, lut, hs, px, red, lvl2); break;
+    case 2: split_body<D, R, 2>(a, k, lane, lut, hs, px, red, lvl2); break;
+    default: split_body<D, R, 3>(a, k, lane, lut, hs, px, red, lvl2); break;
   }
 }
 

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -54,6 +55,13 @@ struct RankTable {
   }
 };
 
+// product of the 1-D weights in long double (GVI_SPGH_EXTENDED)
+long double prod_ext(const std::vector<int>& lv, const std::vector<int>& it, int d) {
+  long double w = 1.0L;
+  for (int a = 0; a < d; ++a) w *= (long double)GQN_WEIGHT[GQN_OFF[lv[a] - 1] + it[a]];
+  return w;
+}
+
 double binom(int n, int k) {
   if (k < 0 || k > n) return 0.0;
   double r = 1.0;
@@ -86,7 +94,13 @@ int spgh_generate(int d, int p, SparseGrid& g) {
   // positive orthant: code vector -> slot; weights accumulate in generation order
   std::unordered_map<std::u16string, int64_t> slot;
   std::vector<std::u16string> keys;
+  // Weights accumulate in double, in the reference's order (bit parity with nwspgr's sequential sums).  GVI_SPGH_EXTENDED=1
+  // keeps the sums and the normalisation in long double instead -- an A/B switch for the rounding study of the (24,7)
+  // table (tests/test_gpu_parity.py::test_c5_*), not a product mode.
+  const char* ext_env = std::getenv("GVI_SPGH_EXTENDED");
+  const bool extended = ext_env && std::atoi(ext_env) != 0;
   std::vector<double> wpos;
+  std::vector<long double> wext;
   std::u16string key(d, u'\0');
   std::vector<int> cnt(d), it(d);
   for (int q = minq; q <= maxq; ++q) {
@@ -105,8 +119,10 @@ int spgh_generate(int d, int p, SparseGrid& g) {
           slot.emplace(key, (int64_t)keys.size());
           keys.push_back(key);
           wpos.push_back(bq * w);
+          if (extended) wext.push_back((long double)bq * prod_ext(lv, it, d));
         } else {
           wpos[f->second] += bq * w;
+          if (extended) wext[f->second] += (long double)bq * prod_ext(lv, it, d);
         }
         int a = d - 1;                                        // last dimension fastest
         while (a >= 0 && ++it[a] == cnt[a]) it[a--] = 0;
@@ -124,6 +140,7 @@ int spgh_generate(int d, int p, SparseGrid& g) {
   }
   std::vector<int16_t> codes((size_t)N * d);
   std::vector<double> w(N);
+  std::vector<long double> wl(extended ? N : 0);
   int64_t r = 0;
   std::vector<int> nzpos;
   for (size_t s = 0; s < keys.size(); ++s) {
@@ -137,6 +154,7 @@ int spgh_generate(int d, int p, SparseGrid& g) {
       for (size_t b = 0; b < nzpos.size(); ++b)
         if (m >> b & 1) row[nzpos[b]] = (int16_t)-row[nzpos[b]];
       w[r] = wpos[s];
+      if (extended) wl[r] = wext[s];
     }
   }
 
@@ -157,9 +175,11 @@ int spgh_generate(int d, int p, SparseGrid& g) {
   g.idx.resize((size_t)N * d * 3);
   double total = 0.0;
   for (int64_t i = 0; i < N; ++i) total += w[order[i]];
+  long double total_ext = 0.0L;
+  if (extended) for (int64_t i = 0; i < N; ++i) total_ext += wl[order[i]];
   for (int64_t i = 0; i < N; ++i) {
     const int16_t* row = &codes[(size_t)order[i] * d];
-    g.w[i] = w[order[i]] / total;
+    g.w[i] = extended ? (double)(wl[order[i]] / total_ext) : w[order[i]] / total;
     for (int a = 0; a < d; ++a) {
       const int c = row[a], rk = c < 0 ? -c : c;
       const Node1D& nd = rt.by_rank[rk];

@@ -24,6 +24,10 @@ CONFIGS = {
     "c3t2": (33, 2, 6, 5, "ltv"),           # shortest chains: one / two prior factors (tail blocks of the fused launches)
     "c3t3": (34, 3, 6, 5, "ltv"),
     "c3": (3, 1025, 6, 5, "ltv"),           # BASELINE.json configs[2] (headline)
+    # the LITERAL SURVEY 8(d) C3 chain: dt = 0.05, seeded stable A_k (6 x 6) / B_k (6 x 3), two end anchors only.
+    # cond(Hessian) ~ 1e7: kept for parity at operator level and for the checked conditioning bound (tests), not benched
+    "c3lit": (36, 1025, 6, 5, "ltvlit"),
+    "c3litmini": (37, 17, 6, 5, "ltvlit"),
     "c5mini": (51, 5, 12, 5, "ltv"),        # d = 24 slice (split kernel), N(24,5) = 243 905
     "c5small": (52, 33, 12, 6, "ltv", 5),   # d = 24, p = 6: N = 2 438 801; unary factors at p = 5
     "c5": (5, 4097, 12, 7, "ltv", 5),       # BASELINE.json configs[4]: N(24,7) = 20 557 057 (fp64, coded table)
@@ -72,12 +76,73 @@ def _ltv(rng, nd, dt):
     return Phi, np.linalg.inv(Q)
 
 
+def _ltv_literal(rng, n, dt):
+    """SURVEY 8(d) C3 as written: (Phi_k, Q_k^-1) = exact discretisation over 4 piece-wise-constant sub-intervals (product of
+    matrix exponentials / Van Loan) of a seeded STABLE A_k (n x n, spectral radius <= 1) and B_k (n x n/2) -- the maths of
+    gp/LTV_prior.h:123-197 without GSL."""
+    from scipy.linalg import expm
+    Phi, Q = np.eye(n), np.zeros((n, n))
+    h = dt / 4
+    for _ in range(4):
+        G = rng.normal(size=(n, n))
+        G = G - (np.linalg.eigvals(G).real.max() + 0.1) * np.eye(n)            # stable: Re(lambda) < 0
+        A = G / max(1.0, np.abs(np.linalg.eigvals(G)).max())                   # spectral radius <= 1
+        B = rng.normal(size=(n, n // 2))
+        M = np.zeros((2 * n, 2 * n))
+        M[:n, :n], M[:n, n:], M[n:, n:] = -A, B @ B.T, A.T
+        E = expm(M * h)
+        Ad = E[n:, n:].T
+        Qd = Ad @ E[:n, n:]
+        Phi = Ad @ Phi
+        Q = Ad @ Q @ Ad.T + (Qd + Qd.T) / 2
+    return Phi, np.linalg.inv(Q)
+
+
+def make_literal_chain(name: str):
+    """The literal BASELINE configs[2] chain of SURVEY 8(d): T - 1 LTV-form priors (d = 2n) and TWO FixedPriorGP end anchors
+    (K0 = 1e-2 I) -- no unary factor on the interior states; start state = straight line + N(0, 0.05^2) jitter, initial
+    precision = sum of the factor Hessians."""
+    cfg, T, n, p, kind = CONFIGS[name][:5]
+    rng = np.random.default_rng(0x5EED + cfg)
+    K, dt = T - 1, 0.05
+    Phi = np.zeros((K, n, n))
+    Qinv = np.zeros((K, n, n))
+    for k in range(K):
+        Phi[k], Qinv[k] = _ltv_literal(rng, n, dt)
+    goal = rng.uniform(1.0, 2.0, n)
+    t = np.arange(T)[:, None] / (T - 1)
+    nominal = goal[None, :] * t
+    mu0 = nominal + 0.05 * rng.normal(size=nominal.shape)
+    anchors = np.stack([nominal[0], nominal[-1]])
+    Kinv = np.stack([np.eye(n) / 1e-2] * 2)
+    D0 = np.zeros((T, n, n))
+    U0 = np.zeros((T - 1, n, n))
+    for k in range(K):
+        Lam = np.hstack([-Phi[k], np.eye(n)])
+        M = Lam.T @ Qinv[k] @ Lam
+        D0[k] += M[:n, :n]
+        D0[k + 1] += M[n:, n:]
+        U0[k] += M[:n, n:]
+    D0[0] += 2 * Kinv[0]
+    D0[-1] += 2 * Kinv[1]
+    specs = [
+        dict(kind=PSI_QUAD_PRIOR, d=2 * n, p=p, start=np.arange(K, dtype=np.int32),
+             params=np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1),
+             temperature=np.ones(K), Phi=Phi, Qinv=Qinv),
+        dict(kind=PSI_FIXED_PRIOR, d=n, p=p, start=np.array([0, T - 1], dtype=np.int32),
+             params=np.concatenate([anchors, Kinv.reshape(2, -1)], axis=1), temperature=np.ones(2), mu0=anchors, Kinv=Kinv),
+    ]
+    return dict(name=name, T=T, n=n, specs=specs, mu0=mu0, D0=D0, U0=U0)
+
+
 def make_chain(name: str):
     """Returns dict(T, n, specs, mu0, D0, U0).  specs[0]: the T-1 binary prior factors (d = 2n,
     QUAD_PRIOR); specs[1]: T unary measurement factors (d = n, FIXED_PRIOR), the first and the last
     being the strong end anchors."""
     if name not in CONFIGS and name.startswith("c3x") and name[3:].isdigit():
         CONFIGS[name] = (3, 1024 * int(name[3:]) + 1, 6, 5, "ltv")      # weak-scaling family: 1024 factors per GPU
+    if CONFIGS[name][4] == "ltvlit":
+        return make_literal_chain(name)
     cfg, T, n, p, kind = CONFIGS[name][:5]
     p_unary = CONFIGS[name][5] if len(CONFIGS[name]) > 5 else p
     rng = np.random.default_rng(0x5EED + cfg)

@@ -275,6 +275,10 @@ gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nch
 /* Kernel variant override for A/B runs: 0 = auto, 1 = generic LDS kernel, 2 = register kernel (psi operands in
  * LDS), 3 = operand-resident, 4 = LDS-staged table (experimental), 5 = register kernel with psi operands in SGPRs. */
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
+/* Runtime form of the A/B environment switches read at gvi_ctx_create; results are identical in every
+ * setting except "split_flush", which changes the summation order of the d = 16 / 20 / 24 kernel (0 = plain recursive sums).
+ * Names: split_flush, sreg_pipe, pair_fuse, fuse_gather, side_solve, warm_start, no_scost, target_waves. */
+gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus
 }

@@ -948,6 +948,16 @@ class FactorSet:
         self.d, self.p, self.psi_batch = d, p, psi_batch
         self.temperature = np.full(len(self.start), float(temperature))
         self.Z, self.w = nwspgr_cached(d, p)
+        # optional (mk, Sk, temperature) -> (E_phi, Vdmu, Vddmu): the C restatement (oracle/c, reference-shaped three-pass
+        # form, OpenMP over factors) instead of the numpy one -- same numbers (tests/test_oracle_c.py), seconds instead
+        # of a minute per pass at BASELINE sizes
+        self.fast_moments = None
+
+    def moments(self, mk, Sk):
+        if self.fast_moments is None:
+            return batched_moments(self.Z, self.w, mk, Sk, self.psi_batch, self.temperature)
+        E, Vd, Vdd = self.fast_moments(mk, Sk, self.temperature)
+        return dict(E_phi=E, cost=E / self.temperature, Vdmu=Vd, Vddmu=Vdd)
 
 
 class ChainNGD:
@@ -964,7 +974,7 @@ class ChainNGD:
         value = 0.0
         for fs in self.sets:
             mk, Sk = gather_marginals(mu, SigD, SigU, fs.start, fs.d)
-            r = batched_moments(fs.Z, fs.w, mk, Sk, fs.psi_batch, fs.temperature)
+            r = fs.moments(mk, Sk)
             value += r["cost"].sum()
         return value + logdet_half(bt_ldlt_pivots(D, U))
 
@@ -972,7 +982,7 @@ class ChainNGD:
         parts = []
         for fs in self.sets:
             mk, Sk = gather_marginals(self.mu, self.SigD, self.SigU, fs.start, fs.d)
-            r = batched_moments(fs.Z, fs.w, mk, Sk, fs.psi_batch, fs.temperature)
+            r = fs.moments(mk, Sk)
             parts.append((fs.start, r["Vdmu"], r["Vddmu"]))
         g, Dv, Uv = bt_assemble(self.T, self.n, parts)
         dmu = bt_solve(Dv, Uv, -g.reshape(-1)).reshape(self.T, self.n)

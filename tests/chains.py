@@ -50,11 +50,18 @@ def make_chain(name):
         if spec["kind"] < syn.PSI_HINGE_SDF_2D:
             spec["psi_point"] = oracle_psi_point(spec)
 
-    def oracle_sets():
+    def oracle_sets(fast=False):
+        """fast: quadratic kinds go through the oracle's C restatement (oracle/c, OpenMP) instead of numpy -- the same
+        checker, pinned against the numpy one in tests/test_oracle_c.py; for full-size multi-iteration runs."""
         out = []
         for spec in ch["specs"]:
             fs = o.FactorSet(spec["start"], spec["d"], spec["p"], spec["psi_batch"])
             fs.temperature = np.asarray(spec["temperature"], dtype=np.float64)
+            if fast and spec["kind"] in (syn.PSI_QUAD_PRIOR, syn.PSI_FIXED_PRIOR):
+                import c_oracle
+                n_arg = ch["n"] if spec["kind"] == syn.PSI_QUAD_PRIOR else spec["d"]
+                fs.fast_moments = (lambda sp, fs_, n_: lambda mk, Sk, temp: c_oracle.moments(
+                    fs_.Z, fs_.w, mk, Sk, sp["kind"], sp["params"], n_, temp, fused=False))(spec, fs, n_arg)
             out.append(fs)
         return out
     ch["oracle_sets"] = oracle_sets

@@ -91,3 +91,13 @@ def test_generator_rejects_untabulated(lib):
     with pytest.raises(api.GviError) as e:
         api.spgh_count(3, 26)
     assert e.value.status == 4
+
+
+@pytest.mark.parametrize("p,lo,hi", [(5, 1.5e5, 3e5), (6, 1.5e6, 2.5e6)])
+def test_wide_table_weight_cancellation(lib, p, lo, hi):
+    """sum |w_i| / |sum w_i| of the d = 24 tables (2.0e5 at p = 5, 1.9e6 at p = 6, 1.5e7 at p = 7 -- the
+    (24,7) figure is measured in the GPU suite): the reason config 5 runs in fp64."""
+    Z, w, idx = api.spgh_nodes(24, p)
+    ratio = np.abs(w).sum() / abs(w.sum())
+    assert lo < ratio < hi, ratio
+    assert abs(w.sum() - 1.0) < 1e-9

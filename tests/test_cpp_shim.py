@@ -204,3 +204,49 @@ def test_recorder_writes_the_nine_reference_files_in_reference_layout(tmp_path):
     # the layout really is column-major: the (0, 1) block entry of state 0's precision sits at row 2, not row 1
     P0 = want["joint_precision"][:, 0].reshape((T * n, T * n), order="F")
     assert abs(P0[0, n] - P0[n, 0]) < 1e-12 and abs(P0[0, n]) > 0
+
+
+@pytest.mark.gpu
+def test_optimize_follows_backtrack_exhaustion_through_the_temperature_switch(tmp_path):
+    """gvibase/GVI-GH-impl.h:102-117: when the line search runs out of backtracking steps in the first temperature phase,
+    optimize() switches every factor to the other temperature and carries on.  Forced here with a huge base step and one
+    backtrack (first phase T = 10: both trials rejected -> switch to T = 1 -> second trials accepted), on the device
+    through the C++ shim in both execution modes, against the oracle's restatement o.NGDGH.optimize."""
+    import gvi_oracle as o
+    from chains import make_chain
+    from gaussianvi_amd import synthetic as syn
+    build.build_examples()
+    exe = os.path.join(os.path.dirname(build.build_examples()), "factorwise_example")
+    ch = make_chain("tiny")
+    T, n = ch["T"], ch["n"]
+    prob, out = str(tmp_path / "tiny.txt"), str(tmp_path / "out.txt")
+    _write_problem(prob, ch, syn.DT["minacc"], syn.QC)
+    iters, base, maxbt, t_first, t_after = 6, 3.0, 1, 10.0, 1.0
+    r = subprocess.run([exe, prob, str(iters), out, "-", repr(base), str(maxbt), repr(t_first), repr(t_after)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    facs = []
+    for spec in ch["specs"]:
+        for k, s in enumerate(spec["start"]):
+            facs.append(o.NGDFactorizedBaseGH(spec["d"], n, spec["p"], spec["psi_point"](k), T, int(s), t_first, t_after))
+    opt = o.NGDGH(facs, n, T, iters, solver="direct")
+    opt.set_step_size_base(base); opt.set_max_iter_backtrack(maxbt); opt.set_niter_low_temperature(iters + 1)
+    opt.set_initial_values(ch["mu0"].reshape(-1), o.bt_to_dense(ch["D0"], ch["U0"]))
+    opt.optimize()
+    costs, means = opt.record["cost"], opt.record["mean"]
+    assert len(costs) == iters and costs[1] > costs[0] and facs[0].temperature() == t_after      # the switch happened
+    assert np.allclose(means[0], means[1])                                                        # ... without a move
+    rows, info = {"factorwise": [], "resident": []}, {}
+    for line in open(out):
+        tok = line.split()
+        if tok[0] in rows:
+            rows[tok[0]].append((int(tok[1]), float(tok[2]), np.array(tok[3:], dtype=np.float64)))
+        else:
+            info[tok[0]] = tok[1:]
+    for name in ("factorwise", "resident"):
+        assert float(info[name + "_final_temperature"][0]) == t_after
+        got = rows[name][:iters]
+        assert len(got) == iters
+        for (it, cost, mu), c_ref, mu_ref in zip(got, costs, means):
+            assert abs(cost - c_ref) < 1e-9 * abs(c_ref), (name, it, cost, c_ref)
+            assert np.abs(mu - mu_ref).max() < 1e-8 * np.abs(mu_ref).max(), (name, it)
