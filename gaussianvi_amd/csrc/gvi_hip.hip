@@ -49,6 +49,8 @@ struct Table {
   int64_t N = 0, Np = 0;
   DevMem Zt, w;
   DevMem Zq;               // tile-major copy [Np / 64][d + 1][64] (row d = w) read by the hand-pipelined kernels
+  DevMem Zm;               // mirror-half tile-major table (one representative per +-pair), empty if the table is not symmetric
+  int64_t Nm = 0, Nmp = 0;
   DevMem codes, lut;       // 8-bit node codes [d/4][Np] + value look-up (moments_split_kernel); empty when not coded
   bool coded = false;
 };
@@ -76,6 +78,7 @@ struct FactorSet {
   bool fused_pair = false;            // last resident launch went out fused with the other set
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   bool all_pos = false;               // every residual row has sgn = +1 (positive-definite weight)
+  bool use_mirror = true;             // evaluate +-pairs from the mirror-half table where the kernel supports it (ctx->mirror)
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
   hipEvent_t done = nullptr;
@@ -95,6 +98,7 @@ struct FactorSet {
     f.N = table->N; f.Np = table->Np;
     f.Zt = table->Zt.d(); f.w = table->w.d();
     f.Zq = table->Zq.p ? table->Zq.d() : nullptr; f.all_pos = all_pos ? 1 : 0;
+    f.Zm = (table->Zm.p && use_mirror) ? table->Zm.d() : nullptr; f.Nm = table->Nm; f.Nmp = table->Nmp;
     f.codes = table->coded ? (const uint32_t*)table->codes.p : nullptr; f.lut = table->coded ? table->lut.d() : nullptr;
     f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
     f.temperature = unit_temperature ? ones.d() : temperature.d();
@@ -151,6 +155,7 @@ struct gvi_ctx {
   int profile_every = 1;              // on = 3: bracket only every 8th dominant launch (an event pair costs ~14 us of queue gaps)
   long profile_count = 0;
   int target_waves = 2048;
+  bool mirror = true;                 // GVI_MIRROR=0: never pair z with -z (A/B; results agree to rounding)
   int split_flush = SPLIT_FLUSH;      // GVI_SPLIT_FLUSH=0: plain recursive sums in the split kernel (A/B of the (24,7) rounding)
   bool sreg_pipe = true;              // GVI_SREG_PIPE=0: full pass on the compiler-scheduled body (A/B; bit-identical results)
   bool no_scost = false;              // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
@@ -251,6 +256,31 @@ gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const dou
     }
     HIPCK(c, t.Zq.ensure(zq.size() * 8));
     HIPCK(c, hipMemcpy(t.Zq.p, zq.data(), zq.size() * 8, hipMemcpyHostToDevice));
+    // Mirror-half table.  Rows are in ascending lexicographic order, so the mirror image of row i is row N - 1 - i; the
+    // grid of nwspgr (sym = 1: every non-zero coordinate reflected with the weight copied, nwspgr.m:108-126) is exactly
+    // symmetric.  A caller-supplied table that is not keeps the unpaired kernels.
+    bool sym = true;
+    for (int64_t i = 0; i < N / 2 && sym; ++i) {
+      sym = w[i] == w[N - 1 - i];
+      for (int a = 0; a < d && sym; ++a) sym = Z[(size_t)i * d + a] == -Z[(size_t)(N - 1 - i) * d + a];
+    }
+    if (sym && (N & 1))
+      for (int a = 0; a < d; ++a) sym = sym && Z[(size_t)(N / 2) * d + a] == 0.0;
+    t.Nm = t.Nmp = 0;
+    t.Zm.release();
+    if (sym) {
+      t.Nm = N - N / 2;                                   // upper half (first non-zero coordinate positive) + the origin
+      t.Nmp = (t.Nm + 63) / 64 * 64;
+      std::vector<double> zm((size_t)t.Nmp / 64 * rows * 64, 0.0);
+      for (int64_t j = 0; j < t.Nm; ++j) {
+        const int64_t i = N / 2 + j;                      // j = 0 is the origin when N is odd
+        const size_t base = ((size_t)j / 64) * rows * 64 + (size_t)j % 64;
+        for (int a = 0; a < d; ++a) zm[base + (size_t)a * 64] = Z[(size_t)i * d + a];
+        zm[base + (size_t)d * 64] = ((N & 1) && j == 0) ? 0.5 * w[i] : w[i];   // the origin is its own mirror image
+      }
+      HIPCK(c, t.Zm.ensure(zm.size() * 8));
+      HIPCK(c, hipMemcpy(t.Zm.p, zm.data(), zm.size() * 8, hipMemcpyHostToDevice));
+    }
   }
   // 8-bit node codes for the split kernel: a Smolyak table has a few dozen distinct node values
   t.coded = false;
@@ -527,8 +557,14 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   const size_t need = (size_t)s.K * s.nchunk * npairs(s.d) * 8;
   HIPCK(c, s.partial.ensure(need));
   MomArgs a;
+  s.use_mirror = c->mirror;
   a.f = s.dev(); a.mu = mu; a.psi_ext = psi_ext; a.partial = s.partial.d();
   a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full; a.flush = c->split_flush;
+  a.mchunk = 0;
+  if (s.table->Nmp > 0) {                                   // same number of chunks over the mirror-half table
+    const int64_t tiles = s.table->Nmp / 64;
+    a.mchunk = (tiles + s.nchunk - 1) / s.nchunk * 64;
+  }
   const int which = full ? 0 : 1;
   bool prof = !c->defer && c->profile && (c->profile_all || (full && &s == c->sets[0].get()));
   if (prof && !c->profile_all && (c->profile_count++ % c->profile_every) != 0) prof = false;
@@ -865,6 +901,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
+  if (const char* w = getenv("GVI_MIRROR")) c->mirror = atoi(w) != 0;
   if (const char* w = getenv("GVI_SPLIT_FLUSH")) c->split_flush = std::max(0, atoi(w));
   if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
   if (const char* w = getenv("GVI_NO_FUSE_GATHER")) c->fuse_gather = atoi(w) == 0;
@@ -2253,6 +2290,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   const std::string n(name);
   if (n == "split_flush") ctx->split_flush = std::max(0, value);
   else if (n == "sreg_pipe") ctx->sreg_pipe = value != 0;
+  else if (n == "mirror") ctx->mirror = value != 0;
   else if (n == "pair_fuse") ctx->pair_fuse = value != 0;
   else if (n == "fuse_gather") ctx->fuse_gather = value != 0;
   else if (n == "side_solve") ctx->side_solve = value != 0;

@@ -52,6 +52,12 @@ struct FactorDev {
   const double* Zt;         // [d][Np] dimension-major: lane-over-points loads are coalesced
   const double* w;          // [Np]
   const double* Zq;         // [Np / 64][d + 1][64] tile-major copy (row d = w): one contiguous block per 64-point step
+  // Mirror-half table: a sparse Gauss-Hermite grid is symmetric -- with every point z it holds -z with the same weight --
+  // so only one representative per +-pair is stored (first non-zero coordinate positive; the origin with HALF its weight)
+  // and the kernels evaluate psi at z and -z from one load:  Zm [Nmp / 64][d + 1][64], Nm representatives, null if the
+  // table is not symmetric.
+  const double* Zm;
+  int64_t Nm, Nmp;
   int all_pos;              // 1: every sgn entry is +1 (sum-of-squares kinds with a positive-definite weight)
   const uint32_t* codes;    // [d/4][Np] four 8-bit node codes per word (tables with <= 256 distinct values) or null
   const double* lut;        // [256] code -> node value
@@ -543,6 +549,7 @@ struct MomArgs {
   int nchunk;
   int full;                // 1: all moments, 0: m0 only (cost pass)
   int flush;               // split kernel: steps between second-level flushes (SPLIT_FLUSH; 0 = plain recursive sums, A/B only)
+  int64_t mchunk;          // mirror-half table: representatives per chunk (same nchunk)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1335,23 +1342,25 @@ __device__ __forceinline__ void pipe_psi_cols(double (&u)[M], double (&z)[D], do
 }
 
 // accumulation phase, row C of the packed second moment; behind it the NEXT step's z[C] is loaded into the same register
-template <int D, int BIAS, int C = 0>
-__device__ __forceinline__ void pipe_acc_rows(double (&acc)[(D + 1) * (D + 2) / 2], double (&z)[D], const double cw,
+// MIRROR: cw = c(z) + c(-z) feeds the (even) second moment, cm = c(z) - c(-z) the (odd) first moment
+template <int D, int BIAS, bool MIRROR, int C = 0>
+__device__ __forceinline__ void pipe_acc_rows(double (&acc)[(D + 1) * (D + 2) / 2], double (&z)[D], const double cw, const double cm,
                                               const unsigned voff, const char* const Zq) {
   if constexpr (C < D) {
     constexpr int q0 = 1 + D + C * D - C * (C - 1) / 2;         // packed index of (C, C)
     const double tc = cw * z[C];
-    acc[1 + C] += tc;
+    if constexpr (MIRROR) acc[1 + C] = fma(cm, z[C], acc[1 + C]);
+    else acc[1 + C] += tc;
 #pragma unroll
     for (int e = C; e < D; ++e) acc[q0 + e - C] = fma(tc, z[e], acc[q0 + e - C]);
     __builtin_amdgcn_sched_barrier(0);
     GVI_ZLOAD(z[C], voff, Zq, C * 512 - BIAS);                  // row C was the last reader of z[C]
     __builtin_amdgcn_sched_barrier(0);
-    pipe_acc_rows<D, BIAS, C + 1>(acc, z, cw, voff, Zq);
+    pipe_acc_rows<D, BIAS, MIRROR, C + 1>(acc, z, cw, cm, voff, Zq);
   }
 }
 
-template <int D, int M, bool SIGNED>
+template <int D, int M, bool SIGNED, bool MIRROR>
 __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
   constexpr int NP = (D + 1) * (D + 2) / 2;
   constexpr int NB = (NP + 15) / 16;
@@ -1382,14 +1391,15 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
   double u0v[M];
 #pragma unroll
   for (int r = 0; r < M; ++r) u0v[r] = us_w[r];
-  const int64_t Np = a.f.Np;
-  const int64_t i0 = (int64_t)by * a.chunk;
-  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
-  const int ntiles = (int)((i1 - i0) >> 6);          // chunks are whole 64-point tiles (Np is a multiple of 256)
-  const char* const Zq = (const char*)a.f.Zq;
+  const int64_t Np = MIRROR ? a.f.Nmp : a.f.Np;
+  const int64_t ck = MIRROR ? a.mchunk : a.chunk;
+  const int64_t i0 = (int64_t)by * ck;
+  const int64_t i1 = (i0 + ck < Np) ? i0 + ck : Np;
+  const int ntiles = i1 > i0 ? (int)((i1 - i0) >> 6) : 0;   // chunks are whole 64-point tiles
+  const char* const Zq = (const char*)(MIRROR ? a.f.Zm : a.f.Zq);
   unsigned voff = (unsigned)(i0 >> 6) * (unsigned)TB + (unsigned)lane * 8u + (unsigned)BIAS;
   unsigned idx = (unsigned)(i0 + lane);
-  const unsigned nvalid = (unsigned)a.f.N;
+  const unsigned nvalid = (unsigned)(MIRROR ? a.f.Nm : a.f.N);
   double z[D], wi;
   double hA[GS], hB[GS];                             // operand groups of even / odd index (SGPRs)
   if (ntiles > 0) {
@@ -1419,7 +1429,25 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
       for (int rr = 0; rr < M; ++rr) psi = fma(u[rr], u[rr], psi);
     }
     asm volatile("" : "+v"(wi));                       // w was issued before z[0]: it has landed with z[0]'s wait
-    const double cw = idx < nvalid ? wi * psi : 0.0;   // pad rows carry w = 0, z = 0; the select keeps a NaN psi out
+    double cw, cm = 0.0;
+    if constexpr (MIRROR) {
+      // the mirror point: u(-z) = u0 - H z = 2 u0 - u(z), psi(-z) from it; one load and one H z for two evaluations
+      double psim = 0.0;
+#pragma unroll
+      for (int rr = 0; rr < M; ++rr) u[rr] = fma(u0v[rr], 2.0, -u[rr]);
+      if constexpr (SIGNED) {
+#pragma unroll
+        for (int rr = 0; rr < M; ++rr) psim = fma(us_w[M + rr] * u[rr], u[rr], psim);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < M; ++rr) psim = fma(u[rr], u[rr], psim);
+      }
+      const bool ok = idx < nvalid;                    // pad rows carry w = 0, z = 0; the select keeps a NaN psi out
+      cw = ok ? wi * (psi + psim) : 0.0;
+      cm = ok ? wi * (psi - psim) : 0.0;
+    } else {
+      cw = idx < nvalid ? wi * psi : 0.0;              // pad rows carry w = 0, z = 0; the select keeps a NaN psi out
+    }
     // next step (the last step re-reads its own tile: no out-of-range address, the values are never used)
     const bool more = t + 1 < ntiles;
     voff += more ? (unsigned)TB : 0u;
@@ -1435,7 +1463,7 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
     }
     __builtin_amdgcn_sched_barrier(0);
     acc[0] += cw;
-    pipe_acc_rows<D, BIAS>(acc, z, cw, voff, Zq);
+    pipe_acc_rows<D, BIAS, MIRROR>(acc, z, cw, cm, voff, Zq);
   }
   // drain: nothing below may reuse z / w registers while the (unused) loads of the last step are in flight
   if (ntiles > 0) {
@@ -1464,8 +1492,13 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
 // every residual row of the set has positive weight (sgn = +1): the sign multiply of psi is dropped
 template <int D, int M>
 __device__ __forceinline__ void sreg_pipe_dispatch(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
-  if (a.f.all_pos) sreg_pipe_body<D, M, false>(a, bx, by, usb, redb);
-  else sreg_pipe_body<D, M, true>(a, bx, by, usb, redb);
+  if (a.f.Zm) {
+    if (a.f.all_pos) sreg_pipe_body<D, M, false, true>(a, bx, by, usb, redb);
+    else sreg_pipe_body<D, M, true, true>(a, bx, by, usb, redb);
+  } else {
+    if (a.f.all_pos) sreg_pipe_body<D, M, false, false>(a, bx, by, usb, redb);
+    else sreg_pipe_body<D, M, true, false>(a, bx, by, usb, redb);
+  }
 }
 
 // PIPE selects the hand-pipelined body for the full pass (the cost pass has its own kernels)

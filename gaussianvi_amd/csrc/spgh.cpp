@@ -94,11 +94,18 @@ int spgh_generate(int d, int p, SparseGrid& g) {
   // positive orthant: code vector -> slot; weights accumulate in generation order
   std::unordered_map<std::u16string, int64_t> slot;
   std::vector<std::u16string> keys;
-  // Weights accumulate in double, in the reference's order (bit parity with nwspgr's sequential sums).  GVI_SPGH_EXTENDED=1
-  // keeps the sums and the normalisation in long double instead -- an A/B switch for the rounding study of the (24,7)
-  // table (tests/test_gpu_parity.py::test_c5_*), not a product mode.
+  // Merged weights.  The reference sums the contributions of one node in double, in generation order (nwspgr.m:88-103);
+  // `wpos` reproduces those sums bit for bit and is what every key of the reference's table file gets
+  // (quadrature/saveSparseGHWeightMap.h:16-23: dims 1..13 up to degree {25,25,19,13,11,9,8,7,7,7,6,6,6}, dims 14..20 up to
+  // 5) -- parity with the reference's table comes first.  The contributions alternate in sign with binomial magnitudes,
+  // and OUTSIDE that key range the double sums degrade visibly: at (24,7) they lose ~7 digits and a quadratic psi is
+  // integrated to 1e-5 only (measured A/B, tests/test_gpu_parity.py::test_c5_full_table_*: 1.0e-5 with the double sums,
+  // 4e-8 with the sums below; the summation order on the device plays no role).  Keys the reference never tabulated are
+  // therefore merged and normalised in long double and rounded once (`wext`).  GVI_SPGH_EXTENDED=0 / 1 forces either.
+  static const int kRefMaxDeg[13] = {25, 25, 19, 13, 11, 9, 8, 7, 7, 7, 6, 6, 6};
+  const bool ref_key = (d <= 13 && p <= kRefMaxDeg[d - 1]) || (d >= 14 && d <= 20 && p <= 5);
   const char* ext_env = std::getenv("GVI_SPGH_EXTENDED");
-  const bool extended = ext_env && std::atoi(ext_env) != 0;
+  const bool extended = ext_env ? std::atoi(ext_env) != 0 : !ref_key;
   std::vector<double> wpos;
   std::vector<long double> wext;
   std::u16string key(d, u'\0');

@@ -71,12 +71,12 @@ def spgr_get_seq(d: int, norm: int) -> np.ndarray:
     return np.array(fs, dtype=np.int64) + 1
 
 
-def _kron_prod(levels):
+def _kron_prod(levels, wdtype=np.float64):
     """Tensor product of positive-half rules, last dimension fastest (nwspgr.m:183-190).
     Returns nodes, weights and the (level, node-index) pair of every coordinate."""
     n0, w0 = gqn(int(levels[0]))
     nodes = n0[:, None]
-    weights = w0.copy()
+    weights = w0.astype(wdtype)
     idx = np.stack([np.full(len(n0), levels[0]), np.arange(len(n0))], axis=1)[:, None, :]
     for lv in levels[1:]:
         nn, ww = gqn(int(lv))
@@ -85,7 +85,7 @@ def _kron_prod(levels):
         new_idx = np.stack([np.full(r_new, lv), np.arange(r_new)], axis=1)
         idx = np.concatenate([np.repeat(idx, r_new, axis=0),
                               np.tile(new_idx, (r_old, 1))[:, None, :]], axis=1)
-        weights = np.kron(weights, ww)
+        weights = np.kron(weights, ww.astype(wdtype))
     return nodes, weights, idx
 
 
@@ -94,22 +94,37 @@ def _sortrows(nodes):
     return np.lexsort(nodes.T[::-1])
 
 
-def nwspgr(dim: int, k: int, return_index: bool = False):
+_REF_MAX_DEG = (25, 25, 19, 13, 11, 9, 8, 7, 7, 7, 6, 6, 6)
+
+
+def is_reference_table_key(dim: int, k: int) -> bool:
+    """Keys of the reference's quadrature table file (quadrature/saveSparseGHWeightMap.h:16-23)."""
+    return (dim <= 13 and k <= _REF_MAX_DEG[dim - 1]) or (14 <= dim <= 20 and k <= 5)
+
+
+def nwspgr(dim: int, k: int, return_index: bool = False, extended=None):
     """nwspgr('GQN', dim, k, sym=1) (nwspgr.m:32-134).
+
+    `extended`: merge and normalise the weights in long double and round once, instead of the reference's plain double
+    sums.  Default: only for keys OUTSIDE the reference's table file -- there is no reference table to be in parity with,
+    and the double sums degrade there (at (24,7) a quadratic psi is integrated to 1e-5 only; see csrc/spgh.cpp).
 
     Returns Z (N x dim, rows sorted lexicographically), w (N, sums to 1, some negative) and, when
     asked, idx (N x dim x 3 int8: level, node index inside the positive half-rule, sign) -- the
     'sigma-point index' that the drop-in contract keeps bit-exact.  The value 0 is shared by every
     odd level; it is canonicalised to (1, 0, 0).
     """
+    if extended is None:
+        extended = not is_reference_table_key(dim, k)
+    wdtype = np.longdouble if extended else np.float64
     minq, maxq = max(0, k - dim), k - 1
     nodes = np.zeros((0, dim))
-    weights = np.zeros(0)
+    weights = np.zeros(0, dtype=wdtype)
     idx = np.zeros((0, dim, 2), dtype=np.int64)
     for q in range(minq, maxq + 1):
         bq = (-1) ** (maxq - q) * math.comb(dim - 1, dim + q - k)
         for midx in spgr_get_seq(dim, dim + q):
-            nn, ww, ii = _kron_prod(midx)
+            nn, ww, ii = _kron_prod(midx, wdtype)
             nodes = np.vstack([nodes, nn])
             weights = np.concatenate([weights, bq * ww])
             idx = np.concatenate([idx, ii], axis=0)
@@ -120,7 +135,7 @@ def nwspgr(dim: int, k: int, return_index: bool = False):
             same = np.all(nodes[1:] == nodes[:-1], axis=1)
             keep = np.concatenate([[True], ~same])
             group = np.cumsum(keep) - 1
-            merged = np.zeros(keep.sum())
+            merged = np.zeros(keep.sum(), dtype=wdtype)
             for j in range(len(weights)):  # sequential sum order of the reference
                 merged[group[j]] += weights[j]
             nodes, weights, idx = nodes[keep], merged, idx[keep]
@@ -139,7 +154,7 @@ def nwspgr(dim: int, k: int, return_index: bool = False):
             sign = np.vstack([sign, s2])
     order = _sortrows(nodes)
     nodes, weights, idx, sign = nodes[order], weights[order], idx[order], sign[order]
-    weights = weights / weights.sum()
+    weights = (weights / weights.sum()).astype(np.float64)
     if not return_index:
         return nodes, weights
     full = np.concatenate([idx, sign[:, :, None]], axis=2)
