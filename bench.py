@@ -111,12 +111,19 @@ def cpu_baseline(chain, seconds):
             "fused_single_pass_value": out["fused"]}
 
 
-def exec_ops(d: int, m: int, full: bool, signed: bool = False) -> int:
-    """fp64 VALU instructions per evaluation of a sum-of-squares psi with m residual rows in the z-space formulation
+def exec_ops(d: int, m: int, full: bool, signed: bool = False, mirror: bool = False) -> float:
+    """fp64 VALU instructions per EVALUATION of a sum-of-squares psi with m residual rows in the z-space formulation
     (DESIGN section 2): u = u0 + H z (m d FMA), psi = sum s_r u_r^2 (m FMA; m more MUL for the signs when some residual
     weight is negative -- `signed`), c = w psi (1), m0 (1); the full pass adds t = c z (d), m1 (d) and the packed upper
-    triangle of M2 (d (d + 1) / 2 FMA)."""
-    ops = m * d + (2 * m if signed else m) + 2
+    triangle of M2 (d (d + 1) / 2 FMA).  `mirror`: the kernel evaluates psi at z and -z from one H z and accumulates the
+    pair once (u(-z) = 2 u0 - u(z): m, second psi: m, c+ and c-: 4) -- the count of one pair is halved."""
+    sq = 2 * m if signed else m
+    if mirror:
+        pair = m * d + sq + m + sq + 4 + 1
+        if full:
+            pair += 2 * d + d * (d + 1) // 2
+        return pair / 2
+    ops = m * d + sq + 2
     if full:
         ops += 2 * d + d * (d + 1) // 2
     return ops
@@ -315,7 +322,8 @@ def main():
             K1, d1, p1, N1 = ctx.sets[1]
             sets_in_launch.append((K1, d1, d1, N1, weights_signed(local["specs"][1])))   # unary: psi = (x - mu0)^T Kinv (x - mu0), m = d
         evals_launch = sum(K * N for K, d, m, N, sg in sets_in_launch)
-        ops_of = lambda d, m, sg: exec_ops(d, m, True, sg)
+        mirror = geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"      # sreg kernels on a symmetric table
+        ops_of = lambda d, m, sg: exec_ops(d, m, True, sg, mirror)
         if geo["variant"] == 3:
             # four waves per factor (moments_split_kernel): psi rows always carry the sign multiply, every wave forms
             # c = w psi and adds the four partial sums of psi (3 adds each)
@@ -351,6 +359,7 @@ def main():
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": f"factors/{world} contiguous, all-reduce [g|D|U] + trial cost (RCCL)" if world > 1 else "none",
                        "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"],
+                       "mirror_pairs": bool(geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"),
                        "fuse_trial": args.fuse_trial},
             "ngd_iters_per_s": args.steps / elapsed,
             # `value` split by pass kind (SURVEY 8(d) defines an evaluation "in one moments pass")

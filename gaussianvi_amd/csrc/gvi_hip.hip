@@ -435,7 +435,7 @@ bool dispatch_sreg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t 
   if (s.kind == KIND_FIXED_PRIOR) {
     switch (s.d) {
       case 6: launch_sreg<6, 6>(a, grid, st, pipe); return true;
-      case 12: launch_sreg<12, 12>(a, grid, st, pipe); return true;
+      case 12: launch_sreg<12, 12>(a, grid, st, false); return true;   // M = 12: the pipelined body does not fit 256 registers
     }
   }
   return false;

@@ -1175,7 +1175,7 @@ __device__ __forceinline__ void split_cost_body(const MomArgs& a, const int k, c
 constexpr int SPLIT_LDS_DOUBLES(int D) { return 256 + 2 * D + 8 + 2 * 4 * 64 + 4 * 16 * 65 + 4 * 2 * SPLIT_LVL2_SLOTS; }
 
 template <int D, int R, bool FULL>
-__global__ __launch_bounds__(256) void moments_split_kernel(MomArgs a) {
+__global__ __launch_bounds__(256, 2) void moments_split_kernel(MomArgs a) {
   extern __shared__ double sm[];
   double* lut = sm;                        // [256]
   double* hs = lut + 256;                  // u0 [4 R] | sgn [4 R]  (rows >= m: 0)
@@ -1492,18 +1492,17 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
 // every residual row of the set has positive weight (sgn = +1): the sign multiply of psi is dropped
 template <int D, int M>
 __device__ __forceinline__ void sreg_pipe_dispatch(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
-  if (a.f.Zm) {
-    if (a.f.all_pos) sreg_pipe_body<D, M, false, true>(a, bx, by, usb, redb);
-    else sreg_pipe_body<D, M, true, true>(a, bx, by, usb, redb);
-  } else {
-    if (a.f.all_pos) sreg_pipe_body<D, M, false, false>(a, bx, by, usb, redb);
-    else sreg_pipe_body<D, M, true, false>(a, bx, by, usb, redb);
-  }
+  // +-pairing only on the unsigned path: with signed residual weights the pair body does not fit two waves per SIMD
+  if (a.f.Zm && a.f.all_pos) sreg_pipe_body<D, M, false, true>(a, bx, by, usb, redb);
+  else if (a.f.all_pos) sreg_pipe_body<D, M, false, false>(a, bx, by, usb, redb);
+  else sreg_pipe_body<D, M, true, false>(a, bx, by, usb, redb);
 }
 
 // PIPE selects the hand-pipelined body for the full pass (the cost pass has its own kernels)
+// (256, 2): two blocks per CU = two waves per SIMD = at most 256 registers per lane INCLUDING AGPRs; without the second
+// argument the compiler may take 256 + spill AGPRs and silently halve the occupancy
 template <int D, int M, bool FULL, bool PIPE = false>
-__global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
+__global__ __launch_bounds__(256, 2) void moments_sreg_kernel(MomArgs a) {
   __shared__ double us[4 * 2 * M];
   __shared__ double red[4 * 16 * 65];
   if constexpr (FULL && PIPE) sreg_pipe_dispatch<D, M>(a, blockIdx.x, blockIdx.y, us, red);
@@ -1514,7 +1513,7 @@ __global__ __launch_bounds__(256) void moments_sreg_kernel(MomArgs a) {
 // independent, so fusing them removes one dependent-launch boundary (~6 us on this part) and lets the small set's
 // blocks fill the tail of the large one.  Blocks [0, nb0) belong to set 0 (x fastest), the rest to set 1.
 template <int D0, int M0, int D1, int M1, bool FULL, bool PIPE = false>
-__global__ __launch_bounds__(256) void moments_sreg_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
+__global__ __launch_bounds__(256, 2) void moments_sreg_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
   constexpr int MM = M0 > M1 ? M0 : M1;
   __shared__ double us[4 * 2 * MM];
   __shared__ double red[4 * 16 * 65];
