@@ -14,4 +14,16 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // (vmcnt); everything the phases exchange goes through LDS.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Publish a scalar result to host-mapped (fine-grained, uncached) memory: {value, sequence} go out in ONE 16-byte store, so
+// the host, which spins on the sequence word, can never see a new sequence with an old value -- without the system-scope
+// fence a two-store protocol needs.  (__threadfence_system() writes back the whole L2: behind a kernel that has just
+// written megabytes of results it cost ~50 us, measured on the fused epilogue tail.)
+__device__ __forceinline__ void publish_to_host(double* host_out, double value, double seq) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 v;
+  v.x = value;
+  v.y = seq;
+  __builtin_nontemporal_store(v, (d2*)host_out);
+}
+
 }  // namespace gvi

@@ -176,11 +176,12 @@ struct gvi_ctx {
   bool solve_pending[2] = {false, false};
   DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
   DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
+  DevMem epi_counter;                 // two-level arrival counters of epilogue_all_kernel's tail
   // trial precision formed inside the first BCR pass of the next run_seg call (see SegArgs::mix*)
   struct Mix { const double* VD = nullptr; const double* VU = nullptr; double* outD = nullptr; double* outU = nullptr; double step = 0.0; } mix;
   hipStream_t chain_stream = nullptr; // stream of the chain launches being queued (null: ctx->stream)
   int chain_ws = 0;
-  double* host_slot = nullptr;        // host-mapped {cost_sum, half_logdet, sequence}
+  double* host_slot = nullptr;        // host-mapped {cost value, sequence}: one 16-byte device store (publish_to_host)
   // kernels whose dynamic-LDS limit was raised on THIS context's device (the attribute is per device, and a
   // process may hold contexts on several devices)
   std::set<const void*> lds_attr_done;
@@ -1568,12 +1569,26 @@ static EpiList make_epi_list(gvi_ctx* ctx, int full, int* dmax_out) {
   return L;
 }
 
-static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full) {
+// publish_slot >= 0: the launch also sums the factor costs and publishes the cost of NGD slot `publish_slot` (EpiTail)
+static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1) {
   int dmax = 0;
   const EpiList L = make_epi_list(ctx, full, &dmax);
-  const size_t lds = (size_t)(npairs(dmax) + 2 * dmax * dmax) * 8;
+  const size_t lds = std::max<size_t>((size_t)(npairs(dmax) + 2 * dmax * dmax) * 8, 256 * 8);
   if (L.koff[L.nsets] == 0) return GVI_OK;
-  hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L);
+  EpiTail tail;
+  tail.on = 0; tail.acc = nullptr; tail.half_logdet = nullptr; tail.host_out = nullptr; tail.seq = 0.0; tail.counter = nullptr;
+  if (publish_slot >= 0) {
+    const size_t need = (size_t)128 * (2 + (size_t)L.koff[L.nsets] / EPI_GROUP);
+    if (ctx->epi_counter.bytes < need) {
+      HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCK(ctx, ctx->epi_counter.ensure(need));
+      HIPCK(ctx, hipMemsetAsync(ctx->epi_counter.p, 0, need, ctx->stream));
+    }
+    ctx->seq += 1.0;
+    tail.on = 1; tail.acc = ctx->ngd.exch1.d(); tail.half_logdet = ctx->ngd.hld[publish_slot].d();
+    tail.host_out = ctx->host_slot_dev; tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
+  }
+  hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L, tail);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -1688,7 +1703,7 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
   bool seen = false;
   const auto t0 = std::chrono::steady_clock::now();
   for (long spins = 0;; ++spins) {
-    if (slot[2] == ctx->seq) { seen = true; break; }
+    if (slot[1] == ctx->seq) { seen = true; break; }
     cpu_relax();
     if ((spins & 1023) == 1023 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(ctx->spin_ms)) break;
@@ -1697,7 +1712,7 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
     // long passes (config 5: seconds per pass): sleep-poll the word and, every millisecond, the stream itself, so a
     // device fault or a drained stream without a publish ends the wait with an error instead of spinning
     for (long polls = 0;; ++polls) {
-      if (slot[2] == ctx->seq) { seen = true; break; }
+      if (slot[1] == ctx->seq) { seen = true; break; }
       std::this_thread::sleep_for(std::chrono::microseconds(20));
       if ((polls & 63) == 63) {
         const hipError_t q = hipStreamQuery(ctx->stream);
@@ -1705,11 +1720,11 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
         if (q != hipErrorNotReady) return fail(ctx, GVI_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
       }
     }
-    if (!seen && slot[2] != ctx->seq)
+    if (!seen && slot[1] != ctx->seq)
       return fail(ctx, GVI_ERR_STATE, "cost publish did not arrive (sequence word stale after the stream drained)");
   }
   __sync_synchronize();
-  const double v = ctx->host_slot[0] + ctx->host_slot[1];     // cost_value = sum of factor costs + 1/2 log det
+  const double v = ctx->host_slot[0];                          // cost_value = sum of factor costs + 1/2 log det (added on the device)
   g.cost[i] = v;
   g.cost_valid[i] = true;
   if (out) *out = v;
@@ -1842,11 +1857,11 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
   return GVI_OK;
 }
 
-static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot) {
+static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot, int publish_slot = -1) {
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
   GVICK(ngd_prep_all(ctx, slot));
   GVICK(ngd_moments_launch(ctx, slot, 1));
-  return ngd_epilogue_all(ctx, 1);
+  return ngd_epilogue_all(ctx, 1, publish_slot);
 }
 
 // ordered assemble of the per-factor results into gradient buffer `gb`
@@ -2060,10 +2075,12 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
       // Fused form: ONE full moments pass at the trial point serves both the trial cost (its m0 column)
       // and -- if the trial is accepted -- the next iteration's gradients.  Same numbers, one psi pass
       // less per accepted iteration; a rejected first trial wasted the moment accumulation.
-      GVICK(ngd_moments_full(ctx, t));
-      hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, t), g.exch1.d());
-      HIPCK(ctx, hipGetLastError());
-      GVICK(ngd_cost_publish(ctx, t));
+      if (ctx->sets.empty()) {
+        HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
+        GVICK(ngd_cost_publish(ctx, t));
+      } else {
+        GVICK(ngd_moments_full(ctx, t, t));           // epilogue + ordered cost sum + publish in one launch
+      }
       GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
       GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
     } else {

@@ -744,10 +744,7 @@ __global__ __launch_bounds__(256) void trial_kernel(int64_t nmu, int64_t nlam, d
 // publish the (all-reduced) cost sum and the log-det into host-mapped memory: out = {cost_sum, hld}
 __global__ void publish_kernel(const double* cost_sum, const double* half_logdet, double* host_out, double seq) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    host_out[0] = cost_sum[0];
-    host_out[1] = half_logdet[0];
-    __threadfence_system();
-    host_out[2] = seq;               // the host spins on this word: payload first, then the sequence
+    publish_to_host(host_out, cost_sum[0] + half_logdet[0], seq);   // cost_value = sum of factor costs + 1/2 log det
   }
 }
 

@@ -1721,7 +1721,8 @@ struct EpiArgs {
   double* E_xxphi;         // [K][d][d] or null
 };
 
-__device__ inline void epilogue_body(const EpiArgs& a, int k, double* sm) {
+// returns the factor's cost E[psi] / T_k (wave-uniform)
+__device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
   const FactorDev& f = a.f;
   const int d = f.d, dd = d * d, lane = threadIdx.x;
   const int npo = a.full ? npairs(d) : 1;
@@ -1737,11 +1738,12 @@ __device__ inline void epilogue_body(const EpiArgs& a, int k, double* sm) {
   wave_lds_sync();
   const double m0 = Ms[0];
   const double Tk = f.temperature[k];
+  const double costk = m0 / Tk;
   if (lane == 0) {
     if (a.Ephi) a.Ephi[k] = m0;
-    if (a.cost) a.cost[k] = m0 / Tk;
+    if (a.cost) a.cost[k] = costk;
   }
-  if (!a.full) return;
+  if (!a.full) return costk;
   for (int e = lane; e < dd; e += 64) {
     const int i = e / d, j = e % d;
     M2[e] = i <= j ? Ms[pair_index(d, i, j)] : Ms[pair_index(d, j, i)];
@@ -1799,6 +1801,7 @@ __device__ inline void epilogue_body(const EpiArgs& a, int k, double* sm) {
       a.E_xxphi[(size_t)k * dd + e] = s;
     }
   }
+  return costk;
 }
 
 __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
@@ -1864,19 +1867,97 @@ __global__ __launch_bounds__(256) void cost_tail_kernel(EpiList L, double* acc, 
     *counter = 0u;                       // ready for the next launch (stream-ordered)
     acc[0] = total;
     if (host_out) {
-      host_out[0] = total;
-      host_out[1] = half_logdet[0];
-      __threadfence_system();
-      host_out[2] = seq;               // the host spins on this word: payload first, then the sequence
+      publish_to_host(host_out, total + half_logdet[0], seq);
     }
   }
 }
 
-__global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L) {
+// Optional tail of the fused-trial iteration: the block that finishes LAST sums the factor costs of every set (the
+// association of cost_sum_all_kernel: 256 strided partial sums, then a fixed 256-leaf tree per set -- bit-identical) and
+// publishes {cost sum, half log-det, sequence} to host-mapped memory.  Replaces two dependent launches
+// (cost_sum_all_kernel, publish_kernel) behind the epilogue.
+constexpr int EPI_GROUP = 64;
+struct EpiTail {
+  int on;
+  double* acc;                 // [1] cost sum
+  const double* half_logdet;   // [1]
+  double* host_out;            // host-mapped {cost_sum, half_logdet, sequence} or null
+  double seq;
+  unsigned* counter;           // [32 (1 + ceil(blocks / EPI_GROUP))] arrival counters, 128 B apart, zero before the launch
+};
+
+__global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tail) {
   extern __shared__ double sm[];
   int si = 0;
   while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
-  epilogue_body(L.e[si], (int)blockIdx.x - L.koff[si], sm);
+  const int kf = (int)blockIdx.x - L.koff[si];
+  const double costk = epilogue_body(L.e[si], kf, sm);
+  if (!tail.on) return;
+  // Cross-block hand-over WITHOUT device-scope fences: on this multi-XCD part a release fence writes the XCD's whole L2
+  // back (the epilogue has just dirtied megabytes: 2049 blocks x __threadfence() cost ~45 us, measured).  Only the
+  // factor's cost has to be seen by the last block, so it is stored write-through at agent scope, the wave waits for
+  // that one store (vmcnt), and the arrival counters are relaxed agent-scope atomics.  Everything else the epilogue
+  // wrote is consumed by later launches (ordinary end-of-kernel release).
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(L.e[si].cost + kf, costk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // two-level arrival count: thousands of atomics on ONE address serialise in L2; groups of EPI_GROUP blocks count on
+    // their own 128-byte-spaced word, the last of each group counts on the top word
+    const unsigned grp = blockIdx.x / EPI_GROUP, ngrp = (gridDim.x + EPI_GROUP - 1) / EPI_GROUP;
+    const unsigned in_grp = grp + 1 < ngrp ? (unsigned)EPI_GROUP : gridDim.x - grp * EPI_GROUP;
+    unsigned* gc = tail.counter + 32u * (1u + grp);
+    int l = 0;
+    if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+      __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+      l = __hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
+    }
+    last = l;
+  }
+  wave_lds_sync();
+  if (!last) return;
+  const int lane = threadIdx.x;
+  double* sh = sm;                                      // [256]
+  double total = 0.0;
+  for (int s2 = 0; s2 < L.nsets; ++s2) {
+    const double* cost = L.e[s2].cost;
+    const int K = L.e[s2].f.K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                       // virtual thread v = lane + 64 j of the 256-thread kernel
+      double s = 0.0;
+      for (int k0 = lane + 64 * j; k0 < K; k0 += 8 * 256) {
+        // device-scope relaxed loads (the other blocks' stores, made visible by their fences): eight in flight, then the
+        // ordered sum (x + 0.0 == x)
+        double p[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = k0 + q * 256;
+          p[q] = k < K ? __hip_atomic_load(cost + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += p[q];
+      }
+      sh[lane + 64 * j] = s;
+    }
+    wave_lds_sync();
+    sh[lane] += sh[lane + 128]; sh[lane + 64] += sh[lane + 192];     // w = 128
+    wave_lds_sync();
+    sh[lane] += sh[lane + 64];                                        // w = 64
+    wave_lds_sync();
+    for (int w = 32; w > 0; w >>= 1) {
+      if (lane < w) sh[lane] += sh[lane + w];
+      wave_lds_sync();
+    }
+    total += sh[0];
+    wave_lds_sync();
+  }
+  if (lane == 0) {
+    __hip_atomic_store(tail.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    tail.acc[0] = total;
+    if (tail.host_out) {
+      publish_to_host(tail.host_out, total + tail.half_logdet[0], tail.seq);
+    }
+  }
 }
 
 // X[k][a][i] = mu_a + sum_b S_ab z_b[i]  (reference CUDA-path layout [factor][dim][point])
