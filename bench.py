@@ -194,7 +194,7 @@ def main():
             rccl_ranks = int(round(float(probe.item())))
 
     from gaussianvi_amd import api, synthetic
-    from gaussianvi_amd.dist import HipEngine, ShardedNGD, shard_chain
+    from gaussianvi_amd.dist import shard_chain, torch_allgather
 
     if args.scaling == "weak" and world > 1 and args.config == "c3":
         args.config = f"c3x{world}"
@@ -203,9 +203,18 @@ def main():
     ctx, ids = api.context_for_chain(local, device=local_rank)
     ctx.set_variant(args.variant)
     ctx.ngd_set_mode(True, args.fuse_trial)
-    engine = HipEngine(ctx, local_rank)
-    ngd = ShardedNGD(engine, world=world)
-    ngd.group_forced = use_pg and world == 1
+    # N > 1 (or a forced size-1 group): both exchange steps of a pass run INSIDE the library on its own stream
+    # (include/gvi_hip.h, gvi_dist_init_*): RCCL all-gathers; the rehearsal on one GPU goes through a gloo callback
+    sharded = use_pg and (world > 1 or os.environ.get("GVI_FORCE_ALLREDUCE") == "1")
+    if sharded:
+        if rehearsal:
+            ctx.dist_init_callback(rank, world, torch_allgather(local_rank))
+        else:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(api.dist_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            ctx.dist_init_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
     ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
     # HIP events around every 8th dominant launch (a pair costs ~14 us of queue gaps); every launch for the seconds-long c5 passes
     ctx.profile_enable(1 if big else 3)
@@ -216,14 +225,12 @@ def main():
         torch.cuda.synchronize()
 
     evals_pass = sum(K * N for (K, d, p, N) in ctx.sets)          # local, per pass over every set
-    # one process: the whole iteration (backtracking loop included) is one C-ABI call; sharded: the
-    # Python driver interleaves the two all-reduces between the *_local / *_finish halves
-    single = world == 1 and not ngd.group_forced
-    step_fn = (lambda: ctx.ngd_step(0.55, 10)) if single else (lambda: ngd.step(0.55, 10))
+    # the whole iteration (backtracking loop and, when sharded, both exchanges included) is one C-ABI call
+    single = not sharded
+    step_fn = lambda: ctx.ngd_step(0.55, 10)
 
     def restart():
         ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
-        ngd.reset()
 
     # one-time costs (buffer growth on the first cost pass, side stream / event creation, kernel attribute calls, the
     # cold Jacobi start) are primed outside the contract's W warm-up steps as well, so a small W does not time them
@@ -357,7 +364,9 @@ def main():
                                    f"T={chain['T']} n={chain['n']}, +{chain['T']} unary d={chain['n']} factors; one step = one device-resident NGD iteration "
                                    f"(state re-initialised inside the timed region every {args.restart_every} steps)",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
-                       "sharding": f"factors/{world} contiguous, all-reduce [g|D|U] + trial cost (RCCL)" if world > 1 else "none",
+                       "sharding": (f"factors/{world} contiguous; per pass: all-gather of each rank's state records of [g|D|U] "
+                                    f"({ctx.dist_info()['records_per_rank']} states per rank, folded in rank order) + all-gather of the partial "
+                                    f"cost sums, issued inside the library ({'gloo callback (rehearsal)' if rehearsal else 'RCCL'})") if sharded else "none",
                        "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"],
                        "mirror_pairs": bool(geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"),
                        "fuse_trial": args.fuse_trial},
@@ -399,7 +408,7 @@ def main():
         if world > 1:
             # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU kernel times of this round
             # (profiles/): factor work W shards, the chain recursions R are replicated, two exchanges X are added.
-            W, R, X = 0.165, 0.085, 0.040                     # ms, DESIGN section 5
+            W, R, X = 0.120, 0.100, 0.040                     # ms, DESIGN section 5 (profiles/r02_c_kernel_stats.csv)
             out["strong_scaling_model"] = {"W_ms_sharded": W, "R_ms_replicated": R, "X_ms_exchange": X,
                                            "expected_speedup_at_n": (W + R) / (W / world + R + X),
                                            "note": "t(N) = W / N + R + X; the ceiling as N grows is (W + R) / (R + X)"}

@@ -12,6 +12,8 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_int8_p = C.POINTER(C.c_int8)
 c_void_pp = C.POINTER(C.c_void_p)
+# gvi_allgather_fn: int (*)(void* user, const void* send, void* recv, int64_t count, void* hip_stream)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 # name -> argtypes; every function returns int status except the two string getters.
 # This table is also what tests/test_abi.py checks against include/gvi_hip.h.
@@ -74,6 +76,10 @@ SIGNATURES = {
     "gvi_ngd_trial_local": [C.c_void_p, C.c_double],
     "gvi_ngd_trial_finish": [C.c_void_p, c_double_p],
     "gvi_ngd_exchange": [C.c_void_p, C.c_int, c_void_pp, C.POINTER(C.c_int64)],
+    "gvi_dist_unique_id": [C.c_void_p],
+    "gvi_dist_init_rccl": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "gvi_dist_init_callback": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "gvi_dist_info": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "gvi_ngd_get_state": [C.c_void_p] + [C.c_void_p] * 5,
     "gvi_ngd_get_gradients": [C.c_void_p] + [C.c_void_p] * 6,
     "gvi_profile_enable": [C.c_void_p, C.c_int],

@@ -79,6 +79,14 @@ def table_file_write(path: str, keys):
     _ck_global(lib, lib.gvi_table_file_write(path.encode(), len(keys), _p(dims), _p(degs)))
 
 
+def dist_unique_id() -> bytes:
+    """ncclUniqueId (128 bytes) for gvi_dist_init_rccl; call on rank 0 and distribute."""
+    lib = _lib.load()
+    buf = C.create_string_buffer(128)
+    _ck_global(lib, lib.gvi_dist_unique_id(buf))
+    return buf.raw
+
+
 class Context:
     def __init__(self, device: int = 0, dtype: int = GVI_F64):
         self.lib = _lib.load()
@@ -369,6 +377,29 @@ class Context:
         self._ck(self.lib.gvi_prox_step(self.h, float(step_size_base), int(max_backtrack), C.byref(c0), C.byref(ok),
                                         C.byref(c1), C.byref(nt)))
         return dict(cost_iter=c0.value, decreased=bool(ok.value), new_cost=c1.value, ntrials=nt.value)
+
+    # ---- sharded factors: exchange inside the library ----
+    def dist_init_rccl(self, rank, world, unique_id: bytes):
+        assert len(unique_id) == 128
+        self._ck(self.lib.gvi_dist_init_rccl(self.h, int(rank), int(world), C.c_char_p(unique_id)))
+
+    def dist_init_callback(self, rank, world, fn):
+        """fn(send_ptr, recv_ptr, count, stream_ptr) -> None (raise on failure): all-gather of `count` doubles per rank."""
+        def trampoline(user, send, recv, count, stream):
+            try:
+                fn(send, recv, int(count), stream)
+                return 0
+            except Exception:                      # a Python exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._allgather_cb = _lib.ALLGATHER_FN(trampoline)      # keep alive as long as the context
+        self._ck(self.lib.gvi_dist_init_callback(self.h, int(rank), int(world), C.cast(self._allgather_cb, C.c_void_p), None))
+
+    def dist_info(self):
+        r, w, n = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.gvi_dist_info(self.h, C.byref(r), C.byref(w), C.byref(n)))
+        return dict(rank=r.value, world=w.value, records_per_rank=n.value)
 
     def set_variant(self, v):
         self._ck(self.lib.gvi_set_variant(self.h, v))

@@ -2,6 +2,7 @@
 #include "../../include/gvi_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -181,6 +182,21 @@ struct gvi_ctx {
   struct Mix { const double* VD = nullptr; const double* VU = nullptr; double* outD = nullptr; double* outU = nullptr; double step = 0.0; } mix;
   hipStream_t chain_stream = nullptr; // stream of the chain launches being queued (null: ctx->stream)
   int chain_ws = 0;
+  // ---- sharded factors (one process per GPU): the exchange steps run inside the library, on the context stream ----
+  struct Dist {
+    int rank = 0, world = 1;
+    // all-gather of `count` doubles per rank: send [count] -> recv [world][count], ordered after / before the work on `stream`
+    gvi_allgather_fn fn = nullptr;       // host-supplied collective (tests: gloo; hosts with their own transport: MPI ...)
+    void* user = nullptr;
+    void* rccl_lib = nullptr;            // dlopen handle; the default transport
+    void* comm = nullptr;                // ncclComm_t
+    int (*ncclAllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*ncclCommDestroy)(void*) = nullptr;
+    DevMem send, recv, ranges;           // packed state records; [world][2] state ranges (device); cost scratch
+    std::vector<int32_t> lo, hi;         // owned state range [lo, hi] of every rank (records sent)
+    int maxlen = 0;
+    bool ranges_valid = false;
+  } dist;
   double* host_slot = nullptr;        // host-mapped {cost value, sequence}: one 16-byte device store (publish_to_host)
   // kernels whose dynamic-LDS limit was raised on THIS context's device (the attribute is per device, and a
   // process may hold contexts on several devices)
@@ -928,6 +944,7 @@ gvi_status gvi_ctx_destroy(gvi_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->sets.clear();
+  if (ctx->dist.comm && ctx->dist.ncclCommDestroy) (void)ctx->dist.ncclCommDestroy(ctx->dist.comm);
   if (ctx->fork) (void)hipEventDestroy(ctx->fork);
   if (ctx->side) (void)hipStreamSynchronize(ctx->side);
   if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
@@ -1005,6 +1022,7 @@ gvi_status gvi_chain_set(gvi_ctx* ctx, int T, int n) {
   ctx->sets.clear();
   ctx->ngd.ready = false;
   ctx->ngd.have_trial = false;
+  ctx->dist.ranges_valid = false;
   return GVI_OK;
 }
 
@@ -1133,6 +1151,7 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   HIPCK(ctx, hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
   HIPCK(ctx, hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
   ctx->sets.push_back(std::move(s));
+  ctx->dist.ranges_valid = false;
   ctx->ngd.ready = false;
   if (set_id) *set_id = (int)ctx->sets.size() - 1;
   return GVI_OK;
@@ -1736,6 +1755,94 @@ static gvi_status ngd_cost_finish(gvi_ctx* ctx, int i, double* out) {
   return ngd_cost_wait(ctx, i, out);
 }
 
+// ---- sharded factors: the two exchange steps (no-ops in a single process) ----
+static bool dist_on(const gvi_ctx* ctx) { return ctx->dist.world > 1 || ctx->dist.fn || ctx->dist.comm; }
+
+static gvi_status dist_allgather(gvi_ctx* ctx, const void* send, void* recv, int64_t count) {
+  gvi_ctx::Dist& d = ctx->dist;
+  if (d.fn) {
+    if (d.fn(d.user, send, recv, count, (void*)ctx->stream) != 0) return fail(ctx, GVI_ERR_HIP, "all-gather callback failed");
+    return GVI_OK;
+  }
+  if (!d.comm) return fail(ctx, GVI_ERR_STATE, "sharded context without a transport: call gvi_dist_init_rccl / _callback");
+  const int rc = d.ncclAllGather(send, recv, (size_t)count, 8 /* ncclFloat64 */, d.comm, ctx->stream);
+  if (rc != 0) return fail(ctx, GVI_ERR_HIP, "ncclAllGather failed with code " + std::to_string(rc));
+  return GVI_OK;
+}
+
+// state range [lo, hi] this rank's factors touch; gathered once per problem definition over all ranks
+static gvi_status dist_ranges(gvi_ctx* ctx) {
+  gvi_ctx::Dist& d = ctx->dist;
+  if (d.ranges_valid) return GVI_OK;
+  int lo = ctx->T, hi = -1;
+  for (auto& s : ctx->sets)
+    for (int k = 0; k < s->K; ++k) {
+      lo = std::min(lo, (int)s->start[k]);
+      hi = std::max(hi, (int)s->start[k] + (s->d == 2 * ctx->n ? 1 : 0));
+    }
+  if (hi < lo) { lo = 0; hi = -1; }                         // a rank without factors sends nothing
+  const int W = d.world;
+  HIPCK(ctx, d.ranges.ensure((size_t)(3 * W + 4) * 8));     // [int range table | own range | cost parts]
+  double mine[2] = {(double)lo, (double)hi};
+  double* dsend = d.ranges.d() + 2 * W;
+  HIPCK(ctx, hipMemcpyAsync(dsend, mine, 16, hipMemcpyHostToDevice, ctx->stream));
+  HIPCK(ctx, hipStreamSynchronize(ctx->stream));            // `mine` is a stack buffer
+  HIPCK(ctx, d.recv.ensure((size_t)2 * W * 8));
+  GVICK(dist_allgather(ctx, dsend, d.recv.p, 2));
+  std::vector<double> all(2 * W);
+  HIPCK(ctx, hipMemcpyAsync(all.data(), d.recv.p, (size_t)2 * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+  d.lo.resize(W); d.hi.resize(W);
+  std::vector<int32_t> packed(2 * W);
+  d.maxlen = 1;
+  for (int r = 0; r < W; ++r) {
+    d.lo[r] = (int32_t)all[2 * r]; d.hi[r] = (int32_t)all[2 * r + 1];
+    packed[2 * r] = d.lo[r]; packed[2 * r + 1] = d.hi[r];
+    d.maxlen = std::max(d.maxlen, d.hi[r] - d.lo[r] + 1);
+  }
+  HIPCK(ctx, hipMemcpyAsync(d.ranges.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t per = (size_t)ctx->n + 2 * nn_(ctx);
+  HIPCK(ctx, d.send.ensure((size_t)d.maxlen * per * 8));
+  HIPCK(ctx, d.recv.ensure(std::max<size_t>((size_t)W * d.maxlen * per * 8, (size_t)2 * W * 8)));
+  d.ranges_valid = true;
+  return GVI_OK;
+}
+
+// exchange 0 on gradient buffer gb: pack own records -> all-gather -> fold in rank order back into exch0[gb]
+static gvi_status dist_exchange0(gvi_ctx* ctx, int gb) {
+  if (!dist_on(ctx)) return GVI_OK;
+  GVICK(dist_ranges(ctx));
+  gvi_ctx::Dist& d = ctx->dist;
+  const size_t T = ctx->T, n = ctx->n, nn = n * n, per = n + 2 * nn;
+  double* eg = ctx->ngd.exch0[gb].d();
+  double* eD = eg + T * n;
+  double* eU = eD + T * nn;
+  const int lo = d.lo[d.rank], len = d.hi[d.rank] - d.lo[d.rank] + 1;
+  const int64_t np = (int64_t)d.maxlen * per;
+  hipLaunchKernelGGL(dist_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, lo, len, d.maxlen,
+                     eg, eD, eU, d.send.d());
+  HIPCK(ctx, hipGetLastError());
+  GVICK(dist_allgather(ctx, d.send.p, d.recv.p, np));
+  const int64_t nf = (int64_t)T * per;
+  hipLaunchKernelGGL(dist_fold_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, d.world, d.maxlen,
+                     (const int32_t*)d.ranges.p, d.recv.d(), eg, eD, eU);
+  HIPCK(ctx, hipGetLastError());
+  return GVI_OK;
+}
+
+// exchange 1: the ranks' partial cost sums (exch1[0]) -> their ordered total (exch1[0]); recv is reused after exchange 0
+static gvi_status dist_exchange1(gvi_ctx* ctx) {
+  if (!dist_on(ctx)) return GVI_OK;
+  GVICK(dist_ranges(ctx));
+  gvi_ctx::Dist& d = ctx->dist;
+  double* parts = d.ranges.d() + 2 * d.world + 2;           // [world] behind the range table
+  GVICK(dist_allgather(ctx, ctx->ngd.exch1.p, parts, 1));
+  hipLaunchKernelGGL(dist_cost_fold_kernel, dim3(1), dim3(64), 0, ctx->stream, d.world, parts, ctx->ngd.exch1.d());
+  HIPCK(ctx, hipGetLastError());
+  return GVI_OK;
+}
+
 gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const double* U) {
   if (!ctx) return GVI_ERR_ARG;
   if (ctx->T < 1) return fail(ctx, GVI_ERR_STATE, "call gvi_chain_set first");
@@ -1777,6 +1884,7 @@ gvi_status gvi_ngd_cost(gvi_ctx* ctx, double* cost) {
   NgdState& g = ctx->ngd;
   if (!g.cost_valid[g.cur]) {
     GVICK(ngd_cost_local(ctx, g.cur));
+    GVICK(dist_exchange1(ctx));
     GVICK(ngd_cost_finish(ctx, g.cur, nullptr));
   }
   if (cost) *cost = g.cost[g.cur];
@@ -1938,6 +2046,7 @@ gvi_status gvi_ngd_gradients_finish(gvi_ctx* ctx) {
 
 gvi_status gvi_ngd_gradients(gvi_ctx* ctx) {
   GVICK(gvi_ngd_gradients_local(ctx));
+  GVICK(dist_exchange0(ctx, ctx->ngd.gcur));
   return gvi_ngd_gradients_finish(ctx);
 }
 
@@ -1999,6 +2108,7 @@ gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost) {
 
 gvi_status gvi_ngd_trial(gvi_ctx* ctx, double step, double* new_cost) {
   GVICK(gvi_ngd_trial_local(ctx, step));
+  GVICK(dist_exchange1(ctx));
   return gvi_ngd_trial_finish(ctx, new_cost);
 }
 
@@ -2075,22 +2185,37 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
       // Fused form: ONE full moments pass at the trial point serves both the trial cost (its m0 column)
       // and -- if the trial is accepted -- the next iteration's gradients.  Same numbers, one psi pass
       // less per accepted iteration; a rejected first trial wasted the moment accumulation.
-      if (ctx->sets.empty()) {
+      if (dist_on(ctx)) {
+        // sharded: the local cost sum and the local [g | D | U] go through the two exchanges before publish / solve
+        GVICK(ngd_moments_full(ctx, t));
+        hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, t), g.exch1.d());
+        HIPCK(ctx, hipGetLastError());
+        GVICK(dist_exchange1(ctx));
+        GVICK(ngd_cost_publish(ctx, t));
+      } else if (ctx->sets.empty()) {
         HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
         GVICK(ngd_cost_publish(ctx, t));
       } else {
         GVICK(ngd_moments_full(ctx, t, t));           // epilogue + ordered cost sum + publish in one launch
       }
       GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
+      GVICK(dist_exchange0(ctx, 1 - g.gcur));
       GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
     } else {
-      GVICK(ngd_cost_local(ctx, t, true));          // cost tail publishes in the same launch
+      if (dist_on(ctx)) {
+        GVICK(ngd_cost_local(ctx, t, false));
+        GVICK(dist_exchange1(ctx));
+        GVICK(ngd_cost_publish(ctx, t));
+      } else {
+        GVICK(ngd_cost_local(ctx, t, true));        // cost tail publishes in the same launch
+      }
       // Speculation: the first trial is accepted in the common case, and then the next iteration starts
       // with the gradients at exactly this trial state.  Queue them BEHIND the publish, into the other
       // gradient buffer, so the device never idles while the host reads the cost and decides.  A rejected
       // trial just leaves that buffer unused (same numbers either way).
       if (spec) {
         GVICK(ngd_grad_local(ctx, t, 1 - g.gcur));
+        GVICK(dist_exchange0(ctx, 1 - g.gcur));
         GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
       }
     }
@@ -2213,6 +2338,84 @@ gvi_status gvi_ngd_set_mode(gvi_ctx* ctx, int speculate, int fuse_trial) {
   ctx->speculate = speculate != 0;
   ctx->fuse_trial = fuse_trial;
   ctx->last_first_accepted = true;
+  return GVI_OK;
+}
+
+// ---- transports of the exchange ----
+namespace {
+struct RcclApi {
+  struct Id128 { char b[128]; };       // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+};
+bool load_rccl(RcclApi& r, std::string& err) {
+  const char* names[] = {getenv("GVI_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* nm : names) {
+    if (!nm || !*nm) continue;
+    r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (r.lib) break;
+  }
+  if (!r.lib) { err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return false; }
+  r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+  r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { err = "librccl lacks an expected symbol"; return false; }
+  return true;
+}
+}  // namespace
+
+gvi_status gvi_dist_unique_id(void* id128) {
+  if (!id128) return fail(nullptr, GVI_ERR_ARG, "id128 is NULL");
+  RcclApi r;
+  std::string err;
+  if (!load_rccl(r, err)) return fail(nullptr, GVI_ERR_HIP, err);
+  const int rc = r.GetUniqueId(id128);
+  return rc == 0 ? GVI_OK : fail(nullptr, GVI_ERR_HIP, "ncclGetUniqueId failed with code " + std::to_string(rc));
+}
+
+gvi_status gvi_dist_init_rccl(gvi_ctx* ctx, int rank, int world, const void* id128) {
+  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return fail(ctx, GVI_ERR_ARG, "bad rank / world / id");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  RcclApi r;
+  std::string err;
+  if (!load_rccl(r, err)) return fail(ctx, GVI_ERR_HIP, err);
+  RcclApi::Id128 id;
+  memcpy(id.b, id128, 128);
+  void* comm = nullptr;
+  const int rc = r.CommInitRank(&comm, world, id, rank);
+  if (rc != 0 || !comm) return fail(ctx, GVI_ERR_HIP, "ncclCommInitRank failed with code " + std::to_string(rc));
+  gvi_ctx::Dist& d = ctx->dist;
+  if (d.comm && d.ncclCommDestroy) d.ncclCommDestroy(d.comm);
+  d.rank = rank; d.world = world; d.fn = nullptr; d.user = nullptr;
+  d.rccl_lib = r.lib; d.comm = comm; d.ncclAllGather = r.AllGather; d.ncclCommDestroy = r.CommDestroy;
+  d.ranges_valid = false;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_dist_init_callback(gvi_ctx* ctx, int rank, int world, gvi_allgather_fn fn, void* user) {
+  if (!ctx || !fn || world < 1 || rank < 0 || rank >= world) return fail(ctx, GVI_ERR_ARG, "bad rank / world / callback");
+  GVICK(sync(ctx));
+  gvi_ctx::Dist& d = ctx->dist;
+  if (d.comm && d.ncclCommDestroy) { d.ncclCommDestroy(d.comm); d.comm = nullptr; }
+  d.rank = rank; d.world = world; d.fn = fn; d.user = user;
+  d.ranges_valid = false;
+  ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
+  ctx->ngd.grad_valid = false;
+  return GVI_OK;
+}
+
+gvi_status gvi_dist_info(const gvi_ctx* ctx, int* rank, int* world, int* records_per_rank) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (rank) *rank = ctx->dist.rank;
+  if (world) *world = ctx->dist.world;
+  if (records_per_rank) *records_per_rank = ctx->dist.ranges_valid ? ctx->dist.maxlen : 0;
   return GVI_OK;
 }
 

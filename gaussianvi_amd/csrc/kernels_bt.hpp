@@ -741,6 +741,49 @@ __global__ __launch_bounds__(256) void trial_kernel(int64_t nmu, int64_t nlam, d
   }
 }
 
+// ---- sharded factors: exchange 0 as an all-gather of state records ----
+// pack: the rank's state range [lo, lo + len) of [g | D | U] -> records [maxlen][n + 2 n^2] (zero padded)
+__global__ __launch_bounds__(256) void dist_pack_kernel(int T, int n, int lo, int len, int maxlen, const double* __restrict__ g,
+                                                        const double* __restrict__ D, const double* __restrict__ U,
+                                                        double* __restrict__ rec) {
+  const int nn = n * n, per = n + 2 * nn;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)maxlen * per) return;
+  const int j = (int)(gid / per), e = (int)(gid % per), t = lo + j;
+  double v = 0.0;
+  if (j < len && t < T) {
+    if (e < n) v = g[(size_t)t * n + e];
+    else if (e < n + nn) v = D[(size_t)t * nn + (e - n)];
+    else if (t < T - 1) v = U[(size_t)t * nn + (e - n - nn)];
+  }
+  rec[gid] = v;
+}
+// fold: every state sums the records of the ranks whose range holds it, in rank order -> full [g | D | U]
+__global__ __launch_bounds__(256) void dist_fold_kernel(int T, int n, int world, int maxlen, const int32_t* __restrict__ range,
+                                                        const double* __restrict__ rec, double* __restrict__ g,
+                                                        double* __restrict__ D, double* __restrict__ U) {
+  const int nn = n * n, per = n + 2 * nn;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)T * per) return;
+  const int t = (int)(gid / per), e = (int)(gid % per);
+  double acc = 0.0;
+  for (int r = 0; r < world; ++r) {
+    const int lo = range[2 * r], hi = range[2 * r + 1];
+    if (t >= lo && t <= hi) acc += rec[((size_t)r * maxlen + (t - lo)) * per + e];
+  }
+  if (e < n) g[(size_t)t * n + e] = acc;
+  else if (e < n + nn) D[(size_t)t * nn + (e - n)] = acc;
+  else if (t < T - 1) U[(size_t)t * nn + (e - n - nn)] = acc;
+}
+// exchange 1: ordered sum of the ranks' partial cost sums -> acc[0]
+__global__ void dist_cost_fold_kernel(int world, const double* __restrict__ parts, double* acc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int r = 0; r < world; ++r) s += parts[r];
+    acc[0] = s;
+  }
+}
+
 // publish the (all-reduced) cost sum and the log-det into host-mapped memory: out = {cost_sum, hld}
 __global__ void publish_kernel(const double* cost_sum, const double* half_logdet, double* host_out, double seq) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -91,6 +91,42 @@ class HipEngine:
     def accept_spec(self): self.ctx.ngd_accept_spec()
 
 
+def torch_allgather(device_index: int, group=None):
+    """All-gather callback for gvi_dist_init_callback built on torch.distributed: RCCL when the group's backend is nccl
+    (stream-ordered on the library's stream), a host round trip through gloo otherwise (tests / rehearsal on one GPU)."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", device_index)
+
+    def fn(send, recv, count, stream):
+        world = dist.get_world_size(group)
+        t_send = torch.as_tensor(_DevArray(send, count), device=dev)
+        t_recv = torch.as_tensor(_DevArray(recv, count * world), device=dev)
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+            if dist.get_backend(group) == "nccl":
+                dist.all_gather_into_tensor(t_recv, t_send, group=group)
+            else:
+                cpu = t_send.cpu()                                   # synchronises with the stream
+                parts = [torch.empty_like(cpu) for _ in range(world)]
+                dist.all_gather(parts, cpu, group=group)
+                t_recv.copy_(torch.cat(parts), non_blocking=False)
+    return fn
+
+
+class InLibraryNGD:
+    """The sharded iteration with BOTH exchange steps inside the C library (gvi_dist_init_*): the driver issues one
+    gvi_ngd_step per iteration, exactly as in a single process."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def reset(self):
+        pass
+
+    def step(self, step_size_base=0.55, max_backtrack=10):
+        return self.ctx.ngd_step(step_size_base, max_backtrack)
+
+
 class ShardedNGD:
     """GVIGH::optimize body (gvibase/GVI-GH-impl.h:39-118) over sharded factors."""
 

@@ -246,6 +246,28 @@ gvi_status gvi_ngd_trial_finish(gvi_ctx* ctx, double* new_cost);
  * which = 1: the trial's partial sum of factor costs (count = 1) written by trial_local;
  * which = 2: the packed partial sums written by spec_gradients_local (the other gradient buffer). */
 gvi_status gvi_ngd_exchange(gvi_ctx* ctx, int which, void** dev_ptr, int64_t* count);
+
+/* ---- sharded factors, exchange INSIDE the library (one process per GPU; no reference counterpart -- the
+ *      reference is single-process OpenMP, ngd/NGD-GH-impl.h:31-52).  Every rank adds only ITS contiguous range of each
+ *      factor set (gvi_factors_add with global start indices; an empty range is K = 0) and calls the ordinary
+ *      gvi_ngd_init / gvi_ngd_cost / gvi_ngd_gradients / gvi_ngd_trial / gvi_ngd_step: after gvi_dist_init_* those run
+ *      the two exchange steps of a pass on the context stream themselves -- the host issues ONE call per iteration:
+ *        exchange 0  each rank's partial [g | D | U] is non-zero only on its state range [lo, hi]: the ranks ALL-GATHER
+ *                    those state records (n + 2 n^2 doubles per state, padded to the longest range) and fold them in rank
+ *                    order (the ranges of neighbours overlap in one state) -- (N-1)/N of an all-reduce's zeros never move;
+ *        exchange 1  the partial factor-cost sums: all-gather of one double per rank, summed in rank order.
+ *      Both are deterministic and give bit-identical results on every rank, which the replicated chain recursions need.
+ * Transport: RCCL (dlopen of librccl, ncclAllGather on the context stream) or a host-supplied all-gather. */
+/* 128-byte ncclUniqueId from rank 0, to be distributed by the host (any channel) before gvi_dist_init_rccl. */
+gvi_status gvi_dist_unique_id(void* id128);
+gvi_status gvi_dist_init_rccl(gvi_ctx* ctx, int rank, int world, const void* id128);
+/* All-gather callback: send [count] doubles -> recv [world][count] doubles, both DEVICE pointers; the implementation
+ * must order itself after the work already queued on hip_stream and either complete or queue its result on that stream
+ * before returning.  Returns 0 on success. */
+typedef int (*gvi_allgather_fn)(void* user, const void* send, void* recv, int64_t count, void* hip_stream);
+gvi_status gvi_dist_init_callback(gvi_ctx* ctx, int rank, int world, gvi_allgather_fn fn, void* user);
+/* rank / world of the context (1 process: 0 / 1) and the last exchange's geometry: records sent per rank. */
+gvi_status gvi_dist_info(const gvi_ctx* ctx, int* rank, int* world, int* records_per_rank);
 /* Speculative pipeline of the sharded driver (what gvi_ngd_step does inside one process): after trial_local and the
  * all-reduce of exchange 1, trial_publish queues the publish of the trial cost WITHOUT waiting; spec_gradients_local /
  * _finish (all-reduce exchange 2 in between) queue the next iteration's gradients at the trial state behind it;

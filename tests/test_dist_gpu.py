@@ -70,3 +70,86 @@ def test_two_ranks_on_one_gpu_match_single_process(name, iters, speculate):
         assert np.abs(SigD - ref["SigD"]).max() < 1e-9 * np.abs(ref["SigD"]).max()
     # the replicated chain state is bit-identical across ranks (same all-reduced inputs, same chain code)
     assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+
+
+def _worker_inlib(rank, world, port, name, iters, fuse, q):
+    """Same problem, exchange INSIDE the library (gvi_dist_init_callback with a gloo all-gather): one gvi_ngd_step per
+    iteration, no Python between the halves."""
+    import torch.distributed as dist
+    from gaussianvi_amd import api
+    from gaussianvi_amd.dist import HipEngine, shard_chain, torch_allgather
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ch = make_chain(name)
+        ctx, ids = api.context_for_chain(shard_chain(ch, rank, world), device=0)
+        eng = HipEngine(ctx, 0)                                   # puts the library on a torch stream
+        ctx.dist_init_callback(rank, world, torch_allgather(0))
+        ctx.ngd_set_mode(True, fuse)
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        log = [ctx.ngd_step(40.0 if it == 1 else 0.55, 10) for it in range(iters)]
+        st = ctx.ngd_get_state()
+        q.put((rank, log, st["mu"], st["D"], st["SigD"], ctx.dist_info()))
+        ctx.close()
+        del eng
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fuse", [0, 2])
+@pytest.mark.parametrize("name,iters,world", [("c2", 4, 2), ("c3small", 3, 3), ("planar", 3, 4)])
+def test_in_library_exchange_matches_single_process(name, iters, world, fuse):
+    """exchange 0 as an all-gather of each rank's state records (+ the one state neighbours share),
+    exchange 1 as an all-gather of the partial cost sums, both issued by the library itself.  2, 3 and 4 ranks (4 ranks on
+    the planar graph leave two ranks with an EMPTY shard of the two-anchor set) against the single-process run."""
+    from gaussianvi_amd import api
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_set_mode(True, fuse)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    ref_log = [ctx.ngd_step(40.0 if it == 1 else 0.55, 10) for it in range(iters)]
+    ref = ctx.ngd_get_state()
+    ctx.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker_inlib, args=(r, world, port, name, iters, fuse, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    T = ch["T"]
+    for rank, log, mu, D, SigD, info in res:
+        assert info["world"] == world and 0 < info["records_per_rank"] <= (T + world - 1) // world + 2
+        for a, b in zip(log, ref_log):
+            assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"]
+            assert np.isclose(a["new_cost"], b["new_cost"], rtol=1e-10)
+        s = np.abs(ref["mu"]).max()
+        assert np.abs(mu - ref["mu"]).max() < 1e-9 * s
+        assert np.abs(D - ref["D"]).max() < 1e-9 * np.abs(ref["D"]).max()
+        assert np.abs(SigD - ref["SigD"]).max() < 1e-9 * np.abs(ref["SigD"]).max()
+    for r in res[1:]:                                  # replicated state: bit-identical across ranks
+        assert np.array_equal(res[0][2], r[2]) and np.array_equal(res[0][3], r[3])
+
+
+def test_rccl_transport_with_one_rank():
+    """The RCCL transport itself (dlopen of librccl, ncclCommInitRank, ncclAllGather on the context stream) with a
+    communicator of size one -- the only size a one-GPU box allows; N > 1 over xGMI is first run by the driver."""
+    from gaussianvi_amd import api
+    ch = make_chain("c2")
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    ref = [ctx.ngd_step(0.55, 10) for _ in range(3)]
+    ref_mu = ctx.ngd_get_state()["mu"]
+    ctx.close()
+    ctx, ids = api.context_for_chain(ch)
+    ctx.dist_init_rccl(0, 1, api.dist_unique_id())
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    got = [ctx.ngd_step(0.55, 10) for _ in range(3)]
+    for a, b in zip(got, ref):
+        assert a["accepted"] == b["accepted"] and np.isclose(a["new_cost"], b["new_cost"], rtol=1e-12)
+    assert np.abs(ctx.ngd_get_state()["mu"] - ref_mu).max() < 1e-12 * np.abs(ref_mu).max()
+    assert ctx.dist_info()["records_per_rank"] == ch["T"]
+    ctx.close()
