@@ -14,6 +14,6 @@ GVI_FORCE_ALLREDUCE=1 timeout -k 10 300 python -m torch.distributed.run --nnodes
 python - <<'PY'
 import json
 for n in ("reh1", "reh2", "reh4", "rccl1"):
-    d = json.load(open(f"gpurun_out/r02/{n}.json"))
+    d = json.loads([l for l in open(f"gpurun_out/r02/{n}.json") if l.startswith("{")][-1])
     print(n, "final_cost", d["final_cost"], "ms/step", d["ms_per_step"], "scaling", d["scaling"], "rccl_ranks", d.get("rccl_ranks"), d["config"]["sharding"][:90])
 PY
