@@ -175,6 +175,10 @@ struct gvi_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_grad = nullptr, ev_solve[2] = {nullptr, nullptr};
   bool solve_pending[2] = {false, false};
+  // dual_chain (GVI_DUAL_CHAIN=0 restores the side stream): the gradient solve is not launched at once but parked, and goes
+  // out fused with the next trial factorisation (same three launches, no fork / join events)
+  bool dual_chain = true;
+  bool solve_deferred[2] = {false, false};
   DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
   DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
   DevMem epi_counter;                 // two-level arrival counters of epilogue_all_kernel's tail
@@ -810,18 +814,65 @@ gvi_status launch_seg_n(gvi_ctx* c, const SegArgs& a, const SegPlan& pl) {
   return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: block size");
 }
 
-gvi_status run_seg(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, bool pivot,
-                   bool need_E, double* SigD, double* SigU, double* x, double* hld) {
-  BcrWs w;
-  GVICK(ensure_chain_ws(c, w));
+SegArgs make_seg_args(gvi_ctx* c, const BcrWs& w, const double* D, const double* U, const double* rhs, double scale, bool need_E,
+                      double* SigD, double* SigU, double* x, double* hld, bool with_mix) {
   SegArgs a;
   a.T = c->T; a.n = c->n; a.need_E = need_E ? 1 : 0;
   a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.w = w;
   a.SigD = SigD; a.SigU = SigU; a.x = x; a.hld = hld;
   a.level0 = a.m = a.S = a.prev0 = a.top = 0;
-  a.mixVD = c->mix.VD; a.mixVU = c->mix.VU; a.mixOutD = c->mix.outD; a.mixOutU = c->mix.outU; a.mix_step = c->mix.step;
+  a.mixVD = with_mix ? c->mix.VD : nullptr; a.mixVU = with_mix ? c->mix.VU : nullptr;
+  a.mixOutD = with_mix ? c->mix.outD : nullptr; a.mixOutU = with_mix ? c->mix.outU : nullptr; a.mix_step = with_mix ? c->mix.step : 0.0;
+  return a;
+}
+
+gvi_status run_seg(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, bool pivot,
+                   bool need_E, double* SigD, double* SigU, double* x, double* hld) {
+  BcrWs w;
+  GVICK(ensure_chain_ws(c, w));
+  const SegArgs a = make_seg_args(c, w, D, U, rhs, scale, need_E, SigD, SigU, x, hld, true);
   const SegPlan pl = seg_plan(c);
   return pivot ? launch_seg_n<true>(c, a, pl) : launch_seg_n<false>(c, a, pl);
+}
+
+// factorisation a0 (workspace 0, may carry the fused trial precision) and solve a1 (workspace 1) side by side in the same
+// launches (bcr_seg_*_dual_kernel)
+template <int N>
+gvi_status launch_seg_dual(gvi_ctx* c, SegArgs a0, SegArgs a1, const SegPlan& pl) {
+  GVICK(allow_lds(c, (const void*)bcr_seg_forward_dual_kernel<N>, 160 * 1024));
+  GVICK(allow_lds(c, (const void*)bcr_seg_backward_dual_kernel<N>, 160 * 1024));
+  for (const SegPass& ps : pl.passes) {
+    for (SegArgs* a : {&a0, &a1}) { a->level0 = ps.level0; a->m = ps.m; a->S = ps.S; a->prev0 = ps.prev0; a->top = ps.top; }
+    const size_t lds = std::max(seg_fwd_lds_doubles(N, ps.S, false, ps.top != 0, pl.threads / 64),
+                                seg_fwd_lds_doubles(N, ps.S, true, ps.top != 0, pl.threads / 64)) * 8;
+    if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: LDS budget");
+    const int stride = ps.S << ps.level0;
+    const int blocks = ps.top ? 1 : (c->T + stride - 1) / stride;
+    hipLaunchKernelGGL((bcr_seg_forward_dual_kernel<N>), dim3(2 * blocks), dim3(pl.threads), lds, c->stream, a0, a1, blocks);
+  }
+  for (int i = (int)pl.passes.size() - 2; i >= 0; --i) {
+    const SegPass& ps = pl.passes[i];
+    for (SegArgs* a : {&a0, &a1}) { a->level0 = ps.level0; a->m = ps.m; a->S = ps.S; a->prev0 = ps.prev0; a->top = 0; }
+    const size_t lds = std::max(seg_bwd_lds_doubles(N, ps.S, false), seg_bwd_lds_doubles(N, ps.S, true)) * 8;
+    const int stride = ps.S << ps.level0;
+    const int blocks = (c->T + stride - 1) / stride;
+    hipLaunchKernelGGL((bcr_seg_backward_dual_kernel<N>), dim3(2 * blocks), dim3(pl.threads), lds, c->stream, a0, a1, blocks);
+  }
+  HIPCK(c, hipGetLastError());
+  return GVI_OK;
+}
+
+gvi_status launch_seg_dual_n(gvi_ctx* c, const SegArgs& a0, const SegArgs& a1, const SegPlan& pl) {
+  switch (c->n) {
+    case 1: return launch_seg_dual<1>(c, a0, a1, pl);
+    case 2: return launch_seg_dual<2>(c, a0, a1, pl);
+    case 3: return launch_seg_dual<3>(c, a0, a1, pl);
+    case 4: return launch_seg_dual<4>(c, a0, a1, pl);
+    case 6: return launch_seg_dual<6>(c, a0, a1, pl);
+    case 8: return launch_seg_dual<8>(c, a0, a1, pl);
+    case 12: return launch_seg_dual<12>(c, a0, a1, pl);
+  }
+  return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: block size");
 }
 
 // log-det (+ optionally marginals) of the chain (D, U) device arrays
@@ -923,6 +974,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
   if (const char* w = getenv("GVI_NO_FUSE_GATHER")) c->fuse_gather = atoi(w) == 0;
   if (const char* w = getenv("GVI_SIDE_SOLVE")) c->side_solve = atoi(w) != 0;
+  if (const char* w = getenv("GVI_DUAL_CHAIN")) c->dual_chain = atoi(w) != 0;
   if (const char* w = getenv("GVI_SCOST_F")) c->scost_f = atoi(w) == 4 ? 4 : 2;
   if (const char* w = getenv("GVI_COST_CHUNK_MULT")) c->cost_chunk_mult = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
@@ -1861,6 +1913,7 @@ gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const d
     HIPCK(ctx, g.dmu2[i].ensure(T * n * 8));
   }
   g.gcur = 0; g.grad_valid = false; g.grad_slot = -1;
+  ctx->solve_deferred[0] = ctx->solve_deferred[1] = false;
   HIPCK(ctx, g.exch1.ensure(8));
   HIPCK(ctx, g.dmu.ensure(T * n * 8));
   HIPCK(ctx, g.dLam.ensure(bt * 8));
@@ -1987,6 +2040,7 @@ static gvi_status ngd_scatter(gvi_ctx* ctx, int slot, int gb) {
 }
 
 static gvi_status ngd_grad_local(gvi_ctx* ctx, int slot, int gb) {
+  ctx->solve_deferred[gb] = false;                      // a parked solve of this buffer's previous contents is moot
   GVICK(ngd_moments_full(ctx, slot));
   return ngd_scatter(ctx, slot, gb);
 }
@@ -1998,6 +2052,10 @@ static gvi_status ngd_grad_finish(gvi_ctx* ctx, int gb) {
   double* eg = g.exch0[gb].d();
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
+  if (ctx->dual_chain && ctx->side_solve && seg_supported(ctx->n) && ctx->bcr_variant != 1 && ctx->T > 1) {
+    ctx->solve_deferred[gb] = true;                     // goes out with the next trial factorisation (ngd_trial_state)
+    return GVI_OK;
+  }
   if (ctx->side_solve && seg_supported(ctx->n) && ctx->bcr_variant != 1) {
     // the solve only feeds mu_trial; the trial precision and its factorisation need Vddmu alone, so the solve goes
     // to the side stream and ngd_join_solve() waits for it right before the first reader of dmu
@@ -2021,6 +2079,16 @@ static gvi_status ngd_grad_finish(gvi_ctx* ctx, int gb) {
 
 // main stream waits for a side-stream solve of gradient buffer gb (no-op when none is pending)
 static gvi_status ngd_join_solve(gvi_ctx* ctx, int gb) {
+  if (ctx->solve_deferred[gb]) {                        // nobody fused it with a factorisation: run it now, in stream order
+    ctx->solve_deferred[gb] = false;
+    NgdState& g = ctx->ngd;
+    const size_t T = ctx->T, n = ctx->n, nn = n * n;
+    double* eg = g.exch0[gb].d();
+    ctx->chain_ws = 1;
+    const gvi_status st = run_bt_solve(ctx, eg + T * n, eg + T * n + T * nn, eg, -1.0, g.dmu2[gb].d());
+    ctx->chain_ws = 0;
+    return st;
+  }
   if (ctx->solve_pending[gb]) {
     HIPCK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_solve[gb], 0));
     ctx->solve_pending[gb] = false;
@@ -2058,7 +2126,32 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
   const int c = g.cur, t = 1 - c;
   g.cost_valid[t] = false;
   g.spec_ready = false;
-  if (ctx->solve_pending[g.gcur]) {
+  if (ctx->solve_deferred[g.gcur]) {
+    // Lam_trial formed and factorised (log-det + marginals) and the parked gradient solve, side by side in three launches
+    const size_t T = ctx->T, Tnn = T * nn_(ctx);
+    double* eg = g.exch0[g.gcur].d();
+    const double* V = eg + Tn;
+    ctx->mix.VD = V; ctx->mix.VU = V + Tnn; ctx->mix.outD = g.Lam[t].d(); ctx->mix.outU = g.Lam[t].d() + Tnn; ctx->mix.step = step;
+    BcrWs w0, w1;
+    ctx->chain_ws = 0;
+    gvi_status fs = ensure_chain_ws(ctx, w0);
+    ctx->chain_ws = 1;
+    if (fs == GVI_OK) fs = ensure_chain_ws(ctx, w1);
+    ctx->chain_ws = 0;
+    if (fs == GVI_OK) {
+      double* sD = g.Sig[t].d();
+      const SegArgs a0 = make_seg_args(ctx, w0, g.Lam[c].d(), g.Lam[c].d() + Tnn, nullptr, 1.0, true, sD, sD + Tnn, nullptr, g.hld[t].d(), true);
+      const SegArgs a1 = make_seg_args(ctx, w1, V, V + Tnn, eg, -1.0, false, nullptr, nullptr, g.dmu2[g.gcur].d(), nullptr, false);
+      fs = launch_seg_dual_n(ctx, a0, a1, seg_plan(ctx));
+    }
+    ctx->mix = gvi_ctx::Mix();
+    GVICK(fs);
+    ctx->solve_deferred[g.gcur] = false;
+    ctx->defer_gather = true;               // mu_trial and the gather ride in the prep launch of the cost pass
+    const gvi_status gs = ngd_refresh_gather(ctx, t, g.mu[c].d(), g.dmu2[g.gcur].d(), step);
+    ctx->defer_gather = false;
+    GVICK(gs);
+  } else if (ctx->solve_pending[g.gcur]) {
     // precision part first (needs no dmu), factorise, then join the side-stream solve and form mu_trial
     if (seg_supported(ctx->n) && ctx->bcr_variant != 1 && ctx->T > 1) {
       // Lam_trial = Lam + step (V - Lam) is formed by the first BCR pass while it loads the chain (and written to
@@ -2514,6 +2607,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "pair_fuse") ctx->pair_fuse = value != 0;
   else if (n == "fuse_gather") ctx->fuse_gather = value != 0;
   else if (n == "side_solve") ctx->side_solve = value != 0;
+  else if (n == "dual_chain") ctx->dual_chain = value != 0;
   else if (n == "warm_start") ctx->warm_start = value != 0;
   else if (n == "no_scost") ctx->no_scost = value != 0;
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);

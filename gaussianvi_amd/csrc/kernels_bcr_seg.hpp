@@ -292,13 +292,12 @@ __device__ inline double seg_fold_y(const SegArgs& a, int x, int r) {
 
 // ---- pass A / B forward (+ pass B backward): one workgroup per segment ----
 template <bool PIVOT, int N>
-__global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
-  extern __shared__ double sm[];
+__device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int bid, double* sm) {
   constexpr int nn = N * N;
   const int T = a.T, S = a.S, st = 1 << a.level0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
   const bool rhs = a.rhs != nullptr;
-  const int x0 = (int)blockIdx.x * S * st;
+  const int x0 = bid * S * st;
   double* Dl = sm;                    // [S][nn] effective diagonal blocks
   double* Cl = Dl + S * nn;           // [S][nn] coupling A[x_j, x_{j+1}] at this pass's spacing
   double* NUl = Cl + S * nn;          // [S][nn] new couplings, indexed by the eliminated node
@@ -455,17 +454,34 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
   }
 }
 
+template <bool PIVOT, int N>
+__global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
+  extern __shared__ double sm[];
+  bcr_seg_forward_body<PIVOT, N>(a, (int)blockIdx.x, sm);
+}
+
+// Two chain operations in ONE launch: blocks [0, nb0) run the (unpivoted) factorisation a0, the rest the (pivoted)
+// solve a1.  In the resident NGD iteration the trial factorisation (log-det + marginals of Lam_trial, needs Vddmu only) and
+// the gradient solve (dmu = Vddmu^-1 (-g)) are independent; on two streams they overlapped but the fork / join event packets
+// left ~7 + ~12 us of gaps per iteration (profiles/r02_b kernel trace) -- side by side in the same three launches they cost
+// neither a second stream nor an event.
+template <int N>
+__global__ __launch_bounds__(1024) void bcr_seg_forward_dual_kernel(SegArgs a0, SegArgs a1, int nb0) {
+  extern __shared__ double sm[];
+  if ((int)blockIdx.x < nb0) bcr_seg_forward_body<false, N>(a0, (int)blockIdx.x, sm);
+  else bcr_seg_forward_body<true, N>(a1, (int)blockIdx.x - nb0, sm);
+}
+
 // ---- pass C: backward recursion inside every segment of an earlier pass ----
 // The segment's factors (E, GA, GB / v) are fetched from global ONCE into LDS, then the m levels run
 // on LDS only.
 template <int N>
-__global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
-  extern __shared__ double sm[];
+__device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const int bid, double* sm) {
   constexpr int nn = N * N;
   const int T = a.T, S = a.S, st = 1 << a.level0;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
   const bool rhs = a.rhs != nullptr;
-  const int x0 = (int)blockIdx.x * S * st;
+  const int x0 = bid * S * st;
   int cnt = 0;
   for (int j = 0; j < S; ++j) if (x0 + j * st < T) cnt = j + 1;
   const int xn = x0 + S * st;                         // the next segment's first node (slot S)
@@ -557,6 +573,19 @@ __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
     }
     lds_barrier();
   }
+}
+
+template <int N>
+__global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
+  extern __shared__ double sm[];
+  bcr_seg_backward_body<N>(a, (int)blockIdx.x, sm);
+}
+
+template <int N>
+__global__ __launch_bounds__(1024) void bcr_seg_backward_dual_kernel(SegArgs a0, SegArgs a1, int nb0) {
+  extern __shared__ double sm[];
+  if ((int)blockIdx.x < nb0) bcr_seg_backward_body<N>(a0, (int)blockIdx.x, sm);
+  else bcr_seg_backward_body<N>(a1, (int)blockIdx.x - nb0, sm);
 }
 
 }  // namespace gvi
