@@ -115,11 +115,11 @@ def exec_ops(d: int, m: int, full: bool, signed: bool = False, mirror: bool = Fa
     """fp64 VALU instructions per EVALUATION of a sum-of-squares psi with m residual rows in the z-space formulation
     (DESIGN section 2): u = u0 + H z (m d FMA), psi = sum s_r u_r^2 (m FMA; m more MUL for the signs when some residual
     weight is negative -- `signed`), c = w psi (1), m0 (1); the full pass adds t = c z (d), m1 (d) and the packed upper
-    triangle of M2 (d (d + 1) / 2 FMA).  `mirror`: the kernel evaluates psi at z and -z from one H z and accumulates the
-    pair once (u(-z) = 2 u0 - u(z): m, second psi: m, c+ and c-: 4) -- the count of one pair is halved."""
+    triangle of M2 (d (d + 1) / 2 FMA).  `mirror`: the kernel evaluates a +-pair from ONE v = H z: q = sum s v^2 (m, + m
+    signed), l = sum (s u0) v (m), c+ = 2 w (q + k0) and c- = 4 w l (5) -- the count of one pair is halved."""
     sq = 2 * m if signed else m
     if mirror:
-        pair = m * d + sq + m + sq + 4 + 1
+        pair = m * d + sq + m + 5 + 1
         if full:
             pair += 2 * d + d * (d + 1) // 2
         return pair / 2

@@ -1312,7 +1312,8 @@ __device__ __forceinline__ void pipe_zload_all(double (&z)[D], const unsigned vo
 // psi phase, column C: u += H[:, C] z[C].  Operand group g = C / GC lives in hA (g even) or hB (g odd); the request of
 // group g + 1 goes out behind the first column of group g (g >= 1), i.e. behind that group's wait, into the buffer
 // group g - 1 has left.
-template <int D, int M, int GC, int C = 0>
+// FROM_ZERO: u starts at 0 (v = H z alone, the mirror-pair form) instead of u0
+template <int D, int M, int GC, bool FROM_ZERO, int C = 0>
 __device__ __forceinline__ void pipe_psi_cols(double (&u)[M], double (&z)[D], double (&hA)[GC * M], double (&hB)[GC * M],
                                               const double (&u0v)[M], cdouble_t* const hp) {
   if constexpr (C < D) {
@@ -1324,7 +1325,7 @@ __device__ __forceinline__ void pipe_psi_cols(double (&u)[M], double (&z)[D], do
     if constexpr (C == 0) {
       asm volatile("s_waitcnt vmcnt(%1)" : "+v"(z[0]) : "n"(D - 1));
 #pragma unroll
-      for (int rr = 0; rr < M; ++rr) u[rr] = fma(h[rr], z[0], u0v[rr]);
+      for (int rr = 0; rr < M; ++rr) u[rr] = FROM_ZERO ? h[rr] * z[0] : fma(h[rr], z[0], u0v[rr]);
     } else {
       asm volatile("s_waitcnt vmcnt(%2)" : "+v"(z[C]), "+v"(u[0]) : "n"(D - 1 - C));
 #pragma unroll
@@ -1337,7 +1338,7 @@ __device__ __forceinline__ void pipe_psi_cols(double (&u)[M], double (&z)[D], do
       for (int j = 0; j < GS; ++j) hnext[j] = hp[(g + 1) * GS + j];
       __builtin_amdgcn_sched_barrier(0);
     }
-    pipe_psi_cols<D, M, GC, C + 1>(u, z, hA, hB, u0v, hp);
+    pipe_psi_cols<D, M, GC, FROM_ZERO, C + 1>(u, z, hA, hB, u0v, hp);
   }
 }
 
@@ -1388,9 +1389,13 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
   double acc[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) acc[j] = 0.0;
-  double u0v[M];
+  // unpaired: u0.  Mirror pairs: s_r u0_r (the odd moment's weights) and k0 = sum_r s_r u0_r^2 (see below)
+  double u0v[M], k0 = 0.0;
 #pragma unroll
-  for (int r = 0; r < M; ++r) u0v[r] = us_w[r];
+  for (int r = 0; r < M; ++r) {
+    u0v[r] = MIRROR ? us_w[M + r] * us_w[r] : us_w[r];
+    if (MIRROR) k0 = fma(u0v[r], us_w[r], k0);
+  }
   const int64_t Np = MIRROR ? a.f.Nmp : a.f.Np;
   const int64_t ck = MIRROR ? a.mchunk : a.chunk;
   const int64_t i0 = (int64_t)by * ck;
@@ -1419,7 +1424,7 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
     cdouble_t* hp = hq;
     asm volatile("" : "+s"(hp));                      // opaque per step: the operand loads stay inside the loop
     double u[M];
-    pipe_psi_cols<D, M, GC>(u, z, hA, hB, u0v, hp);
+    pipe_psi_cols<D, M, GC, MIRROR>(u, z, hA, hB, u0v, hp);
     double psi = 0.0;
     if constexpr (SIGNED) {
 #pragma unroll
@@ -1431,20 +1436,16 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
     asm volatile("" : "+v"(wi));                       // w was issued before z[0]: it has landed with z[0]'s wait
     double cw, cm = 0.0;
     if constexpr (MIRROR) {
-      // the mirror point: u(-z) = u0 - H z = 2 u0 - u(z), psi(-z) from it; one load and one H z for two evaluations
-      double psim = 0.0;
+      // +-pair from ONE v = H z (u holds v, psi holds q = sum_r s_r v_r^2):  psi(+-z) = sum_r s_r (u0_r +- v_r)^2, so
+      //   c+ = w (psi(z) + psi(-z)) = 2 w (q + k0),          k0 = sum_r s_r u0_r^2  (per factor)
+      //   c- = w (psi(z) - psi(-z)) = 4 w sum_r (s_r u0_r) v_r                       (no cancellation)
+      double l = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < M; ++rr) u[rr] = fma(u0v[rr], 2.0, -u[rr]);
-      if constexpr (SIGNED) {
-#pragma unroll
-        for (int rr = 0; rr < M; ++rr) psim = fma(us_w[M + rr] * u[rr], u[rr], psim);
-      } else {
-#pragma unroll
-        for (int rr = 0; rr < M; ++rr) psim = fma(u[rr], u[rr], psim);
-      }
-      const bool ok = idx < nvalid;                    // pad rows carry w = 0, z = 0; the select keeps a NaN psi out
-      cw = ok ? wi * (psi + psim) : 0.0;
-      cm = ok ? wi * (psi - psim) : 0.0;
+      for (int rr = 0; rr < M; ++rr) l = fma(u0v[rr], u[rr], l);
+      const bool ok = idx < nvalid;                    // pad rows carry w = 0, z = 0 (finite values: the select is for safety)
+      const double w2 = wi + wi;
+      cw = ok ? w2 * (psi + k0) : 0.0;
+      cm = ok ? (w2 + w2) * l : 0.0;
     } else {
       cw = idx < nvalid ? wi * psi : 0.0;              // pad rows carry w = 0, z = 0; the select keeps a NaN psi out
     }
@@ -1492,10 +1493,13 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
 // every residual row of the set has positive weight (sgn = +1): the sign multiply of psi is dropped
 template <int D, int M>
 __device__ __forceinline__ void sreg_pipe_dispatch(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
-  // +-pairing only on the unsigned path: with signed residual weights the pair body does not fit two waves per SIMD
-  if (a.f.Zm && a.f.all_pos) sreg_pipe_body<D, M, false, true>(a, bx, by, usb, redb);
-  else if (a.f.all_pos) sreg_pipe_body<D, M, false, false>(a, bx, by, usb, redb);
-  else sreg_pipe_body<D, M, true, false>(a, bx, by, usb, redb);
+  if (a.f.Zm) {
+    if (a.f.all_pos) sreg_pipe_body<D, M, false, true>(a, bx, by, usb, redb);
+    else sreg_pipe_body<D, M, true, true>(a, bx, by, usb, redb);
+  } else {
+    if (a.f.all_pos) sreg_pipe_body<D, M, false, false>(a, bx, by, usb, redb);
+    else sreg_pipe_body<D, M, true, false>(a, bx, by, usb, redb);
+  }
 }
 
 // PIPE selects the hand-pipelined body for the full pass (the cost pass has its own kernels)
@@ -1539,8 +1543,64 @@ __global__ __launch_bounds__(256, 2) void moments_sreg_pair_kernel(MomArgs a0, M
 // evaluation drops by F (the cost pass executes only M D + M FMAs per point and is otherwise bound by the
 // 8-byte-per-lane table loads).  Block = 4 waves = 4 F consecutive factors over the same range of points.
 // ---------------------------------------------------------------------------------------------
+// Cost pass on the mirror-half table.  For a +-pair the cross terms of the two evaluations cancel:
+//   psi(z) + psi(-z) = sum_r s_r [(u0_r + v_r)^2 + (u0_r - v_r)^2] = 2 (sum_r s_r v_r^2 + sum_r s_r u0_r^2),   v = H z,
+// so a pair costs ONE H z (started from zero) and one sum of squares; k0 = sum_r s_r u0_r^2 is a per-factor constant.
+// (The origin is stored with half its weight: v = 0 there and the pair formula returns w psi(0).)
+template <int D, int M, int F>
+__device__ __forceinline__ void scost_mirror_body(const MomArgs& a, const int bx, const int by, double* usb) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  double (*us_w)[3 * M] = (double (*)[3 * M])(usb + wave * F * 3 * M);     // [F][zeros | sgn | unused]
+  const int k0i = (bx * 4 + wave) * F;
+  cdouble_t* hq[F];
+  double kc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const int k = __builtin_amdgcn_readfirstlane(k0i + f < a.f.K ? k0i + f : a.f.K - 1);
+    double kk = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) { const double u = a.f.u0[(size_t)k * M + r]; kk = fma(a.f.sgn[(size_t)k * M + r] * u, u, kk); }
+    kc[f] = kk;
+    if (lane < M) {
+      us_w[f][lane] = 0.0;
+      us_w[f][M + lane] = a.f.sgn[(size_t)k * M + lane];
+    }
+    const uint64_t hbase = (uint64_t)(a.f.H + (size_t)k * M * D);
+    hq[f] = (cdouble_t*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(hbase >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)hbase));
+  }
+  __syncthreads();
+  double acc[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[f] = 0.0;
+  const int64_t Np = a.f.Nmp;
+  const int64_t i0 = (int64_t)by * a.mchunk;
+  const int64_t i1 = (i0 + a.mchunk < Np) ? i0 + a.mchunk : Np;
+  const double* __restrict__ Zm = a.f.Zm;
+  for (int64_t base = i0; base < i1; base += 64) {             // wave-uniform loop over whole 64-pair tiles
+    const double* tile = Zm + (size_t)(base >> 6) * (D + 1) * 64 + lane;
+    double z[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) z[c] = tile[c * 64];
+    const double w2 = 2.0 * tile[D * 64];                      // pad lanes: w = 0, z = 0
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const double q = split_psi_rows<D, M>(hq[f], us_w[f], us_w[f] + M, z);   // sum_r s_r (H z)_r^2
+      acc[f] = fma(w2, q + kc[f], acc[f]);
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    double s = acc[f];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0 && k0i + f < a.f.K) a.partial[(size_t)(k0i + f) * a.nchunk + by] = s;
+  }
+}
+
 template <int D, int M, int F>
 __device__ __forceinline__ void scost_body(const MomArgs& a, const int bx, const int by, double* usb) {
+  if (a.f.Zm) { scost_mirror_body<D, M, F>(a, bx, by, usb); return; }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double (*us_w)[2 * M] = (double (*)[2 * M])(usb + wave * F * 2 * M);     // [F][2 M]
   const int k0 = (bx * 4 + wave) * F;
@@ -1588,14 +1648,14 @@ __device__ __forceinline__ void scost_body(const MomArgs& a, const int bx, const
 
 template <int D, int M, int F>
 __global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
-  __shared__ double us[4 * F * 2 * M];
+  __shared__ double us[4 * F * 3 * M];
   scost_body<D, M, F>(a, blockIdx.x, blockIdx.y, us);
 }
 
 template <int D0, int M0, int D1, int M1, int F>
 __global__ __launch_bounds__(256) void moments_scost_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
   constexpr int MM = M0 > M1 ? M0 : M1;
-  __shared__ double us[4 * F * 2 * MM];
+  __shared__ double us[4 * F * 3 * MM];
   const int b = blockIdx.x;
   if (b < nb0) scost_body<D0, M0, F>(a0, b % nbx0, b / nbx0, us);
   else scost_body<D1, M1, F>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us);
