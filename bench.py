@@ -129,6 +129,28 @@ def exec_ops(d: int, m: int, full: bool, signed: bool = False, mirror: bool = Fa
     return ops
 
 
+def orbit_exec_ops(d: int, p: int, m: int, full: bool, signed: bool = False) -> float:
+    """fp64 VALU instructions per EVALUATION of the sign-orbit kernel (csrc/kernels_orbit.hpp), averaged over the (d, p)
+    table: an orbit of support size s costs  s m (start corner)  +  2^(s-1) half-points x [q: m (+ m signed), l: m, c+ and
+    its sum: 2, sign-weighted sums: s + s (s - 1) / 2]  +  (2^(s-1) - 1) flips x (m + 1)  +  the per-orbit scaling
+    (3 + 5 s + 2 s (s - 1) / 2 multiplies); the cost pass keeps q, c+ and the flips only.  The LDS atomics that fold an
+    orbit into the factor's accumulators are not VALU instructions."""
+    import numpy as np
+    from gaussianvi_amd import api
+    Z, w, _ = api.spgh_nodes(d, p)
+    rep = np.all(Z >= 0.0, axis=1)
+    sizes = np.count_nonzero(Z[rep], axis=1)
+    total = 0.0
+    for sz in range(1, int(sizes.max()) + 1):
+        n = int(np.sum(sizes == sz))
+        nh = 2 ** (sz - 1)
+        sq = 2 * m if signed else m
+        per_point = sq + 2 + ((m + sz + sz * (sz - 1) // 2) if full else 0)
+        per_orbit = sz * m + nh * per_point + (nh - 1) * (m + 1) + ((3 + 5 * sz + sz * (sz - 1)) if full else 2)
+        total += n * per_orbit
+    return total / len(w)
+
+
 def alg_flops(d: int, m: int) -> int:
     """expand d^2 + residual + quadratic form (m^2 + m each) + accumulate 1 + d + d (d + 1) / 2 FMA."""
     return 2 * (d * d + 2 * (m * m + m) + 1 + d + d * (d + 1) // 2)
@@ -142,7 +164,7 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 register (LDS operands), 3 operand-resident, 5 register (SGPR operands)")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 register (LDS operands), 3 operand-resident, 5 register (SGPR operands), 6 sign-orbit")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default, BASELINE configs[3]): the same chain over N GPUs (128 factors per GPU at N = 8: bounded "
                          "by the replicated chain recursions and the exchange); weak: 1024 factors PER GPU, i.e. a (1024 N)-factor "
@@ -307,7 +329,9 @@ def main():
         geo = ctx.profile_geometry(ids[0])
         km = float(np.mean(kern_ms)) * 1e-3 if kern_ms else float("nan")
         sreg_shapes = (4, 8, 12)
-        if geo["variant"] == 5:
+        if geo["variant"] == 6:
+            kernel_name = f"moments_orbit{'_pair' if len(ctx.sets) == 2 else ''}_kernel<{m0}, full>"
+        elif geo["variant"] == 5:
             kernel_name = f"moments_sreg_pair_kernel<{d0}, {m0}, {m0}, {m0}, full>"
         elif geo["variant"] == 2:
             kernel_name = {0: f"moments_sreg_kernel<{d0}, {m0}, full>" if d0 in sreg_shapes else f"moments_reg_kernel<{d0}, PsiQuad<{d0},{m0}>, full>",
@@ -324,13 +348,18 @@ def main():
             return bool(np.linalg.eigvalsh(0.5 * (W + np.transpose(W, (0, 2, 1)))).min() <= 0.0)
         sg0 = weights_signed(local["specs"][0])
         sets_in_launch = [(K0, d0, m0, N0, sg0)]
-        fused_pair = geo["variant"] == 5 and len(ctx.sets) == 2
+        fused_pair = geo["variant"] in (5, 6) and len(ctx.sets) == 2
         if fused_pair:
             K1, d1, p1, N1 = ctx.sets[1]
             sets_in_launch.append((K1, d1, d1, N1, weights_signed(local["specs"][1])))   # unary: psi = (x - mu0)^T Kinv (x - mu0), m = d
         evals_launch = sum(K * N for K, d, m, N, sg in sets_in_launch)
         mirror = geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"      # sreg kernels on a symmetric table
         ops_of = lambda d, m, sg: exec_ops(d, m, True, sg, mirror)
+        if geo["variant"] == 6:
+            p_of = {d0: p0}
+            if len(ctx.sets) == 2:
+                p_of[ctx.sets[1][1]] = ctx.sets[1][2]
+            ops_of = lambda d, m, sg: orbit_exec_ops(d, p_of[d], m, True, sg)
         if geo["variant"] == 3:
             # four waves per factor (moments_split_kernel): psi rows always carry the sign multiply, every wave forms
             # c = w psi and adds the four partial sums of psi (3 adds each)
@@ -385,7 +414,7 @@ def main():
             # algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.  The contract's compute label is
             # "mfma"; the kernel issues NO MFMA instruction: fp64 MFMA and fp64 VALU share one pipe on MI355X and
             # v_fma_f64 is the faster form (profiles/r01_fp64_pipes.txt), hence "pipe".
-            "roofline": {"bound": "mfma", "pipe": "valu_f64 (v_fma_f64; zero MFMA instructions)",
+            "roofline": {"bound": "mfma", "pipe": "valu_f64 (v_fma_f64 / v_add_f64; zero MFMA instructions)",
                          "achieved": exec_flop / km / 1e12, "peak": FP64_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": exec_flop / km / FP64_PEAK,
                          "traffic": traffic, "traffic_source": traffic_source,

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <set>
 #include <string>
 #include <thread>
@@ -20,6 +21,8 @@
 #include "kernels_bt.hpp"
 #include "kernels_bcr_seg.hpp"
 #include "kernels_factor.hpp"
+#include "kernels_orbit.hpp"
+#include "orbits.hpp"
 #include "spgh.hpp"
 
 using namespace gvi;
@@ -54,6 +57,10 @@ struct Table {
   int64_t Nm = 0, Nmp = 0;
   DevMem codes, lut;       // 8-bit node codes [d/4][Np] + value look-up (moments_split_kernel); empty when not coded
   bool coded = false;
+  // sign-orbit form (orbits.hpp; moments_orbit_kernel): host copy keeps only the tile lists, the rest lives on the device
+  OrbitHost orb;
+  DevMem orb_cpk, orb_mag, orb_w, orb_ts, orb_tf;
+  std::map<int, std::unique_ptr<DevMem>> orb_bounds;   // nchunk -> [nchunk + 1] tile bounds
 };
 
 struct FactorSet {
@@ -76,6 +83,7 @@ struct FactorSet {
   int64_t chunk = 0;
   bool use_reg = false;
   bool use_split = false;
+  bool use_orbit = false;
   bool fused_pair = false;            // last resident launch went out fused with the other set
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   bool all_pos = false;               // every residual row has sgn = +1 (positive-definite weight)
@@ -160,10 +168,14 @@ struct gvi_ctx {
   int split_flush = SPLIT_FLUSH;      // GVI_SPLIT_FLUSH=0: plain recursive sums in the split kernel (A/B of the (24,7) rounding)
   bool sreg_pipe = true;              // GVI_SREG_PIPE=0: full pass on the compiler-scheduled body (A/B; bit-identical results)
   bool no_scost = false;              // GVI_NO_SCOST=1: cost pass on the one-factor-per-wave kernel (A/B)
+  // sum-of-squares sets on the sign-orbit kernel (kernels_orbit.hpp) when the table decomposes; GVI_ORBIT=0: the
+  // lane-per-point kernels (A/B; results agree to rounding)
+  bool orbit = true;
+  int orbit_waves = 8192;             // waves the orbit launch of one set aims for (chunks = orbit_waves / K, <= tiles)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
   // run_moments in planning mode: the launch that WOULD be issued is recorded instead (pair fusion of two sets)
-  struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; };
+  struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; OrbitArgs oa; int smax = 0; bool all_pos = false; };
   Deferred* defer = nullptr;
   int update_rule = 0;                // 0 natural gradient (NGD-GH), 1 proximal / JKO (ProxGVI-GH)
   bool pair_fuse = true;              // GVI_NO_PAIR=1: one launch per set
@@ -337,6 +349,28 @@ gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const dou
       HIPCK(c, hipMemcpy(t.codes.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice));
       HIPCK(c, hipMemcpy(t.lut.p, vals.data(), 256 * 8, hipMemcpyHostToDevice));
       t.coded = true;
+    }
+  }
+  // sign-orbit form: every table whose points come in complete sign orbits with one weight (nwspgr's do by construction)
+  t.orb = OrbitHost();
+  t.orb_bounds.clear();
+  if (N > 1) {
+    OrbitHost o = build_orbits(d, N, Z, w, true);
+    if (o.ok && o.smax >= 1) {
+      HIPCK(c, t.orb_cpk.ensure(o.cpk.size() * 8));
+      HIPCK(c, t.orb_mag.ensure(o.mag.size() * 8));
+      HIPCK(c, t.orb_w.ensure(o.w.size() * 8));
+      HIPCK(c, t.orb_ts.ensure(o.tile_s.size() * 4));
+      HIPCK(c, t.orb_tf.ensure(o.tile_first.size() * 4));
+      HIPCK(c, hipMemcpy(t.orb_cpk.p, o.cpk.data(), o.cpk.size() * 8, hipMemcpyHostToDevice));
+      HIPCK(c, hipMemcpy(t.orb_mag.p, o.mag.data(), o.mag.size() * 8, hipMemcpyHostToDevice));
+      HIPCK(c, hipMemcpy(t.orb_w.p, o.w.data(), o.w.size() * 8, hipMemcpyHostToDevice));
+      HIPCK(c, hipMemcpy(t.orb_ts.p, o.tile_s.data(), o.tile_s.size() * 4, hipMemcpyHostToDevice));
+      HIPCK(c, hipMemcpy(t.orb_tf.p, o.tile_first.data(), o.tile_first.size() * 4, hipMemcpyHostToDevice));
+      std::vector<uint64_t>().swap(o.cpk);
+      std::vector<double>().swap(o.mag);
+      std::vector<double>().swap(o.w);
+      t.orb = std::move(o);
     }
   }
   return GVI_OK;
@@ -525,6 +559,72 @@ void dispatch_scost(gvi_ctx* c, const FactorSet& s, const MomArgs& a, int nchunk
   else launch_scost<2>(s, a, nchunk, st);
 }
 
+// ---- sign-orbit kernel (kernels_orbit.hpp) ----
+bool orbit_supported(const gvi_ctx* c, const FactorSet& s) {
+  if (!c->orbit || !(c->variant == 0 || c->variant == 6)) return false;
+  if (s.kind != KIND_QUAD_PRIOR && s.kind != KIND_FIXED_PRIOR) return false;
+  if (!(s.m == 6 || s.m == 12) || s.d > 32) return false;
+  const OrbitHost& o = s.table->orb;
+  return o.ok && o.smax >= 1 && o.smax <= ORBIT_SMAX && !o.tile_s.empty();
+}
+
+gvi_status orbit_args(gvi_ctx* c, FactorSet& s, int full, OrbitArgs* out) {
+  Table& t = *s.table;
+  auto it = t.orb_bounds.find(s.nchunk);
+  if (it == t.orb_bounds.end()) {
+    const std::vector<int32_t> b = orbit_chunk_bounds(t.orb, s.nchunk);
+    auto mem = std::make_unique<DevMem>();
+    HIPCK(c, mem->ensure(b.size() * 4));
+    HIPCK(c, hipMemcpy(mem->p, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    it = t.orb_bounds.emplace(s.nchunk, std::move(mem)).first;
+  }
+  OrbitArgs a;
+  a.H = s.H.d(); a.u0 = s.u0.d(); a.sgn = s.sgn.d(); a.partial = s.partial.d();
+  a.K = s.K; a.d = s.d; a.nchunk = s.nchunk;
+  a.ob.cpk = (const uint64_t*)t.orb_cpk.p; a.ob.mag = t.orb_mag.d(); a.ob.w = t.orb_w.d();
+  a.ob.tile_s = t.orb_ts.i(); a.ob.tile_first = t.orb_tf.i(); a.ob.bounds = it->second->i();
+  a.ob.norb_p = t.orb.norb_p; a.ob.w0 = t.orb.w0;
+  (void)full;
+  *out = a;
+  return GVI_OK;
+}
+
+template <int M, int SMAX, int WAVES>
+void launch_orbit_t(const OrbitArgs& a, bool full, bool all_pos, dim3 grid, size_t lds, hipStream_t st) {
+  if (full && all_pos) hipLaunchKernelGGL((moments_orbit_kernel<M, SMAX, true, false, WAVES>), grid, dim3(256), lds, st, a);
+  else if (full) hipLaunchKernelGGL((moments_orbit_kernel<M, SMAX, true, true, WAVES>), grid, dim3(256), lds, st, a);
+  else if (all_pos) hipLaunchKernelGGL((moments_orbit_kernel<M, SMAX, false, false, WAVES>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((moments_orbit_kernel<M, SMAX, false, true, WAVES>), grid, dim3(256), lds, st, a);
+}
+
+void launch_orbit(const OrbitArgs& a, int m, int smax, bool full, bool all_pos, hipStream_t st) {
+  const dim3 grid((a.K + 3) / 4, a.nchunk);
+  const size_t lds = (size_t)4 * orbit_lds_doubles(a.d, m) * 8;
+  if (m == 6 && smax <= 4) launch_orbit_t<6, 4, 4>(a, full, all_pos, grid, lds, st);
+  else if (m == 6) launch_orbit_t<6, 6, 2>(a, full, all_pos, grid, lds, st);
+  else if (smax <= 4) launch_orbit_t<12, 4, 3>(a, full, all_pos, grid, lds, st);
+  else launch_orbit_t<12, 6, 2>(a, full, all_pos, grid, lds, st);
+}
+
+// two sets with the same m and sgn = +1 in one launch
+template <int M, int SMAX, int WAVES>
+void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, size_t lds, hipStream_t st) {
+  const int nbx0 = (a0.K + 3) / 4, nbx1 = (a1.K + 3) / 4;
+  const int nb0 = nbx0 * a0.nchunk, nb1 = nbx1 * a1.nchunk;
+  if (full)
+    hipLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, true, false, WAVES>), dim3(nb0 + nb1), dim3(256), lds, st, a0, a1, nbx0, nb0, nbx1);
+  else
+    hipLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, false, false, WAVES>), dim3(nb0 + nb1), dim3(256), lds, st, a0, a1, nbx0, nb0, nbx1);
+}
+
+void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st) {
+  const size_t lds = (size_t)4 * std::max(orbit_lds_doubles(a0.d, m), orbit_lds_doubles(a1.d, m)) * 8;
+  if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st);
+  else if (m == 6) launch_orbit_pair_t<6, 6, 2>(a0, a1, full, lds, st);
+  else if (smax <= 4) launch_orbit_pair_t<12, 4, 3>(a0, a1, full, lds, st);
+  else launch_orbit_pair_t<12, 6, 2>(a0, a1, full, lds, st);
+}
+
 // prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
 gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma, int slot = -1,
                     hipStream_t st = nullptr) {
@@ -546,7 +646,7 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
 gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full,
                        hipStream_t st = nullptr) {
   if (!st) st = c->stream;
-  if (s.K == 0) { s.nchunk = 1; s.chunk = s.table->Np; s.use_reg = s.use_split = false; return GVI_OK; }   // empty shard
+  if (s.K == 0) { s.nchunk = 1; s.chunk = s.table->Np; s.use_reg = s.use_split = s.use_orbit = false; return GVI_OK; }   // empty shard
   if (s.kind == KIND_HINGE_SDF_3D_ARM && !psi_ext && !s.arm.p)
     return fail(c, GVI_ERR_STATE, "HINGE_SDF_3D_ARM set without an arm model: call gvi_factors_set_arm");
   if (s.kind >= KIND_HINGE_SDF_2D && !psi_ext && s.sdf_rows == 0)
@@ -555,9 +655,15 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   if (c->variant == 2 && !reg && !psi_ext)
     return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
   const bool closed = s.closed_form && !psi_ext;
-  const bool split = !closed && !reg && !psi_ext && c->variant != 1 && split_supported(s);
+  const bool orbit = !closed && !psi_ext && orbit_supported(c, s);
+  const bool split = !closed && !orbit && !reg && !psi_ext && c->variant != 1 && split_supported(s);
   if (closed) { reg = false; s.chunk = s.table->Np; s.nchunk = 1; }
-  else if (split) {
+  else if (orbit) {
+    reg = false;
+    const int64_t tiles = (int64_t)s.table->orb.tile_s.size();
+    s.nchunk = (int)std::min<int64_t>(tiles, std::max<int64_t>(1, (c->orbit_waves + s.K - 1) / s.K));
+    s.chunk = s.table->Np;
+  } else if (split) {
     const int64_t tiles = s.table->Np / 64;                          // ~2 blocks per CU: K * nchunk >= 1024
     int64_t nch = std::max<int64_t>(1, (1024 + s.K - 1) / s.K);
     nch = std::max<int64_t>(nch, (tiles + 16383) / 16384);         // <= 16k points per lane: bounds the rounding of the
@@ -565,7 +671,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     s.chunk = (tiles + nch - 1) / nch * 64;
     s.nchunk = (int)((s.table->Np + s.chunk - 1) / s.chunk);
   } else plan_chunks(c, s, reg);
-  if (reg && !full && !closed && (c->variant == 5 || c->variant == 0) && scost_supported(s) && !c->no_scost) {
+  if (reg && !full && !closed && !orbit && (c->variant == 5 || c->variant == 0) && scost_supported(s) && !c->no_scost) {
     // F factors per wave: keep the wave count up with more, shorter chunks
     const int64_t iters = s.table->Np / 256;
     int64_t nch = std::min<int64_t>(std::max<int64_t>(1, (int64_t)s.nchunk * c->cost_chunk_mult), std::max<int64_t>(1, iters));
@@ -575,6 +681,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   }
   s.use_reg = reg;
   s.use_split = split;
+  s.use_orbit = orbit;
   const size_t need = (size_t)s.K * s.nchunk * npairs(s.d) * 8;
   HIPCK(c, s.partial.ensure(need));
   MomArgs a;
@@ -596,6 +703,15 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   }
   if (closed) {
     hipLaunchKernelGGL(moments_closed_kernel, dim3(s.K), dim3(64), 0, st, a);
+  } else if (orbit) {
+    OrbitArgs oa;
+    GVICK(orbit_args(c, s, full, &oa));
+    if (c->defer) {
+      c->defer->kind = 2; c->defer->oa = oa; c->defer->d = s.d; c->defer->m = s.m;
+      c->defer->smax = s.table->orb.smax; c->defer->all_pos = s.all_pos;
+      return GVI_OK;
+    }
+    launch_orbit(oa, s.m, s.table->orb.smax, full != 0, s.all_pos, st);
   } else if (split) {
     const dim3 grid(s.K, s.nchunk);
     const int R = (s.m + 3) / 4;
@@ -968,6 +1084,8 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
+  if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
+  if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
   if (const char* w = getenv("GVI_MIRROR")) c->mirror = atoi(w) != 0;
   if (const char* w = getenv("GVI_SPLIT_FLUSH")) c->split_flush = std::max(0, atoi(w));
@@ -1978,7 +2096,9 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
     FactorSet& s1 = *ctx->sets[1];
     const bool shape = s0.kind == KIND_QUAD_PRIOR && s1.kind == KIND_FIXED_PRIOR && s0.d == 12 && s1.d == 6 &&
                        !s0.closed_form && !s1.closed_form && s0.K > 0 && s1.K > 0;
-    if (shape) {
+    const bool shape_orbit = orbit_supported(ctx, s0) && orbit_supported(ctx, s1) && s0.m == s1.m && s0.all_pos && s1.all_pos &&
+                             !s0.closed_form && !s1.closed_form && s0.K > 0 && s1.K > 0;
+    if (shape || shape_orbit) {
       gvi_ctx::Deferred d0, d1;
       ctx->defer = &d0;
       gvi_status st = run_moments(ctx, s0, s0.mu_k[slot].d(), nullptr, full);
@@ -1986,6 +2106,25 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
       ctx->defer = nullptr;
       GVICK(st);
       const int want = full ? 0 : 1;
+      if (d0.kind == 2 && d1.kind == 2) {              // both sets on the sign-orbit kernel
+        const bool prof = ctx->profile && full && (ctx->profile_count++ % ctx->profile_every) == 0;
+        if (prof) {
+          for (int e = 0; e < 2; ++e)
+            if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
+          HIPCK(ctx, hipEventRecord(s0.ev[0][0], ctx->stream));
+        }
+        launch_orbit_pair(d0.oa, d1.oa, d0.m, std::max(d0.smax, d1.smax), full != 0, ctx->stream);
+        HIPCK(ctx, hipGetLastError());
+        if (prof) { HIPCK(ctx, hipEventRecord(s0.ev[0][1], ctx->stream)); s0.ev_set[0] = true; }
+        s0.fused_pair = s1.fused_pair = true;
+        return GVI_OK;
+      }
+      if (d0.kind == 2 || d1.kind == 2) {              // only one of them: issue both on their own
+        s0.fused_pair = s1.fused_pair = false;
+        if (d0.kind >= 0) GVICK(run_moments(ctx, s0, s0.mu_k[slot].d(), nullptr, full));
+        if (d1.kind >= 0) GVICK(run_moments(ctx, s1, s1.mu_k[slot].d(), nullptr, full));
+        return GVI_OK;
+      }
       if (d0.kind == want && d1.kind == want) {
         const int nb0 = (int)(d0.grid.x * d0.grid.y), nb1 = (int)(d1.grid.x * d1.grid.y);
         const bool prof = ctx->profile && full && (ctx->profile_count++ % ctx->profile_every) == 0;
@@ -2592,7 +2731,7 @@ gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what, float* ms) {
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk) {
   FactorSet* s = get_set(ctx, set_id);
   if (!s) return GVI_ERR_ARG;
-  if (variant) *variant = s->closed_form ? 0 : (s->fused_pair ? 5 : (s->use_reg ? 2 : (s->use_split ? 3 : 1)));
+  if (variant) *variant = s->closed_form ? 0 : (s->use_orbit ? 6 : (s->fused_pair ? 5 : (s->use_reg ? 2 : (s->use_split ? 3 : 1))));
   if (nchunk) *nchunk = s->nchunk;
   if (chunk) *chunk = s->chunk;
   return GVI_OK;
@@ -2611,6 +2750,8 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "warm_start") ctx->warm_start = value != 0;
   else if (n == "no_scost") ctx->no_scost = value != 0;
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);
+  else if (n == "orbit") ctx->orbit = value != 0;
+  else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);
   else return fail(ctx, GVI_ERR_ARG, "unknown option: " + n);
   for (auto& s : ctx->sets) s->prep_slot = -1;
   ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;
@@ -2620,7 +2761,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
 }
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 5) return GVI_ERR_ARG;
+  if (!ctx || variant < 0 || variant > 6) return GVI_ERR_ARG;
   ctx->variant = variant;
   return GVI_OK;
 }

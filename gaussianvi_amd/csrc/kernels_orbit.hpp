@@ -1,0 +1,244 @@
+// moments_orbit_kernel: the sum-of-squares psi kinds on the SIGN-ORBIT form of the sparse Gauss-Hermite table.
+//
+// The lane-per-point kernels (kernels_factor.hpp) treat a sigma point as a dense d-vector: at (12,5) they spend 72 FMAs on
+// H z and 90 on c z z^T per evaluation although a point has at most FOUR non-zero coordinates, and every point is one of
+// 2^s sign images of the same magnitudes.  Here a lane owns a whole orbit (csrc/orbits.hpp: support c_0 < ... < c_{s-1},
+// magnitudes m_j, one weight w) of ONE factor (wave = factor x chunk of orbit tiles; the factor's H and its 91 moment
+// accumulators live in LDS):
+//   * only the s columns H[:, c_j] of the support are touched: they are read from LDS once per orbit;
+//   * the 2^s sign patterns are walked in Gray-code order, one coordinate flips per step:  v += +-2 m_j H[:, c_j]  (M FMAs);
+//   * only HALF the orbit is walked: for a +-pair the cross terms cancel (kernels_factor.hpp, sreg_pipe_body):
+//         psi(z) + psi(-z) = 2 (q + k0),  psi(z) - psi(-z) = 4 l,   q = sum_r s_r v_r^2,  l = sum_r (s_r u0_r) v_r,  v = H z;
+//   * within the orbit the moments are sign-weighted sums of those two scalars (Walsh sums):
+//         m0 += 2w sum(q + k0);   m1[c_i] += 4w m_i sum sigma_i l;   M2[c_i][c_j] += 2w m_i m_j sum sigma_i sigma_j (q + k0);
+//     they are accumulated in registers with compile-time signs and added to the factor's accumulators ONCE per orbit;
+//   * those adds go to data-dependent entries (the orbit's coordinates): LDS atomics (ds_add_f64).  The lanes of one
+//     instruction are served in a fixed order and every wave owns its accumulators, so results are run-to-run
+//     bit-identical (tests/test_gpu_parity.py checks it); the chunk partials are summed in fixed order by the epilogue as
+//     for every other kernel.
+// Per evaluation at (12,5): ~14 fp64 instructions in the walk + ~9 of per-orbit work, against 96 for the +-paired
+// lane-per-point kernel and 319 FMAs for the reference's x-space algorithm.  Registers: ~110 (M = 6, s = 4), so four and
+// more waves per SIMD instead of two.  The same kernel serves d = 24 (M = 12, s <= 6): accumulators and H sit in LDS, not
+// in registers, so the factor dimension no longer decides the kernel family.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels_factor.hpp"
+
+namespace gvi {
+
+struct OrbitDev {
+  const uint64_t* cpk;       // [norb_p] support coordinates, one byte each
+  const double* mag;         // [smax][norb_p]
+  const double* w;           // [norb_p]
+  const int32_t* tile_s;     // [ntiles]
+  const int32_t* tile_first; // [ntiles]
+  const int32_t* bounds;     // [nchunk + 1] tile ranges of the chunks
+  int64_t norb_p;
+  double w0;                 // weight of the origin
+};
+
+// one factor set on the orbit kernel: the psi operands of prep_kernel + the orbit table
+struct OrbitArgs {
+  const double* H;           // [K][d][M]
+  const double* u0;          // [K][M]
+  const double* sgn;         // [K][M]
+  double* partial;           // [K][nchunk][npairs(d)] (full) or [K][nchunk] (cost)
+  int K, d, nchunk;
+  OrbitDev ob;
+};
+
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// one orbit per lane, support size S (all lanes of the wave: tiles are uniform in S)
+template <int M, int S, bool FULL, bool SIGNED>
+__device__ __forceinline__ void orbit_walk(const int d, const uint64_t cpk, const double (&mg)[S], const double w, const double* Hl,
+                                           double* accl, const double (&su0)[M], const double (&sg)[M], const double k0, double& m0) {
+  int c[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) c[j] = (int)((cpk >> (8 * j)) & 255u);
+  // the support's columns of H: in registers while they fit (M S <= 36 doubles); otherwise the column of the NEXT flip is
+  // fetched from LDS while the current point is evaluated (the compiler barrier keeps the loads from being hoisted back
+  // into one register-resident block)
+  constexpr bool HREG = M * S <= 36;
+  constexpr int NH = 1 << (S - 1);
+  double hcol[HREG ? S : 1][M];
+  const double* hp[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    hp[j] = Hl + c[j] * M;
+    if constexpr (HREG) {
+#pragma unroll
+      for (int r = 0; r < M; ++r) hcol[j][r] = hp[j][r];
+    }
+  }
+  // start at the corner (-, ..., -, +): the last coordinate keeps its sign, the other S-1 are walked in Gray order
+  int sig[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) sig[j] = j == S - 1 ? 1 : -1;
+  double v[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) v[r] = mg[S - 1] * hp[S - 1][r];
+#pragma unroll
+  for (int j = 0; j < S - 1; ++j) {
+    if constexpr (!HREG) {                                      // one column in flight at a time
+#pragma unroll
+      for (int r = 0; r < M; ++r) asm volatile("" : "+v"(v[r]) :: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r) v[r] = fma(-mg[j], hp[j][r], v[r]);
+  }
+  double E0 = 0.0, Eij[S * (S - 1) / 2 + 1], Oi[S];
+#pragma unroll
+  for (int e = 0; e < S * (S - 1) / 2 + 1; ++e) Eij[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < S; ++j) Oi[j] = 0.0;
+#pragma unroll
+  for (int g = 0; g < NH; ++g) {
+    const int jn = g + 1 < NH ? __builtin_ctz(g + 1) : 0;        // coordinate of the next flip (compile-time after unrolling)
+    double hn[M];
+    if constexpr (!HREG) {
+      if (g + 1 < NH) {
+        asm volatile("" : "+v"(E0) :: "memory");                // the previous point is finished before the next fetch
+#pragma unroll
+        for (int r = 0; r < M; ++r) asm volatile("" : "+v"(v[r]) :: "memory");
+#pragma unroll
+        for (int r = 0; r < M; ++r) hn[r] = hp[jn][r];
+      }
+    }
+    double q = 0.0, l = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      q = SIGNED ? fma(sg[r] * v[r], v[r], q) : fma(v[r], v[r], q);
+      if (FULL) l = fma(su0[r], v[r], l);
+    }
+    const double cp = q + k0;
+    E0 += cp;
+    if (FULL) {
+      int e = 0;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        Oi[i] = sig[i] > 0 ? Oi[i] + l : Oi[i] - l;
+#pragma unroll
+        for (int j = i + 1; j < S; ++j) { Eij[e] = sig[i] * sig[j] > 0 ? Eij[e] + cp : Eij[e] - cp; ++e; }
+      }
+    }
+    if (g + 1 < NH) {
+      sig[jn] = -sig[jn];
+      const double t2 = (sig[jn] > 0 ? 2.0 : -2.0) * mg[jn];
+#pragma unroll
+      for (int r = 0; r < M; ++r) v[r] = fma(t2, HREG ? hcol[jn][r] : hn[r], v[r]);
+    }
+  }
+  const double wp = w + w;
+  m0 = fma(wp, E0, m0);
+  if (FULL) {
+    const double w4 = wp + wp;
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      const int a = c[i];
+      const double wm = wp * mg[i];
+      lds_add_f64(accl + 1 + a, w4 * mg[i] * Oi[i]);
+      const int row = 1 + d + a * d - a * (a - 1) / 2 - a;       // packed index of (a, b) = row + b
+      lds_add_f64(accl + row + a, wm * mg[i] * E0);
+#pragma unroll
+      for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + row + c[j], wm * mg[j] * Eij[e]); ++e; }
+    }
+  }
+}
+
+template <int M, int S, bool FULL, bool SIGNED>
+__device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, const int64_t o, const double* Hl, double* accl,
+                                           const double (&su0)[M], const double (&sg)[M], const double k0, double& m0) {
+  const uint64_t cpk = ob.cpk[o];
+  const double w = ob.w[o];
+  double mg[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) mg[j] = ob.mag[(size_t)j * ob.norb_p + o];
+  orbit_walk<M, S, FULL, SIGNED>(d, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
+}
+
+template <int M, int SMAX, bool FULL, bool SIGNED>
+__device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, const int chunk, double* lds) {
+  const OrbitDev& ob = a.ob;
+  const int lane = threadIdx.x & 63, d = a.d;
+  const int NP = FULL ? (d + 1) * (d + 2) / 2 : 1;
+  double* Hl = lds;                              // [d][M]: column c of H = the M operands of coordinate c
+  double* accl = Hl + d * M;                     // [NP] moment accumulators of this (factor, chunk)
+  const double* Hg = a.H + (size_t)k * M * d;    // stored [d][M] by the prep kernel
+  for (int e = lane; e < d * M; e += 64) Hl[e] = Hg[e];
+  if (FULL)
+    for (int e = lane; e < NP; e += 64) accl[e] = 0.0;
+  double su0[M], sg[M], k0 = 0.0;
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    const double u = a.u0[(size_t)k * M + r];
+    sg[r] = a.sgn[(size_t)k * M + r];
+    su0[r] = sg[r] * u;
+    k0 = fma(su0[r], u, k0);
+  }
+  wave_lds_sync();
+  double m0 = 0.0;
+  const int tb = ob.bounds[chunk], te = ob.bounds[chunk + 1];
+  for (int t = tb; t < te; ++t) {
+    const int s = __builtin_amdgcn_readfirstlane(ob.tile_s[t]);
+    const int64_t o = (int64_t)ob.tile_first[t] + lane;
+    if constexpr (SMAX > 4) {
+      if (s == 6) { orbit_tile<M, 6, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); continue; }
+      if (s == 5) { orbit_tile<M, 5, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); continue; }
+    }
+    switch (s) {
+      case 1: orbit_tile<M, 1, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
+      case 2: orbit_tile<M, 2, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
+      case 3: orbit_tile<M, 3, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
+      default: orbit_tile<M, 4, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
+    }
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) m0 += __shfl_xor(m0, sh);
+  if (chunk == 0) m0 = fma(ob.w0, k0, m0);       // the origin: psi(0) = sum_r s_r u0_r^2
+  wave_lds_sync();
+  double* out = a.partial + ((size_t)k * a.nchunk + chunk) * NP;
+  if (lane == 0) out[0] = m0;
+  if (FULL)
+    for (int e = 1 + lane; e < NP; e += 64) out[e] = accl[e];
+}
+
+// LDS doubles per wave
+__host__ __device__ inline int orbit_lds_doubles(int d, int M) { return d * M + (d + 1) * (d + 2) / 2; }
+
+// grid (ceil(K / 4), nchunk) x 256: four waves = four factors on the same chunk of orbit tiles.
+// SMAX: largest support instantiated (4: degree <= 5; 6: degree <= 7); SIGNED: some sgn entry is not +1;
+// WAVES: occupancy the register budget is cut for
+template <int M, int SMAX, bool FULL, bool SIGNED, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void moments_orbit_kernel(OrbitArgs a) {
+  extern __shared__ double sm[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = (int)blockIdx.x * 4 + wave;
+  if (k >= a.K) return;                          // no block-level barrier below
+  orbit_wave<M, SMAX, FULL, SIGNED>(a, k, (int)blockIdx.y, sm + (size_t)wave * orbit_lds_doubles(a.d, M));
+}
+
+// two sets in one launch (the chain pattern: binary priors + unary factors): blocks [0, nb0) serve set 0 as
+// (bx, chunk) = (id % nbx0, id / nbx0), the rest set 1 likewise with nbx1
+template <int M, int SMAX, bool FULL, bool SIGNED, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void moments_orbit_pair_kernel(OrbitArgs a0, OrbitArgs a1, int nbx0, int nb0, int nbx1) {
+  extern __shared__ double sm[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int id = (int)blockIdx.x;
+  const bool second = id >= nb0;
+  if (second) id -= nb0;
+  const int nbx = second ? nbx1 : nbx0;
+  const int k = (id % nbx) * 4 + wave, chunk = id / nbx;
+  if (!second) {
+    if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a0.d, M));
+  } else {
+    if (k < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a1.d, M));
+  }
+}
+
+}  // namespace gvi
