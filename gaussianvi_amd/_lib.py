@@ -93,6 +93,25 @@ STRING_GETTERS = {"gvi_version": [], "gvi_last_error": [C.c_void_p]}
 _lib = None
 
 
+def _torch_runtime_first():
+    """PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; the library links libamdhip64.so.7 by
+    SONAME.  If torch is imported FIRST the dynamic loader resolves that SONAME to torch's already-loaded copy and the
+    process holds one HIP runtime.  If the library is loaded first it brings in the system ROCm runtime, a later
+    `import torch` adds a second one, and torch.cuda then reports "No HIP GPUs are available" (measured on the MI355X
+    pool, tools/torch_after_probe.py).  The Python binding exists beside torch (device memory, streams,
+    torch.distributed), so it imports torch before the dlopen whenever torch is installed; GVI_NO_TORCH_PRELOAD=1 skips
+    that for torch-free processes that want the 1.5 s back.  C / C++ hosts of the C ABI are not affected."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("GVI_NO_TORCH_PRELOAD") == "1":
+        return
+    if importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
 def load():
     """Load gaussianvi_amd/libgvi_hip.so (built by gaussianvi_amd.build / __graft_entry__.build)."""
     global _lib
@@ -102,6 +121,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m gaussianvi_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _torch_runtime_first()
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

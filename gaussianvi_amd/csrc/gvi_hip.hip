@@ -171,7 +171,8 @@ struct gvi_ctx {
   // sum-of-squares sets on the sign-orbit kernel (kernels_orbit.hpp) when the table decomposes; GVI_ORBIT=0: the
   // lane-per-point kernels (A/B; results agree to rounding)
   bool orbit = true;
-  int orbit_waves = 8192;             // waves the orbit launch of one set aims for (chunks = orbit_waves / K, <= tiles)
+  int orbit_waves = 4096;             // waves the orbit launch of one set aims for (chunks = orbit_waves / K, <= tiles)
+  int orbit_copies = 8;               // private LDS copies of the accumulators (1, 2, 4, 8, 16; fewer when LDS is short)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
   // run_moments in planning mode: the launch that WOULD be issued is recorded instead (pair fusion of two sets)
@@ -581,6 +582,11 @@ gvi_status orbit_args(gvi_ctx* c, FactorSet& s, int full, OrbitArgs* out) {
   OrbitArgs a;
   a.H = s.H.d(); a.u0 = s.u0.d(); a.sgn = s.sgn.d(); a.partial = s.partial.d();
   a.K = s.K; a.d = s.d; a.nchunk = s.nchunk;
+  // private accumulator copies: as many as the kernel's occupancy leaves LDS for (160 KB per CU, 64 KB per block), capped by orbit_copies
+  const int waves = (s.m == 6 && t.orb.smax <= 4) ? 4 : ((s.m == 12 && t.orb.smax <= 4) ? 3 : 2);   // launch_orbit's occupancy
+  const size_t lds_cap = std::min<size_t>(64 * 1024, 160 * 1024 / waves);
+  a.copies = 1;
+  while (a.copies * 2 <= c->orbit_copies && (size_t)4 * orbit_lds_doubles(s.d, s.m, a.copies * 2) * 8 <= lds_cap) a.copies *= 2;
   a.ob.cpk = (const uint64_t*)t.orb_cpk.p; a.ob.mag = t.orb_mag.d(); a.ob.w = t.orb_w.d();
   a.ob.tile_s = t.orb_ts.i(); a.ob.tile_first = t.orb_tf.i(); a.ob.bounds = it->second->i();
   a.ob.norb_p = t.orb.norb_p; a.ob.w0 = t.orb.w0;
@@ -599,7 +605,7 @@ void launch_orbit_t(const OrbitArgs& a, bool full, bool all_pos, dim3 grid, size
 
 void launch_orbit(const OrbitArgs& a, int m, int smax, bool full, bool all_pos, hipStream_t st) {
   const dim3 grid((a.K + 3) / 4, a.nchunk);
-  const size_t lds = (size_t)4 * orbit_lds_doubles(a.d, m) * 8;
+  const size_t lds = (size_t)4 * orbit_lds_doubles(a.d, m, a.copies) * 8;
   if (m == 6 && smax <= 4) launch_orbit_t<6, 4, 4>(a, full, all_pos, grid, lds, st);
   else if (m == 6) launch_orbit_t<6, 6, 2>(a, full, all_pos, grid, lds, st);
   else if (smax <= 4) launch_orbit_t<12, 4, 3>(a, full, all_pos, grid, lds, st);
@@ -618,7 +624,7 @@ void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, si
 }
 
 void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st) {
-  const size_t lds = (size_t)4 * std::max(orbit_lds_doubles(a0.d, m), orbit_lds_doubles(a1.d, m)) * 8;
+  const size_t lds = (size_t)4 * std::max(orbit_lds_doubles(a0.d, m, a0.copies), orbit_lds_doubles(a1.d, m, a1.copies)) * 8;
   if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st);
   else if (m == 6) launch_orbit_pair_t<6, 6, 2>(a0, a1, full, lds, st);
   else if (smax <= 4) launch_orbit_pair_t<12, 4, 3>(a0, a1, full, lds, st);
@@ -1086,6 +1092,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
+  if (const char* w = getenv("GVI_ORBIT_COPIES")) c->orbit_copies = std::min(16, std::max(1, atoi(w)));
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
   if (const char* w = getenv("GVI_MIRROR")) c->mirror = atoi(w) != 0;
   if (const char* w = getenv("GVI_SPLIT_FLUSH")) c->split_flush = std::max(0, atoi(w));
@@ -2752,6 +2759,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);
   else if (n == "orbit") ctx->orbit = value != 0;
   else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);
+  else if (n == "orbit_copies") ctx->orbit_copies = std::min(16, std::max(1, value));
   else return fail(ctx, GVI_ERR_ARG, "unknown option: " + n);
   for (auto& s : ctx->sets) s->prep_slot = -1;
   ctx->ngd.cost_valid[0] = ctx->ngd.cost_valid[1] = false;

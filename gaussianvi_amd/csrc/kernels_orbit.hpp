@@ -46,6 +46,7 @@ struct OrbitArgs {
   const double* sgn;         // [K][M]
   double* partial;           // [K][nchunk][npairs(d)] (full) or [K][nchunk] (cost)
   int K, d, nchunk;
+  int copies;                // private copies of every accumulator entry (power of two <= 16), selected by lane % copies
   OrbitDev ob;
 };
 
@@ -55,8 +56,9 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 
 // one orbit per lane, support size S (all lanes of the wave: tiles are uniform in S)
 template <int M, int S, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_walk(const int d, const uint64_t cpk, const double (&mg)[S], const double w, const double* Hl,
-                                           double* accl, const double (&su0)[M], const double (&sg)[M], const double k0, double& m0) {
+__device__ __forceinline__ void orbit_walk(const int d, const int C, const uint64_t cpk, const double (&mg)[S], const double w,
+                                           const double* Hl, double* accl, const double (&su0)[M], const double (&sg)[M],
+                                           const double k0, double& m0) {
   int c[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) c[j] = (int)((cpk >> (8 * j)) & 255u);
@@ -136,30 +138,31 @@ __device__ __forceinline__ void orbit_walk(const int d, const uint64_t cpk, cons
   const double wp = w + w;
   m0 = fma(wp, E0, m0);
   if (FULL) {
+    // accl points at this lane's copy: entry e lives at accl[e * C]
     const double w4 = wp + wp;
     int e = 0;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       const int a = c[i];
       const double wm = wp * mg[i];
-      lds_add_f64(accl + 1 + a, w4 * mg[i] * Oi[i]);
+      lds_add_f64(accl + (1 + a) * C, w4 * mg[i] * Oi[i]);
       const int row = 1 + d + a * d - a * (a - 1) / 2 - a;       // packed index of (a, b) = row + b
-      lds_add_f64(accl + row + a, wm * mg[i] * E0);
+      lds_add_f64(accl + (row + a) * C, wm * mg[i] * E0);
 #pragma unroll
-      for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + row + c[j], wm * mg[j] * Eij[e]); ++e; }
+      for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + (row + c[j]) * C, wm * mg[j] * Eij[e]); ++e; }
     }
   }
 }
 
 template <int M, int S, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, const int64_t o, const double* Hl, double* accl,
+__device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, const int C, const int64_t o, const double* Hl, double* accl,
                                            const double (&su0)[M], const double (&sg)[M], const double k0, double& m0) {
   const uint64_t cpk = ob.cpk[o];
   const double w = ob.w[o];
   double mg[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) mg[j] = ob.mag[(size_t)j * ob.norb_p + o];
-  orbit_walk<M, S, FULL, SIGNED>(d, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
+  orbit_walk<M, S, FULL, SIGNED>(d, C, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
 }
 
 template <int M, int SMAX, bool FULL, bool SIGNED>
@@ -168,11 +171,16 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   const int lane = threadIdx.x & 63, d = a.d;
   const int NP = FULL ? (d + 1) * (d + 2) / 2 : 1;
   double* Hl = lds;                              // [d][M]: column c of H = the M operands of coordinate c
-  double* accl = Hl + d * M;                     // [NP] moment accumulators of this (factor, chunk)
+  // [NP][C] moment accumulators of this (factor, chunk): C private copies per entry, a lane adds to copy lane % C.  A
+  // ds_add_f64 whose lanes hit one address costs ~3 cycles per lane (64-way: 192 cycles, tools/ubench/lds_atomic.hip);
+  // with the copies and the strided orbit order (orbits.hpp) a wave instruction stays near the 8-cycle floor.
+  const int C = a.copies;
+  double* accl = Hl + d * M;
   const double* Hg = a.H + (size_t)k * M * d;    // stored [d][M] by the prep kernel
   for (int e = lane; e < d * M; e += 64) Hl[e] = Hg[e];
   if (FULL)
-    for (int e = lane; e < NP; e += 64) accl[e] = 0.0;
+    for (int e = lane; e < NP * C; e += 64) accl[e] = 0.0;
+  double* accme = accl + (lane & (C - 1));
   double su0[M], sg[M], k0 = 0.0;
 #pragma unroll
   for (int r = 0; r < M; ++r) {
@@ -188,14 +196,14 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
     const int s = __builtin_amdgcn_readfirstlane(ob.tile_s[t]);
     const int64_t o = (int64_t)ob.tile_first[t] + lane;
     if constexpr (SMAX > 4) {
-      if (s == 6) { orbit_tile<M, 6, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); continue; }
-      if (s == 5) { orbit_tile<M, 5, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); continue; }
+      if (s == 6) { orbit_tile<M, 6, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); continue; }
+      if (s == 5) { orbit_tile<M, 5, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); continue; }
     }
     switch (s) {
-      case 1: orbit_tile<M, 1, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
-      case 2: orbit_tile<M, 2, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
-      case 3: orbit_tile<M, 3, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
-      default: orbit_tile<M, 4, FULL, SIGNED>(ob, d, o, Hl, accl, su0, sg, k0, m0); break;
+      case 1: orbit_tile<M, 1, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
+      case 2: orbit_tile<M, 2, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
+      case 3: orbit_tile<M, 3, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
+      default: orbit_tile<M, 4, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
     }
   }
 #pragma unroll
@@ -205,11 +213,15 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   double* out = a.partial + ((size_t)k * a.nchunk + chunk) * NP;
   if (lane == 0) out[0] = m0;
   if (FULL)
-    for (int e = 1 + lane; e < NP; e += 64) out[e] = accl[e];
+    for (int e = 1 + lane; e < NP; e += 64) {
+      double t = accl[e * C];
+      for (int q = 1; q < C; ++q) t += accl[e * C + q];        // fixed order
+      out[e] = t;
+    }
 }
 
 // LDS doubles per wave
-__host__ __device__ inline int orbit_lds_doubles(int d, int M) { return d * M + (d + 1) * (d + 2) / 2; }
+__host__ __device__ inline int orbit_lds_doubles(int d, int M, int copies) { return d * M + copies * (d + 1) * (d + 2) / 2; }
 
 // grid (ceil(K / 4), nchunk) x 256: four waves = four factors on the same chunk of orbit tiles.
 // SMAX: largest support instantiated (4: degree <= 5; 6: degree <= 7); SIGNED: some sgn entry is not +1;
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(256, WAVES) void moments_orbit_kernel(OrbitArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k = (int)blockIdx.x * 4 + wave;
   if (k >= a.K) return;                          // no block-level barrier below
-  orbit_wave<M, SMAX, FULL, SIGNED>(a, k, (int)blockIdx.y, sm + (size_t)wave * orbit_lds_doubles(a.d, M));
+  orbit_wave<M, SMAX, FULL, SIGNED>(a, k, (int)blockIdx.y, sm + (size_t)wave * orbit_lds_doubles(a.d, M, a.copies));
 }
 
 // two sets in one launch (the chain pattern: binary priors + unary factors): blocks [0, nb0) serve set 0 as
@@ -235,9 +247,9 @@ __global__ __launch_bounds__(256, WAVES) void moments_orbit_pair_kernel(OrbitArg
   const int nbx = second ? nbx1 : nbx0;
   const int k = (id % nbx) * 4 + wave, chunk = id / nbx;
   if (!second) {
-    if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a0.d, M));
+    if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a0.d, M, a0.copies));
   } else {
-    if (k < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a1.d, M));
+    if (k < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a1.d, M, a1.copies));
   }
 }
 

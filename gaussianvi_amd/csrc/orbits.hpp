@@ -96,14 +96,27 @@ inline OrbitHost build_orbits(int d, int64_t N, const double* Z, const double* w
   for (int s = o.smax; s >= 1; --s) {
     const int64_t cnt = o.count[s], padded = (cnt + 63) / 64 * 64;
     for (int64_t t = 0; t < padded / 64; ++t) { o.tile_s.push_back(s); o.tile_first.push_back((int32_t)(pos + t * 64)); }
-    for (int64_t q = 0; q < cnt; ++q, ++ri) {
-      const double* z = Z + (size_t)reps[ri].row * d;
+    // Strided order inside a size class: the table is in lexicographic order, where 64 consecutive orbits share their
+    // leading coordinates and all 64 lanes of a tile would add into the same accumulator entries (one LDS atomic
+    // instruction then takes ~3 cycles PER LANE, tools/ubench/lds_atomic.hip).  Position q takes orbit (q * P) mod cnt
+    // with P ~ cnt / 64 coprime to cnt, so every tile samples the whole class.
+    int64_t P = 1;
+    if (cnt > 64) {
+      P = cnt / 64 + 1;
+      auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+      while (gcd(P, cnt) != 1) ++P;
+    }
+    const size_t class_first = ri;
+    ri += (size_t)cnt;
+    for (int64_t q = 0; q < cnt; ++q) {
+      const Rep& rep = reps[class_first + (size_t)((q * P) % cnt)];
+      const double* z = Z + (size_t)rep.row * d;
       uint64_t pk = 0;
       int j = 0;
       for (int a = 0; a < d; ++a)
         if (z[a] != 0.0) { pk |= (uint64_t)a << (8 * j); o.mag[(size_t)j * o.norb_p + pos + q] = z[a]; ++j; }
       o.cpk[pos + q] = pk;
-      o.w[pos + q] = w[reps[ri].row];
+      o.w[pos + q] = w[rep.row];
     }
     pos += padded;
   }

@@ -90,11 +90,14 @@ def test_moments_fixed_prior_vs_oracle(d, p, variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 6])
 @pytest.mark.parametrize("kind,d,p", [("quad", 24, 5), ("quad", 16, 4), ("quad", 20, 3), ("fixed", 24, 3), ("fixed", 16, 3)])
 def test_moments_wide_factors_split_kernel(kind, d, p, variant):
     """BASELINE configs[4] shapes (d = 24): four waves per factor, 8-bit node codes + look-up table
-    (moments_split_kernel) against the oracle and against the generic kernel."""
+    (moments_split_kernel; variant 0 with the sign-orbit kernel switched off) against the oracle and against the generic
+    kernel (1); variant 6 = the sign-orbit kernel, which takes the m = 12 shape by default."""
+    if variant == 6 and not (kind == "quad" and d == 24):
+        pytest.skip("orbit kernel: m in {6, 12}")
     rng = np.random.default_rng(2400 + d + p)
     K = 3
     if kind == "quad":
@@ -112,9 +115,11 @@ def test_moments_wide_factors_split_kernel(kind, d, p, variant):
         ctx, sid = single_set_ctx(api.PSI_FIXED_PRIOR, d, d, p, K, np.concatenate([mu0, Kinv.reshape(K, -1)], axis=1))
         psi = o.psi_batch_fixed_prior(mu0, Kinv)
     ctx.set_variant(variant)
+    if variant == 0:
+        ctx.set_option("orbit", 0)
     mu, Sigma = syn.random_marginals(rng, K, d, 0.3)
     Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
-    assert ctx.profile_geometry(sid)["variant"] == (3 if variant == 0 else 1)
+    assert ctx.profile_geometry(sid)["variant"] == {0: 3, 1: 1, 6: 6}[variant]
     cost = ctx.costs(sid, mu, Sigma)
     Z, w = oracle_table(d, p)
     r = o.batched_moments(Z, w, mu, Sigma, psi, temp)
@@ -980,6 +985,80 @@ def test_hand_pipelined_body_is_bit_identical(monkeypatch, kind, d, p, K):
         assert rel(got[0], ref["E_phi"]) < TIGHT and rel(got[1], ref["Vdmu"]) < TIGHT and rel(got[2], ref["Vddmu"]) < 10 * TIGHT
 
 
+@pytest.mark.parametrize("kind,d,m,p,K", [("quad", 12, 6, 5, 9), ("fixed", 6, 6, 5, 7), ("fixed", 6, 6, 7, 5), ("quad", 12, 6, 3, 6),
+                                          ("quad", 24, 12, 4, 5), ("fixed", 12, 12, 6, 3), ("quad", 12, 6, 7, 2), ("quad", 24, 12, 6, 1)])
+def test_sign_orbit_kernel_vs_lane_per_point_and_oracle(kind, d, m, p, K):
+    """moments_orbit_kernel (lane = sign orbit, half-orbit Gray-code walk, LDS accumulators) for support sizes 1..6 and
+    m = 6 / 12 against (a) the lane-per-point kernels on the same inputs, (b) the oracle; run-to-run bit-identical (the
+    LDS atomics serve the lanes of one instruction in a fixed order and every wave owns its accumulators); independent
+    of the number of accumulator copies and of the chunking up to rounding."""
+    rng = np.random.default_rng(7000 + 10 * d + p)
+    if kind == "quad":
+        n = d // 2
+        Phi, Qinv = quad_params(rng, K, n)
+        params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+        ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params)
+        psi = o.psi_batch_quad_prior(Phi, Qinv)
+    else:
+        mu0 = rng.normal(size=(K, d))
+        Kh = rng.normal(size=(K, d, d))
+        Kinv = Kh @ np.transpose(Kh, (0, 2, 1)) / d + 0.3 * np.eye(d)
+        ctx, sid = single_set_ctx(api.PSI_FIXED_PRIOR, d, d, p, K, np.concatenate([mu0, Kinv.reshape(K, -1)], axis=1))
+        psi = o.psi_batch_fixed_prior(mu0, Kinv)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.3)
+    got = ctx.moments(sid, mu, Sigma)
+    cost = ctx.costs(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == 6
+    again = ctx.moments(sid, mu, Sigma)
+    assert all(np.array_equal(a, b) for a, b in zip(got, again)) and np.array_equal(cost, ctx.costs(sid, mu, Sigma))
+    tol = 1e-10 if p <= 5 else 1e-8                       # |w|_1 grows with the degree: the sums carry more rounding
+    tols = (tol, tol, 10 * tol)                           # Vddmu: two more congruences with Sigma^-1
+    for name, value in (("orbit_copies", 1), ("orbit_copies", 16), ("orbit_waves", 64), ("orbit_waves", 100000)):
+        ctx.set_option(name, value)
+        alt = ctx.moments(sid, mu, Sigma)
+        assert ctx.profile_geometry(sid)["variant"] == 6
+        for a, b, lim in zip(got, alt, tols):
+            assert rel(a, b) < lim, (name, value)
+        assert rel(cost, ctx.costs(sid, mu, Sigma)) < tol
+    ctx.set_option("orbit", 0)
+    base = ctx.moments(sid, mu, Sigma)
+    base_cost = ctx.costs(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] != 6
+    ctx.close()
+    for a, b, lim in zip(got, base, tols):
+        assert rel(a, b) < lim
+    assert rel(cost, base_cost) < tol
+    assert np.array_equal(got[2], np.transpose(got[2], (0, 2, 1)))
+    if p <= 5 or d <= 12:
+        Z, w = oracle_table(d, p)
+        r = o.batched_moments(Z, w, mu, Sigma, psi, np.ones(K))
+        lim = TIGHT if p <= 5 else 1e-8
+        assert rel(got[0], r["E_phi"]) < lim and rel(got[1], r["Vdmu"]) < lim and rel(got[2], r["Vddmu"]) < 10 * lim
+        assert rel(cost, r["cost"]) < lim
+
+
+def test_sign_orbit_kernel_indefinite_weight():
+    """psi with an indefinite Qinv (some sgn = -1): the SIGNED instantiation of the orbit kernel."""
+    rng = np.random.default_rng(77)
+    K, n, p = 5, 6, 4
+    d = 2 * n
+    Phi, _ = quad_params(rng, K, n)
+    Qh = rng.normal(size=(K, n, n))
+    Qinv = 0.5 * (Qh + np.transpose(Qh, (0, 2, 1)))             # symmetric, indefinite
+    assert (np.linalg.eigvalsh(Qinv).min(axis=1) < 0).all() and (np.linalg.eigvalsh(Qinv).max(axis=1) > 0).all()
+    params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+    ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.3)
+    got = ctx.moments(sid, mu, Sigma)
+    cost = ctx.costs(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] == 6
+    ctx.close()
+    Z, w = oracle_table(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_quad_prior(Phi, Qinv), np.ones(K))
+    assert rel(got[0], r["E_phi"]) < TIGHT and rel(got[1], r["Vdmu"]) < TIGHT and rel(got[2], r["Vddmu"]) < 10 * TIGHT
+    assert rel(cost, r["cost"]) < TIGHT
+
+
 def test_asymmetric_user_table_keeps_the_unpaired_kernel():
     """gvi_factors_set_table with a table that is NOT mirror-symmetric (one weight perturbed): the +-pairing must not be
     used; results follow the oracle on that very table."""
@@ -995,6 +1074,7 @@ def test_asymmetric_user_table_keeps_the_unpaired_kernel():
     ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params)
     ctx.factors_set_table(sid, Z, w2)
     got = ctx.moments(sid, mu, Sigma)
+    assert ctx.profile_geometry(sid)["variant"] != 6           # nor the sign-orbit kernel: the orbit of row 3 has two weights
     ctx.close()
     ref = o.batched_moments(Z, w2, mu, Sigma, o.psi_batch_quad_prior(Phi, Qinv), np.ones(K))
     assert rel(got[0], ref["E_phi"]) < TIGHT and rel(got[1], ref["Vdmu"]) < TIGHT and rel(got[2], ref["Vddmu"]) < 10 * TIGHT
@@ -1156,17 +1236,25 @@ def test_c5_full_table_meets_the_bar_and_where_the_rounding_comes_from(monkeypat
             monkeypatch.setenv("GVI_SPGH_EXTENDED", extended)
         ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params)
         assert ctx.sets[sid][3] == 20557057
+        ctx.set_option("orbit", 0)
         for flush in (64, 0):
             ctx.set_option("split_flush", flush)
             Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
             cost = ctx.costs(sid, mu, Sigma)
             assert ctx.profile_geometry(sid)["variant"] == 3
             res[(label, flush)] = _closed_form_worst(Phi, Qinv, mu, Sigma, cost, Vdmu, Vddmu)
+        if extended is None:                                   # the default route: the sign-orbit kernel (plain sums)
+            ctx.set_option("orbit", 1)
+            Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+            cost = ctx.costs(sid, mu, Sigma)
+            assert ctx.profile_geometry(sid)["variant"] == 6
+            res[("shipped", "orbit")] = _closed_form_worst(Phi, Qinv, mu, Sigma, cost, Vdmu, Vddmu)
         ctx.close()
     monkeypatch.delenv("GVI_SPGH_EXTENDED", raising=False)
     print({k: {a: f"{b:.2e}" for a, b in v.items()} for k, v in res.items()})
     shipped = max(res[("shipped", 64)].values())
     assert shipped < RTOL / 5, res
+    assert max(res[("shipped", "orbit")].values()) < RTOL / 5, res
     assert max(res[("shipped", 0)].values()) < RTOL / 5                         # the device summation order is not the issue
     for flush in (64, 0):
         assert max(res[("double_merged_weights", flush)].values()) > 20 * shipped   # ... the double-merged weights are

@@ -3,15 +3,16 @@
 set -o pipefail
 mkdir -p gpurun_out/r02
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_cpp_shim.py -m gpu -x -q ${GVI_TEST_K:+-k "$GVI_TEST_K"} > gpurun_out/r02/pytest_orbit.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_cpp_shim.py -m gpu -q ${GVI_TEST_K:+-k "$GVI_TEST_K"} > gpurun_out/r02/pytest_orbit.log 2>&1; rc=$?
 tail -8 gpurun_out/r02/pytest_orbit.log
 [ $rc -ne 0 ] && exit $rc
-for w in 4096 8192 16384; do
-  GVI_ORBIT_WAVES=$w timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/r02/bench_orbit_w$w.json 2> gpurun_out/r02/bench_orbit.err || { tail -20 gpurun_out/r02/bench_orbit.err; exit 1; }
+for cfg in "4096 8" "8192 8" "4096 1" "4096 4" "4096 16" "2048 8"; do
+  set -- $cfg; w=$1; cp=$2
+  GVI_ORBIT_WAVES=$w GVI_ORBIT_COPIES=$cp timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/r02/bench_orbit_w${w}_c$cp.json 2> gpurun_out/r02/bench_orbit.err || { tail -20 gpurun_out/r02/bench_orbit.err; exit 1; }
   python - <<PY
 import json
-d=json.load(open("gpurun_out/r02/bench_orbit_w$w.json"))
-print("orbit waves $w: c3 ms/step", d["ms_per_step"], "kernel ms", d["moments_kernel"]["ms"], "frac", d["roofline"]["frac"], "final", d["final_cost"], "variant", d["config"]["kernel_variant"], "chunks", d["config"]["chunks_per_factor"])
+d=json.load(open("gpurun_out/r02/bench_orbit_w${w}_c$cp.json"))
+print("orbit waves $w copies $cp: c3 ms/step", d["ms_per_step"], "kernel ms", d["moments_kernel"]["ms"], "frac", d["roofline"]["frac"], "final", d["final_cost"], "variant", d["config"]["kernel_variant"], "chunks", d["config"]["chunks_per_factor"])
 PY
 done
 GVI_ORBIT=0 timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/r02/bench_orbit_off.json 2> gpurun_out/r02/bench_orbit.err || { tail -20 gpurun_out/r02/bench_orbit.err; exit 1; }
