@@ -47,6 +47,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
            "-I", os.path.join(ROOT, "include"),
            os.path.join(CSRC, "gvi_hip.hip"), "-x", "hip", os.path.join(CSRC, "spgh.cpp"), os.path.join(CSRC, "table_io.cpp"),
            "-o", tmp]
+    for define in os.environ.get("GVI_BUILD_DEFINES", "").split():      # profiling builds, e.g. GVI_BCR_TIMING
+        cmd.insert(1, "-D" + define)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -87,6 +87,7 @@ struct FactorSet {
   bool fused_pair = false;            // last resident launch went out fused with the other set
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   bool all_pos = false;               // every residual row has sgn = +1 (positive-definite weight)
+  double jtol = 1e-34;                // ctx->jacobi_tol
   bool use_mirror = true;             // evaluate +-pairs from the mirror-half table where the kernel supports it (ctx->mirror)
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
@@ -112,7 +113,7 @@ struct FactorSet {
     f.A = A.d(); f.b = b.d(); f.sgn = sgn.d(); f.raw = raw.d(); f.raw_stride = raw_stride;
     f.temperature = unit_temperature ? ones.d() : temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.Hq = Hq.p ? Hq.d() : nullptr; f.u0 = u0.d();
-    f.Vws = nullptr; f.warm = 0; f.jko_h = 0.0;
+    f.Vws = nullptr; f.warm = 0; f.jko_h = 0.0; f.jtol = jtol;
     f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz; f.arm = arm.p ? arm.d() : nullptr;
     return f;
   }
@@ -172,6 +173,9 @@ struct gvi_ctx {
   // lane-per-point kernels (A/B; results agree to rounding)
   bool orbit = true;
   int orbit_waves = 4096;             // waves the orbit launch of one set aims for (chunks = orbit_waves / K, <= tiles)
+  // prep: cyclic Jacobi stops when (sum of squared off-diagonals) <= jacobi_tol * (sum of squared diagonals); option
+  // "jacobi_tol_exp" / GVI_JACOBI_TOL_EXP sets 10^value
+  double jacobi_tol = 1e-34;
   int orbit_copies = 8;               // private LDS copies of the accumulators (1, 2, 4, 8, 16; fewer when LDS is short)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
@@ -771,7 +775,7 @@ gvi_status run_epilogue(gvi_ctx* c, FactorSet& s, int full, double* Ephi, double
   EpiArgs e;
   e.f = s.dev(); e.partial = s.partial.d(); e.nchunk = s.nchunk; e.full = full;
   e.Ephi = Ephi; e.cost = cost; e.Vdmu = Vdmu; e.Vddmu = Vddmu; e.E_xmuphi = Ex; e.E_xxphi = Exx;
-  const size_t lds = (size_t)(npairs(s.d) + 2 * s.d * s.d) * 8;
+  const size_t lds = epilogue_lds_doubles(s.d) * 8;
   hipLaunchKernelGGL(epilogue_kernel, dim3(s.K), dim3(64), lds, st, e);
   HIPCK(c, hipGetLastError());
   return GVI_OK;
@@ -1091,6 +1095,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
+  if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
   if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_ORBIT_COPIES")) c->orbit_copies = std::min(16, std::max(1, atoi(w)));
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
@@ -1234,6 +1239,7 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   HIPCK(ctx, hipSetDevice(ctx->device));
 
   std::unique_ptr<FactorSet> s(new FactorSet);
+  s->jtol = ctx->jacobi_tol;
   s->K = K; s->d = d; s->p = p; s->m = m; s->kind = psi_kind;
   if (K > 0) s->start.assign(start, start + K);
   // quadrature table: shared between sets with the same (d, p)
@@ -1769,7 +1775,7 @@ static EpiList make_epi_list(gvi_ctx* ctx, int full, int* dmax_out) {
 static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1) {
   int dmax = 0;
   const EpiList L = make_epi_list(ctx, full, &dmax);
-  const size_t lds = std::max<size_t>((size_t)(npairs(dmax) + 2 * dmax * dmax) * 8, 256 * 8);
+  const size_t lds = std::max<size_t>(epilogue_lds_doubles(dmax) * 8, 256 * 8);
   if (L.koff[L.nsets] == 0) return GVI_OK;
   EpiTail tail;
   tail.on = 0; tail.acc = nullptr; tail.half_logdet = nullptr; tail.host_out = nullptr; tail.seq = 0.0; tail.counter = nullptr;
@@ -2758,6 +2764,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "no_scost") ctx->no_scost = value != 0;
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);
   else if (n == "orbit") ctx->orbit = value != 0;
+  else if (n == "jacobi_tol_exp") { ctx->jacobi_tol = std::pow(10.0, (double)std::min(-20, value)); for (auto& s : ctx->sets) s->jtol = ctx->jacobi_tol; }
   else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);
   else if (n == "orbit_copies") ctx->orbit_copies = std::min(16, std::max(1, value));
   else return fail(ctx, GVI_ERR_ARG, "unknown option: " + n);
@@ -2767,6 +2774,17 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   ctx->ngd.spec_ready = false;
   return GVI_OK;
 }
+
+#ifdef GVI_BCR_TIMING
+// profiling build only (kernels_bcr_seg.hpp): the [6][64] shader-clock stamps of the last chain launches
+gvi_status gvi_debug_bcr_stamps(gvi_ctx* ctx, unsigned long long* out) {
+  if (!ctx || !out) return GVI_ERR_ARG;
+  HIPCK(ctx, hipDeviceSynchronize());
+  HIPCK(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(gvi_bcr_stamps), sizeof(unsigned long long) * 6 * 64));
+  HIPCK(ctx, hipMemcpyFromSymbol(out + 6 * 64, HIP_SYMBOL(gvi_bcr_stamps_elim), sizeof(unsigned long long) * 16));
+  return GVI_OK;
+}
+#endif
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
   if (!ctx || variant < 0 || variant > 6) return GVI_ERR_ARG;

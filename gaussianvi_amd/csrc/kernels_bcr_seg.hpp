@@ -28,6 +28,19 @@
 
 namespace gvi {
 
+// -DGVI_BCR_TIMING: constant-clock stamps (s_memrealtime, 100 MHz) of block 0 of every pass at its phase boundaries, read back with
+// gvi_debug_bcr_stamps -- a profiling aid for the latency-bound chain kernels, compiled out of the product build.
+#ifdef GVI_BCR_TIMING
+__device__ unsigned long long gvi_bcr_stamps[6][64];
+#define GVI_STAMP(slot, idx) do { if (bid == 0 && threadIdx.x == 0 && (idx) < 64) gvi_bcr_stamps[slot][idx] = wall_clock64(); } while (0)
+// inside seg_eliminate: shader-clock (s_memtime) stamps of wave 0 / block 0 at the second level of the factor's pass A
+__device__ unsigned long long gvi_bcr_stamps_elim[16];
+__device__ int gvi_bcr_dbg_on;
+#define GVI_ESTAMP(idx) do { if (gvi_bcr_dbg_on && threadIdx.x == 0) gvi_bcr_stamps_elim[idx] = clock64(); } while (0)
+#else
+#define GVI_STAMP(slot, idx) do { } while (0)
+#define GVI_ESTAMP(idx) do { } while (0)
+#endif
 
 struct SegArgs {
   int T, n;
@@ -76,6 +89,7 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
   constexpr int nn = N * N, NC = 4 * N + 1;
   const bool has_a = Ua != nullptr, has_b = Ub != nullptr, rhs = a.rhs != nullptr;
   const int cE = N, cA = a.need_E ? 2 * N : N, cB = cA + N, cY = cB + N;
+  GVI_ESTAMP(0);
   double col[N];
 #pragma unroll
   for (int r = 0; r < N; ++r) col[r] = 0.0;
@@ -99,6 +113,7 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
 #pragma unroll
     for (int r = 0; r < N; ++r) col[r] = y_e[r];
   }
+  GVI_ESTAMP(1);
   double pivs[N];
   int bad = 0;
 #pragma unroll
@@ -139,6 +154,7 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
       if (r != p) col[r] = fma(-ap[r], f, col[r]);
     col[p] = f;
   }
+  GVI_ESTAMP(2);
   if (a.hld && lane == 0) {
     // log-pivots only feed the log-det (factor calls).  The pivots are wave-uniform: keep their product as
     // (mantissa product, exponent sum) -- two instructions per pivot -- and take ONE log per node in the final
@@ -153,12 +169,14 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
     a.w.logp[x] = mp;                    // in [2^-N, 1) for positive pivots
     a.w.bad[x] = es * 2 + bad;           // exponent sum and the non-positive-pivot flag
   }
+  GVI_ESTAMP(3);
   // ---- park the reduced tile [I | E | GA | GB | v] in LDS, then finish element-wise on all lanes ----
   if (lane < NC) {
 #pragma unroll
     for (int r = 0; r < N; ++r) Tl[r * NC + lane] = col[r];
   }
   wave_lds_sync();
+  GVI_ESTAMP(4);
   for (int el = lane; el < nn; el += 64) {
     const int r = el / N, c = el % N;
     if (a.need_E) { const double ev = Tl[r * NC + cE + c]; a.w.E[(size_t)x * nn + el] = ev; if (Es) Es[el] = ev; }
@@ -184,6 +202,7 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
       if (has_a) { NUs[el] = -u; a.w.NU[(size_t)x * nn + el] = -u; }
     }
   }
+  GVI_ESTAMP(5);
   if (rhs && lane < N) {
     const int r = lane;
     { const double vv = Tl[r * NC + cY]; a.w.v[(size_t)x * N + r] = vv; if (vs) vs[r] = vv; }
@@ -203,6 +222,7 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
     }
   }
   wave_lds_sync();
+  GVI_ESTAMP(6);
 }
 
 // ---- backward step of one node: selected inverse (marginals) ----
@@ -252,14 +272,14 @@ __device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int le
   wave_lds_sync();
 }
 
-// Fold the pending updates of levels [prev0, level0) into node x's diagonal block / rhs (global reads).
-__device__ inline double seg_fold_D(const SegArgs& a, int x, int el) {
+// Fold the pending updates of levels [prev0, level0) into node x's diagonal block / rhs (global reads only: the
+// caller issues the loads of all its elements before the first use, then stores).
+__device__ __forceinline__ double seg_fold_D(const SegArgs& a, int x, int el) {
   const int nn = a.n * a.n;
   double v = (a.level0 == 0 ? a.D : a.w.Deff)[(size_t)x * nn + el];
-  if (a.level0 == 0 && a.mixVD) {
-    v = v + a.mix_step * (a.mixVD[(size_t)x * nn + el] - v);      // same arithmetic as trial_kernel
-    a.mixOutD[(size_t)x * nn + el] = v;
-  }
+  double mv = 0.0;
+  const bool mix = a.level0 == 0 && a.mixVD;
+  if (mix) mv = a.mixVD[(size_t)x * nn + el];
   // at most 5 levels per pass (seg_plan): a fixed-trip, fully unrolled loop keeps the (independent)
   // loads in flight together instead of one global round trip per level
   double cr[5], cl[5];
@@ -270,6 +290,7 @@ __device__ inline double seg_fold_D(const SegArgs& a, int x, int el) {
     cr[q] = (on && x - h >= 0) ? a.w.CR[(size_t)(x - h) * nn + el] : 0.0;
     cl[q] = (on && x + h < a.T) ? a.w.CL[(size_t)(x + h) * nn + el] : 0.0;
   }
+  if (mix) v = v + a.mix_step * (mv - v);                         // same arithmetic as trial_kernel
 #pragma unroll
   for (int q = 0; q < 5; ++q) { v -= cr[q]; v -= cl[q]; }
   return v;
@@ -298,6 +319,9 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
   const bool rhs = a.rhs != nullptr;
   const int x0 = bid * S * st;
+  [[maybe_unused]] const int tslot = (rhs ? 3 : 0) + (a.top ? 1 : 0);
+  [[maybe_unused]] int tix = 0;
+  GVI_STAMP(tslot, tix++);
   double* Dl = sm;                    // [S][nn] effective diagonal blocks
   double* Cl = Dl + S * nn;           // [S][nn] coupling A[x_j, x_{j+1}] at this pass's spacing
   double* NUl = Cl + S * nn;          // [S][nn] new couplings, indexed by the eliminated node
@@ -318,18 +342,40 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
   for (int j = 0; j < S; ++j) if (x0 + j * st < T) cnt = j + 1;
   const bool ext_right = x0 + S * st < T;          // the next segment's first node exists
   // ---- load + fold ----
-  for (int e = tid; e < cnt * nn; e += blockDim.x) {
-    const int j = e / nn, el = e % nn, x = x0 + j * st;
-    const double v = seg_fold_D(a, x, el);
-    Dl[e] = v;
-    if (j == 0 && !a.top) a.w.Deff[(size_t)x * nn + el] = v;      // the survivor's base for the next pass
-    if (x + st < T) {
-      double cu = (a.level0 == 0 ? a.U + (size_t)x * nn : a.w.NU + (size_t)(x + st / 2) * nn)[el];
-      if (a.level0 == 0 && a.mixVU) {
-        cu = cu + a.mix_step * (a.mixVU[(size_t)x * nn + el] - cu);
-        a.mixOutU[(size_t)x * nn + el] = cu;
+  // Two elements per thread and round (S nn <= 2 blockDim for the shipped plans): every global load of the round is
+  // issued before the first result is used, so the phase costs one memory round trip instead of one per element.
+  for (int e0 = tid; e0 < cnt * nn; e0 += 2 * blockDim.x) {
+    double dv[2], cu[2];
+    bool on[2], hasc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = e0 + u * (int)blockDim.x;
+      on[u] = e < cnt * nn;
+      hasc[u] = false;
+      dv[u] = cu[u] = 0.0;
+      if (on[u]) {
+        const int j = e / nn, el = e % nn, x = x0 + j * st;
+        dv[u] = seg_fold_D(a, x, el);
+        hasc[u] = x + st < T;
+        if (hasc[u]) {
+          cu[u] = (a.level0 == 0 ? a.U + (size_t)x * nn : a.w.NU + (size_t)(x + st / 2) * nn)[el];
+          if (a.level0 == 0 && a.mixVU) cu[u] = cu[u] + a.mix_step * (a.mixVU[(size_t)x * nn + el] - cu[u]);
+        }
       }
-      Cl[e] = cu;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = e0 + u * (int)blockDim.x;
+      if (on[u]) {
+        const int j = e / nn, el = e % nn, x = x0 + j * st;
+        Dl[e] = dv[u];
+        if (a.level0 == 0 && a.mixVD) a.mixOutD[(size_t)x * nn + el] = dv[u];
+        if (j == 0 && !a.top) a.w.Deff[(size_t)x * nn + el] = dv[u];      // the survivor's base for the next pass
+        if (hasc[u]) {
+          Cl[e] = cu[u];
+          if (a.level0 == 0 && a.mixVU) a.mixOutU[(size_t)x * nn + el] = cu[u];
+        }
+      }
     }
   }
   if (rhs) {
@@ -341,12 +387,16 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
     }
   }
   __syncthreads();
+  GVI_STAMP(tslot, tix++);
   // ---- m local levels ----
   for (int lam = 0; lam < a.m; ++lam) {
     const int h2 = 1 << lam;
     // eliminated local nodes: odd multiples of h2 that exist
     int nel = 0;
     for (int j = h2; j < cnt; j += 2 * h2) ++nel;
+#ifdef GVI_BCR_TIMING
+    if (bid == 0 && tid == 0) gvi_bcr_dbg_on = (tslot == 0 && lam == 1) ? 1 : 0;
+#endif
     for (int u = wave; u < nel; u += nwaves) {
       const int j = (2 * u + 1) * h2, x = x0 + j * st;
       const int ja = j - h2, jb = j + h2;
@@ -359,6 +409,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
                               a.top ? GBl + j * nn : nullptr, (a.top && rhs) ? vl + j * N : nullptr, lane);
     }
     lds_barrier();
+    GVI_STAMP(tslot, tix++);
     // eager update of the local survivors of this level (node 0 only in the top pass: elsewhere its
     // left-hand updates live in another segment, so it folds both sides from global in the next pass)
     const int first = a.top ? 0 : 2 * h2;
@@ -378,6 +429,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
       }
     }
     lds_barrier();
+    GVI_STAMP(tslot, tix++);
   }
   if (!a.top) return;
   // ---- root (node 0), log-det ----
@@ -385,6 +437,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
     seg_eliminate<PIVOT, N>(a, 0, Dl, nullptr, nullptr, yl, CLl, CRl, NUl, yLl, yRl, scratch, El, GAl, GBl,
                             rhs ? vl : nullptr, lane);
   lds_barrier();                                     // the factors of these nodes live in LDS (El, GAl, GBl, vl)
+  GVI_STAMP(tslot, tix++);
   if (a.hld) {                                       // 1/2 sum of the log-pivots of ALL nodes (every pass)
     int* redb = (int*)(red + 64);
     double s = 0.0;
@@ -406,6 +459,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
     }
     lds_barrier();
   }
+  GVI_STAMP(tslot, tix++);
   // ---- backward recursion for the nodes of this pass ----
   if (rhs) {                                          // solve: x_e = v - GA x_a - GB x_b
     if (tid < N) { const double v = vl[tid]; xl[tid] = v; a.x[tid] = v; }
@@ -428,6 +482,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
         a.x[(size_t)x * N + r] = xe;
       }
       lds_barrier();
+      GVI_STAMP(tslot, tix++);
     }
   } else if (a.need_E) {                              // selected inverse
     double* Sgl = Dl;                                 // [S][nn] Sig_jj          (forward arrays are dead)
@@ -450,6 +505,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
                              SRl + j * nn, lane);
       }
       lds_barrier();
+      GVI_STAMP(tslot, tix++);
     }
   }
 }
@@ -486,6 +542,9 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
   for (int j = 0; j < S; ++j) if (x0 + j * st < T) cnt = j + 1;
   const int xn = x0 + S * st;                         // the next segment's first node (slot S)
   const bool ext_right = xn < T;
+  [[maybe_unused]] const int tslot = rhs ? 5 : 2;
+  [[maybe_unused]] int tix = 0;
+  GVI_STAMP(tslot, tix++);
   if (rhs) {
     double* xl = sm;                                  // [S+1][N]
     double* vl = xl + (S + 1) * N;                    // [S][N]
@@ -502,6 +561,7 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
     if (tid < N) xl[tid] = a.x[(size_t)x0 * N + tid];
     if (ext_right && tid >= 64 && tid < 64 + N) xl[S * N + tid - 64] = a.x[(size_t)xn * N + tid - 64];
     __syncthreads();
+    GVI_STAMP(tslot, tix++);
     for (int lam = a.m - 1; lam >= 0; --lam) {
       const int h2 = 1 << lam;
       int nel = 0;
@@ -521,6 +581,7 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
         a.x[(size_t)x * N + r] = xe;
       }
       lds_barrier();
+      GVI_STAMP(tslot, tix++);
     }
     return;
   }
@@ -533,12 +594,23 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
   // Sig[x0, xn]: the two are adjacent at level level0 + m; the odd one was eliminated there
   const int lvl_up = a.level0 + a.m;
   const bool x0_odd = ext_right && (((x0 >> lvl_up) & 1) != 0);
-  for (int e = tid; e < cnt * nn; e += blockDim.x) {
-    const int j = e / nn, el = e % nn, x = x0 + j * st;
-    if (j > 0) {
-      El[e] = a.w.E[(size_t)x * nn + el];
-      GAl[e] = a.w.GA[(size_t)x * nn + el];
-      GBl[e] = a.w.GB[(size_t)x * nn + el];      // unused garbage when the node had no right neighbour
+  for (int e0 = tid; e0 < cnt * nn; e0 += 2 * blockDim.x) {      // two elements per round: one memory round trip
+    double ev[2], gav[2], gbv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = e0 + u * (int)blockDim.x;
+      const int j = e / nn, el = e % nn, x = x0 + j * st;
+      ev[u] = gav[u] = gbv[u] = 0.0;
+      if (e < cnt * nn && j > 0) {
+        ev[u] = a.w.E[(size_t)x * nn + el];
+        gav[u] = a.w.GA[(size_t)x * nn + el];
+        gbv[u] = a.w.GB[(size_t)x * nn + el];      // unused garbage when the node had no right neighbour
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = e0 + u * (int)blockDim.x;
+      if (e < cnt * nn && e >= nn) { El[e] = ev[u]; GAl[e] = gav[u]; GBl[e] = gbv[u]; }
     }
   }
   for (int el = tid; el < nn; el += blockDim.x) {
@@ -550,6 +622,7 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
     }
   }
   __syncthreads();
+  GVI_STAMP(tslot, tix++);
   for (int lam = a.m - 1; lam >= 0; --lam) {
     const int h2 = 1 << lam;
     int nel = 0;
@@ -572,6 +645,7 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
                            SRl + j * nn, lane);
     }
     lds_barrier();
+    GVI_STAMP(tslot, tix++);
   }
 }
 

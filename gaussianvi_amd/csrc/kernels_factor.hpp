@@ -79,6 +79,7 @@ struct FactorDev {
   double sdf_ox, sdf_oy, sdf_oz, sdf_cell;
   const double* arm;        // HINGE_SDF_3D_ARM: [ndof, ns, a[ndof], alpha[ndof], d[ndof], bias[ndof], frame[ns], centre[ns][3], radius[ns]]
   double jko_h;             // > 0: the third spectral output is the JKO map 1 / (l/2 + h + sqrt(l (l + 4h))/2) instead of 1/l
+  double jtol;              // Jacobi stops when off^2 <= jtol * diag^2 (sums of squares)
   double* Vws;              // [K][d][d] eigenvectors of the previous prep (warm start) or null
   int warm;                 // 1: start the Jacobi sweeps from Vws (resident NGD iteration only)
 };
@@ -105,11 +106,13 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-template <int EPLP>   // elements of the d x d block per lane: 1 (d <= 8), 4 (d <= 16), 16 (d <= 32)
+// DT: d at compile time (the d-long inner products unroll and their loads -- LDS, and the GLOBAL rows of A_k in the H = A S
+// product -- are issued together instead of one dependent round trip per term) or 0 for any d
+template <int EPLP, int DT>   // EPLP: elements of the d x d block per lane: 1 (d <= 8), 4 (d <= 16), 16 (d <= 32)
 // kin: index of the factor inside the (mu, Sigma) INPUT arrays (== k, or 0 when the caller staged this factor's
 // marginal in LDS); outputs always go to slot k
 __device__ inline void prep_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
-  const int d = f.d, dd = d * d, lane = threadIdx.x;
+  const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x;
   const int dp = d + (d & 1);
   double* A0 = sm;
   double* A1 = A0 + dd;
@@ -152,6 +155,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
         if (ei[q] >= 0) {
           const int i = ei[q], j = ej[q];
           double t = 0.0;
+#pragma unroll
           for (int c = 0; c < d; ++c) t += A1[i * d + c] * V0[c * d + j];
           V1[lane + q * 64] = t;
         }
@@ -162,6 +166,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
         if (ei[q] >= 0) {
           const int i = ei[q] <= ej[q] ? ei[q] : ej[q], j = ei[q] <= ej[q] ? ej[q] : ei[q];
           double t = 0.0;
+#pragma unroll
           for (int c = 0; c < d; ++c) t += V0[c * d + i] * V1[c * d + j];
           A0[lane + q * 64] = t;
         }
@@ -191,7 +196,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
     }
     off = wave_sum(off);
     dg = wave_sum(dg);
-    if (off <= 1e-34 * dg) break;      // false for NaN input: runs the (bounded) 40 sweeps
+    if (off <= f.jtol * dg) break;     // false for NaN input: runs the (bounded) 40 sweeps
     for (int r = 0; r < dp - 1; ++r) {
       if (lane < dp / 2) {
         int p, q;
@@ -255,6 +260,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
     if (ei[q] >= 0) {
       const int i = ei[q], j = ej[q], e = lane + q * 64;
       double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
       for (int c = 0; c < d; ++c) {
         const double vv = V[i * d + c] * V[j * d + c];
         s0 += vv * lam[c]; s1 += vv * lam[d + c]; s2 += vv * lam[2 * d + c];
@@ -273,6 +279,7 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
     for (int e = lane; e < m * d; e += 64) {
       const int r = e / d, a = e % d;
       double h = 0.0;
+#pragma unroll
       for (int c = 0; c < d; ++c) h += Ak[r * d + c] * An[c * d + a];
       f.H[(size_t)k * m * d + a * m + r] = h;            // column-major [d][m]: a column's m entries contiguous
       if (f.Hq) {
@@ -282,17 +289,27 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
     }
     if (lane < m) {
       double u = f.b[(size_t)k * m + lane];
+#pragma unroll
       for (int c = 0; c < d; ++c) u += Ak[lane * d + c] * mu[(size_t)kin * d + c];
       f.u0[(size_t)k * m + lane] = u;
     }
   }
 }
 
+// the chain shapes of BASELINE.json get unrolled instances
+template <int EPLP>
+__device__ inline void prep_body_d(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
+  if (EPLP == 1 && f.d == 6) prep_body<EPLP, 6>(f, mu, Sigma, k, sm, kin);
+  else if (EPLP == 4 && f.d == 6) prep_body<EPLP, 6>(f, mu, Sigma, k, sm, kin);
+  else if (EPLP == 4 && f.d == 12) prep_body<EPLP, 12>(f, mu, Sigma, k, sm, kin);
+  else prep_body<EPLP, 0>(f, mu, Sigma, k, sm, kin);
+}
+
 template <int EPLP>
 __global__ __launch_bounds__(64) void prep_kernel(FactorDev f, const double* __restrict__ mu,
                                                   const double* __restrict__ Sigma) {
   extern __shared__ double sm[];
-  prep_body<EPLP>(f, mu, Sigma, blockIdx.x, sm, blockIdx.x);
+  prep_body_d<EPLP>(f, mu, Sigma, blockIdx.x, sm, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(64) void prep_all_kernel(PrepList L) {
   int si = 0;
   while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
   const int k = (int)blockIdx.x - L.koff[si];
-  if (!L.gather) { prep_body<EPLP>(L.f[si], L.mu[si], L.Sigma[si], k, sm, k); return; }
+  if (!L.gather) { prep_body_d<EPLP>(L.f[si], L.mu[si], L.Sigma[si], k, sm, k); return; }
   const FactorDev& f = L.f[si];
   const int d = f.d, dd = d * d, dp = d + (d & 1), n = L.n, nn = n * n;
   double* Sl = sm + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;  // behind prep_body's own LDS
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(64) void prep_all_kernel(PrepList L) {
     L.mu_k[si][(size_t)k * d + e] = v;
   }
   wave_lds_sync();
-  prep_body<EPLP>(f, ml, Sl, k, sm, 0);
+  prep_body_d<EPLP>(f, ml, Sl, k, sm, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1781,18 +1798,40 @@ struct EpiArgs {
   double* E_xxphi;         // [K][d][d] or null
 };
 
-// returns the factor's cost E[psi] / T_k (wave-uniform)
-__device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
+// LDS doubles of the epilogue: packed moments, M2, one product, and the factor's Sinv / Lam (or S) staged once
+__host__ __device__ inline size_t epilogue_lds_doubles(int d) { return (size_t)npairs(d) + 4 * (size_t)d * d; }
+
+// returns the factor's cost E[psi] / T_k (wave-uniform).
+// DT = d at compile time (inner products fully unrolled: their LDS loads pipeline) or 0 (any d).  The operands of the
+// back-transform (Sinv, Lam; S for the raw integrals) are fetched into LDS in one round trip at the top -- with the
+// loads inside the d-long inner loops every product paid d dependent global round trips (profiles/r02_e: 15 us for
+// what is ~2 us of arithmetic).  Summation orders are unchanged (c ascending, chunk index ascending).
+template <int DT>
+__device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm) {
   const FactorDev& f = a.f;
-  const int d = f.d, dd = d * d, lane = threadIdx.x;
+  const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x;
   const int npo = a.full ? npairs(d) : 1;
   double* Ms = sm;              // [npo]
   double* M2 = Ms + npairs(d);  // [d][d]
   double* Tm = M2 + dd;         // [d][d]
+  double* Sv = Tm + dd;         // [d][d] Sinv
+  double* Lv = Sv + dd;         // [d][d] Lam
   const double* P = a.partial + (size_t)k * a.nchunk * npo;
+  const bool want_v = a.full && (a.Vdmu || a.Vddmu);
+  if (want_v) {
+    const double* Sinv = f.Sinv + (size_t)k * dd;
+    const double* Lam = f.Lam + (size_t)k * dd;
+    for (int e = lane; e < dd; e += 64) { Sv[e] = Sinv[e]; Lv[e] = Lam[e]; }
+  }
   for (int j = lane; j < npo; j += 64) {
     double s = 0.0;
-    for (int c = 0; c < a.nchunk; ++c) s += P[(size_t)c * npo + j];   // fixed order: deterministic
+    for (int c0 = 0; c0 < a.nchunk; c0 += 8) {                   // eight loads in flight, then the ordered sum
+      double pv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pv[q] = c0 + q < a.nchunk ? P[(size_t)(c0 + q) * npo + j] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += pv[q];                    // fixed order (x + 0.0 == x): deterministic
+    }
     Ms[j] = s;
   }
   wave_lds_sync();
@@ -1809,13 +1848,11 @@ __device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
     M2[e] = i <= j ? Ms[pair_index(d, i, j)] : Ms[pair_index(d, j, i)];
   }
   wave_lds_sync();
-  const double* Sinv = f.Sinv + (size_t)k * dd;
-  const double* Lam = f.Lam + (size_t)k * dd;
-  const double* S = f.S + (size_t)k * dd;
   if (a.Vdmu) {
     for (int i = lane; i < d; i += 64) {
       double s = 0.0;
-      for (int c = 0; c < d; ++c) s += Sinv[i * d + c] * Ms[1 + c];
+#pragma unroll
+      for (int c = 0; c < d; ++c) s += Sv[i * d + c] * Ms[1 + c];
       a.Vdmu[(size_t)k * d + i] = s / Tk;
     }
   }
@@ -1823,7 +1860,8 @@ __device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
     for (int e = lane; e < dd; e += 64) {
       const int i = e / d, j = e % d;
       double s = 0.0;
-      for (int c = 0; c < d; ++c) s += Sinv[i * d + c] * M2[c * d + j];
+#pragma unroll
+      for (int c = 0; c < d; ++c) s += Sv[i * d + c] * M2[c * d + j];
       Tm[e] = s;
     }
     wave_lds_sync();
@@ -1831,18 +1869,25 @@ __device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
       const int i = e / d, j = e % d;
       if (i <= j) {           // upper triangle, mirrored (ngd/NGDFactorizedBaseGH.h:71-72)
         double s = 0.0;
-        for (int c = 0; c < d; ++c) s += Tm[i * d + c] * Sinv[c * d + j];
-        const double v = (s - Lam[i * d + j] * m0) / Tk;
+#pragma unroll
+        for (int c = 0; c < d; ++c) s += Tm[i * d + c] * Sv[c * d + j];
+        const double v = (s - Lv[i * d + j] * m0) / Tk;
         a.Vddmu[(size_t)k * dd + i * d + j] = v;
         a.Vddmu[(size_t)k * dd + j * d + i] = v;
       }
     }
     wave_lds_sync();
   }
+  if (a.E_xmuphi || a.E_xxphi) {
+    const double* S = f.S + (size_t)k * dd;
+    for (int e = lane; e < dd; e += 64) Sv[e] = S[e];            // Sinv is dead: reuse its slot
+    wave_lds_sync();
+  }
   if (a.E_xmuphi) {
     for (int i = lane; i < d; i += 64) {
       double s = 0.0;
-      for (int c = 0; c < d; ++c) s += S[i * d + c] * Ms[1 + c];
+#pragma unroll
+      for (int c = 0; c < d; ++c) s += Sv[i * d + c] * Ms[1 + c];
       a.E_xmuphi[(size_t)k * d + i] = s;
     }
   }
@@ -1850,18 +1895,29 @@ __device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
     for (int e = lane; e < dd; e += 64) {
       const int i = e / d, j = e % d;
       double s = 0.0;
-      for (int c = 0; c < d; ++c) s += S[i * d + c] * M2[c * d + j];
+#pragma unroll
+      for (int c = 0; c < d; ++c) s += Sv[i * d + c] * M2[c * d + j];
       Tm[e] = s;
     }
     wave_lds_sync();
     for (int e = lane; e < dd; e += 64) {
       const int i = e / d, j = e % d;
       double s = 0.0;
-      for (int c = 0; c < d; ++c) s += Tm[i * d + c] * S[j * d + c];
+#pragma unroll
+      for (int c = 0; c < d; ++c) s += Tm[i * d + c] * Sv[j * d + c];
       a.E_xxphi[(size_t)k * dd + e] = s;
     }
   }
   return costk;
+}
+
+// the chain shapes of BASELINE.json get unrolled instances; everything else runs the runtime-d body
+__device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
+  switch (a.f.d) {
+    case 6: return epilogue_body_t<6>(a, k, sm);
+    case 12: return epilogue_body_t<12>(a, k, sm);
+    default: return epilogue_body_t<0>(a, k, sm);
+  }
 }
 
 __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
