@@ -88,6 +88,8 @@ struct FactorSet {
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   bool all_pos = false;               // every residual row has sgn = +1 (positive-definite weight)
   double jtol = 1e-34;                // ctx->jacobi_tol
+  bool use_chol = true;               // ctx->chol_sqrt
+  bool force_sym = false;             // set around passes whose caller sees the sigma points
   bool use_mirror = true;             // evaluate +-pairs from the mirror-half table where the kernel supports it (ctx->mirror)
   int prep_slot = -1;                 // NGD slot whose (mu_k, Sigma_k) the per-pass products belong to
   hipStream_t st = nullptr;           // the set's own stream: prep -> moments -> epilogue overlap across sets
@@ -114,6 +116,11 @@ struct FactorSet {
     f.temperature = unit_temperature ? ones.d() : temperature.d();
     f.S = S.d(); f.Sinv = Sinv.d(); f.Lam = Lam.d(); f.H = H.d(); f.Hq = Hq.p ? Hq.d() : nullptr; f.u0 = u0.d();
     f.Vws = nullptr; f.warm = 0; f.jko_h = 0.0; f.jtol = jtol;
+    // Cholesky factor instead of the symmetric root: sum-of-squares psi on a generated table of degree >= 3 (exact
+    // quadrature -- kernels_factor.hpp, prep_chol_body), the instantiated dimensions, and not when the caller is going
+    // to look at the sigma points themselves (force_sym: gvi_expand / gvi_moments_from_psi) or runs the JKO map
+    f.chol = (use_chol && !force_sym && (kind == KIND_QUAD_PRIOR || kind == KIND_FIXED_PRIOR) && table->p >= 3 &&
+              (d == 4 || d == 6 || d == 8 || d == 12)) ? 1 : 0;
     f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz; f.arm = arm.p ? arm.d() : nullptr;
     return f;
   }
@@ -176,6 +183,9 @@ struct gvi_ctx {
   // prep: cyclic Jacobi stops when (sum of squared off-diagonals) <= jacobi_tol * (sum of squared diagonals); option
   // "jacobi_tol_exp" / GVI_JACOBI_TOL_EXP sets 10^value
   double jacobi_tol = 1e-34;
+  // sum-of-squares sets: per-pass products from the Cholesky factor of the marginal instead of its symmetric square root
+  // (same moments -- the quadrature is exact there -- without the Jacobi sweeps); GVI_CHOL_SQRT=0 / option "chol_sqrt"
+  bool chol_sqrt = true;
   int orbit_copies = 8;               // private LDS copies of the accumulators (1, 2, 4, 8, 16; fewer when LDS is short)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
@@ -1095,6 +1105,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
+  if (const char* w = getenv("GVI_CHOL_SQRT")) c->chol_sqrt = atoi(w) != 0;
   if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
   if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_ORBIT_COPIES")) c->orbit_copies = std::min(16, std::max(1, atoi(w)));
@@ -1240,6 +1251,7 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
 
   std::unique_ptr<FactorSet> s(new FactorSet);
   s->jtol = ctx->jacobi_tol;
+  s->use_chol = ctx->chol_sqrt;
   s->K = K; s->d = d; s->p = p; s->m = m; s->kind = psi_kind;
   if (K > 0) s->start.assign(start, start + K);
   // quadrature table: shared between sets with the same (d, p)
@@ -1532,7 +1544,10 @@ gvi_status gvi_expand(gvi_ctx* ctx, int set_id, const double* mu, const double* 
   GVICK(upload_pass_inputs(ctx, s, mu, Sigma));
   const size_t bytes = (size_t)s->K * s->d * s->table->N * 8;
   HIPCK(ctx, s->X.ensure(bytes));
-  GVICK(run_prep(ctx, *s, s->in_mu.d(), s->in_Sigma.d()));
+  s->force_sym = true;                                       // the caller sees the nodes: the reference's symmetric root
+  const gvi_status pst = run_prep(ctx, *s, s->in_mu.d(), s->in_Sigma.d());
+  s->force_sym = false;
+  GVICK(pst);
   hipLaunchKernelGGL(expand_kernel, dim3((unsigned)((s->table->N + 255) / 256), s->K), dim3(256), 0, ctx->stream,
                      s->dev(), s->in_mu.d(), s->X.d());
   HIPCK(ctx, hipGetLastError());
@@ -1550,9 +1565,12 @@ gvi_status gvi_moments_from_psi(gvi_ctx* ctx, int set_id, const double* mu, cons
   const size_t bytes = (size_t)s->K * s->table->N * 8;
   HIPCK(ctx, s->psi_ext.ensure(bytes));
   GVICK(h2d(ctx, s->psi_ext.p, psi, bytes));
-  GVICK(run_prep(ctx, *s, s->in_mu.d(), s->in_Sigma.d()));
-  GVICK(run_moments(ctx, *s, s->in_mu.d(), s->psi_ext.d(), 1));
-  GVICK(run_epilogue(ctx, *s, 1, s->Ephi.d(), nullptr, s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr));
+  s->force_sym = true;                                       // psi was evaluated at the reference's nodes (gvi_expand)
+  gvi_status pst = run_prep(ctx, *s, s->in_mu.d(), s->in_Sigma.d());
+  if (pst == GVI_OK) pst = run_moments(ctx, *s, s->in_mu.d(), s->psi_ext.d(), 1);
+  if (pst == GVI_OK) pst = run_epilogue(ctx, *s, 1, s->Ephi.d(), nullptr, s->Vdmu.d(), s->Vddmu.d(), nullptr, nullptr);
+  s->force_sym = false;
+  GVICK(pst);
   if (Ephi) GVICK(d2h(ctx, Ephi, s->Ephi.p, (size_t)s->K * 8));
   if (Vdmu) GVICK(d2h(ctx, Vdmu, s->Vdmu.p, (size_t)s->K * s->d * 8));
   if (Vddmu) GVICK(d2h(ctx, Vddmu, s->Vddmu.p, (size_t)s->K * s->d * s->d * 8));
@@ -2518,6 +2536,7 @@ gvi_status gvi_prox_gradients(gvi_ctx* ctx, double h) {
     FactorDev f = s.dev();                                 // spectral map of Sig_half into scratch (no psi operands)
     f.m = 0; f.S = s.jko_S.d(); f.Sinv = s.jko_Sinv.d(); f.Lam = s.jko_Lam.d(); f.H = nullptr; f.Hq = nullptr; f.u0 = nullptr;
     f.jko_h = h;
+    f.chol = 0;                                            // the JKO map is a function of the eigenvalues
     const int dp = s.d + (s.d & 1);
     const size_t lds = (size_t)(4 * dd + 2 * dp + 3 * d) * 8 + (size_t)dp * 4 + 16;
     if (s.d <= 8) hipLaunchKernelGGL(prep_kernel<1>, dim3(s.K), dim3(64), lds, ctx->stream, f, (const double*)nullptr, (const double*)s.jko_half.d());
@@ -2764,6 +2783,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "no_scost") ctx->no_scost = value != 0;
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);
   else if (n == "orbit") ctx->orbit = value != 0;
+  else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") { ctx->jacobi_tol = std::pow(10.0, (double)std::min(-20, value)); for (auto& s : ctx->sets) s->jtol = ctx->jacobi_tol; }
   else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);
   else if (n == "orbit_copies") ctx->orbit_copies = std::min(16, std::max(1, value));

@@ -80,6 +80,10 @@ struct FactorDev {
   const double* arm;        // HINGE_SDF_3D_ARM: [ndof, ns, a[ndof], alpha[ndof], d[ndof], bias[ndof], frame[ns], centre[ns][3], radius[ns]]
   double jko_h;             // > 0: the third spectral output is the JKO map 1 / (l/2 + h + sqrt(l (l + 4h))/2) instead of 1/l
   double jtol;              // Jacobi stops when off^2 <= jtol * diag^2 (sums of squares)
+  // 1: S is the Cholesky factor L of Sigma instead of its symmetric square root (prep_chol_body), the Sinv slot holds
+  // L^-T.  Only for sum-of-squares psi on a degree >= 3 table, where the quadrature of psi {1, z, z z^T} is exact and
+  // the moments do not depend on WHICH factor S S^T = Sigma maps the nodes (host: FactorSet::dev).
+  int chol;
   double* Vws;              // [K][d][d] eigenvectors of the previous prep (warm start) or null
   int warm;                 // 1: start the Jacobi sweeps from Vws (resident NGD iteration only)
 };
@@ -296,9 +300,112 @@ __device__ inline void prep_body(const FactorDev& f, const double* mu, const dou
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// prep_chol_body: the per-pass products from a CHOLESKY factor, one wave per factor, rows in registers.
+//
+// The reference maps the sigma points with the symmetric square root of Sigma (gvibase/GVIFactorizedBaseGH.h:
+// updateGH -> SparseGaussHermite::update_sigmapoints, an Eigen self-adjoint eigen-decomposition) -- here a cyclic
+// Jacobi solve of ~15 us per pass at d = 12.  For psi = sum_r s_r (A x + b)_r^2 the integrands psi, z psi, z z^T psi are
+// polynomials of degree <= 4 in z, which a sparse Gauss-Hermite rule of degree >= 3 integrates EXACTLY: the moments
+// E[psi], E[(x - mu) psi], E[(x - mu)(x - mu)^T psi] are then the same for every S with S S^T = Sigma (they are
+// functions of (mu, Sigma) alone), and the back-transform only needs S^-T and Sigma^-1:
+//     Vdmu = S^-T m1 / T,   Vddmu = (S^-T M2 S^-1 - Sigma^-1 m0) / T.
+// So for these sets S = L (Sigma = L L^T): 66 multiply-adds per triangle at d = 12 instead of Jacobi sweeps, and the
+// results agree with the symmetric-root route to rounding (tests/test_gpu_parity.py A/Bs the two; option "chol_sqrt").
+// Every psi kind that is NOT a polynomial of degree <= 2 (hinge / range factors, host-evaluated psi, gvi_expand) keeps
+// the symmetric root: there the node positions matter.  A non-positive pivot gives NaN exactly where a negative
+// eigenvalue did (the line search rejects such a trial either way).
+// lane i < d owns row i of the lower triangle; pivots / multipliers travel as wave-uniform scalars (v_readlane).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double chol_readlane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+template <int DT>
+__device__ inline void prep_chol_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
+  constexpr int d = DT, dd = DT * DT;
+  const int lane = threadIdx.x;
+  double* Ll = sm;            // [d][d] L, zeros above the diagonal
+  double* Xl = Ll + dd;       // [d][d] X = L^-1
+  const double* Sg = Sigma + (size_t)kin * dd;
+  const int li = lane < d ? lane : d - 1;                     // lanes >= d shadow the last row (results unused)
+  double row[DT];
+#pragma unroll
+  for (int c = 0; c < d; ++c) row[c] = c <= li ? Sg[li * d + c] : 0.0;      // lower triangle, like SelfAdjointEigenSolver
+  double inv[DT];
+#pragma unroll
+  for (int j = 0; j < d; ++j) {
+    const double pj = chol_readlane(row[j], j);
+    double r = __builtin_amdgcn_rsq(pj);                      // 1 / sqrt(pj): NaN for a negative pivot
+    r = r * fma(-0.5 * pj * r, r, 1.5);
+    r = r * fma(-0.5 * pj * r, r, 1.5);
+    inv[j] = r;
+    row[j] = li == j ? pj * r : (li > j ? row[j] * r : 0.0);
+#pragma unroll
+    for (int c = j + 1; c < d; ++c) {
+      const double lcj = chol_readlane(row[j], c);
+      row[c] = li >= c ? fma(-row[j], lcj, row[c]) : 0.0;
+    }
+  }
+  // X = L^-1 by forward substitution: lane c owns column c
+  double xcol[DT];
+#pragma unroll
+  for (int i = 0; i < d; ++i) {
+    double sacc = li == i ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < i; ++q) sacc = fma(-chol_readlane(row[q], i), xcol[q], sacc);
+    xcol[i] = li <= i ? sacc * inv[i] : 0.0;
+  }
+  if (lane < d) {
+#pragma unroll
+    for (int c = 0; c < d; ++c) { Ll[lane * d + c] = row[c]; Xl[c * d + lane] = xcol[c]; }
+  }
+  wave_lds_sync();
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    double lam = 0.0;
+#pragma unroll
+    for (int c = 0; c < d; ++c) lam = fma(Xl[c * d + i], Xl[c * d + j], lam);      // Sigma^-1 = X^T X
+    f.S[(size_t)k * dd + e] = Ll[e];
+    f.Sinv[(size_t)k * dd + e] = Xl[j * d + i];                                      // S^-T = X^T
+    f.Lam[(size_t)k * dd + e] = lam;
+  }
+  if (f.m > 0) {
+    const int m = f.m;
+    const double* Ak = f.A + (size_t)k * m * d;
+    for (int e = lane; e < m * d; e += 64) {
+      const int r = e / d, a = e % d;
+      double h = 0.0;
+#pragma unroll
+      for (int c = 0; c < d; ++c) h += Ak[r * d + c] * Ll[c * d + a];
+      f.H[(size_t)k * m * d + a * m + r] = h;            // column-major [d][m]: a column's m entries contiguous
+      if (f.Hq) {
+        const int R = (m + 3) / 4;
+        f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+      }
+    }
+    if (lane < m) {
+      double u = f.b[(size_t)k * m + lane];
+#pragma unroll
+      for (int c = 0; c < d; ++c) u += Ak[lane * d + c] * mu[(size_t)kin * d + c];
+      f.u0[(size_t)k * m + lane] = u;
+    }
+  }
+}
+
 // the chain shapes of BASELINE.json get unrolled instances
 template <int EPLP>
 __device__ inline void prep_body_d(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
+  if (f.chol) {
+    switch (f.d) {
+      case 4: prep_chol_body<4>(f, mu, Sigma, k, sm, kin); return;
+      case 6: prep_chol_body<6>(f, mu, Sigma, k, sm, kin); return;
+      case 8: prep_chol_body<8>(f, mu, Sigma, k, sm, kin); return;
+      case 12: prep_chol_body<12>(f, mu, Sigma, k, sm, kin); return;
+    }
+  }
   if (EPLP == 1 && f.d == 6) prep_body<EPLP, 6>(f, mu, Sigma, k, sm, kin);
   else if (EPLP == 4 && f.d == 6) prep_body<EPLP, 6>(f, mu, Sigma, k, sm, kin);
   else if (EPLP == 4 && f.d == 12) prep_body<EPLP, 12>(f, mu, Sigma, k, sm, kin);
@@ -1870,7 +1977,7 @@ __device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm) {
       if (i <= j) {           // upper triangle, mirrored (ngd/NGDFactorizedBaseGH.h:71-72)
         double s = 0.0;
 #pragma unroll
-        for (int c = 0; c < d; ++c) s += Tm[i * d + c] * Sv[c * d + j];
+        for (int c = 0; c < d; ++c) s += Tm[i * d + c] * Sv[j * d + c];     // (W M2) W^T, W = S^-T (symmetric root: W = Sinv)
         const double v = (s - Lv[i * d + j] * m0) / Tk;
         a.Vddmu[(size_t)k * dd + i * d + j] = v;
         a.Vddmu[(size_t)k * dd + j * d + i] = v;

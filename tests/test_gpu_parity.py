@@ -1059,6 +1059,68 @@ def test_sign_orbit_kernel_indefinite_weight():
     assert rel(cost, r["cost"]) < TIGHT
 
 
+@pytest.mark.parametrize("kind,d,p,K", [("quad", 12, 5, 9), ("fixed", 6, 5, 7), ("quad", 8, 4, 5), ("quad", 4, 3, 6), ("fixed", 12, 3, 4)])
+def test_cholesky_factor_route_matches_symmetric_root(kind, d, p, K):
+    """Sum-of-squares psi on a degree >= 3 table: the quadrature of psi {1, z, z z^T} is exact, so the moments do not
+    depend on which factor S S^T = Sigma maps the nodes.  The default route takes S = chol(Sigma) (prep_chol_body, no Jacobi
+    sweeps); option chol_sqrt = 0 restores the reference's symmetric root.  Both against each other and the oracle (which
+    follows the reference: symmetric root), including ill-conditioned marginals; gvi_expand keeps the symmetric root
+    whatever the option says (the caller sees the nodes)."""
+    rng = np.random.default_rng(8100 + d + p)
+    if kind == "quad":
+        n = d // 2
+        Phi, Qinv = quad_params(rng, K, n)
+        params = np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1)
+        temp = rng.uniform(0.5, 3.0, K)
+        ctx, sid = single_set_ctx(api.PSI_QUAD_PRIOR, d, n, p, K, params, temperature=temp)
+        psi = o.psi_batch_quad_prior(Phi, Qinv)
+    else:
+        mu0 = rng.normal(size=(K, d))
+        Kh = rng.normal(size=(K, d, d))
+        Kinv = Kh @ np.transpose(Kh, (0, 2, 1)) / d + 0.3 * np.eye(d)
+        temp = np.ones(K)
+        ctx, sid = single_set_ctx(api.PSI_FIXED_PRIOR, d, d, p, K, np.concatenate([mu0, Kinv.reshape(K, -1)], axis=1))
+        psi = o.psi_batch_fixed_prior(mu0, Kinv)
+    mu, Sigma = syn.random_marginals(rng, K, d, 0.3)
+    # make the last marginal ill-conditioned (cond 1e4; Vddmu = S^-T (M2 - m0 I) S^-1 loses cond^2 eps on EVERY route)
+    w_, V_ = np.linalg.eigh(Sigma[-1])
+    Sigma[-1] = (V_ * np.geomspace(1e-2, 1e2, d)) @ V_.T
+    Sigma[-1] = 0.5 * (Sigma[-1] + Sigma[-1].T)
+    got = ctx.moments(sid, mu, Sigma)
+    cost = ctx.costs(sid, mu, Sigma)
+    X_chol_default = ctx.expand(sid, mu, Sigma)
+    ctx.set_option("chol_sqrt", 0)
+    sym = ctx.moments(sid, mu, Sigma)
+    sym_cost = ctx.costs(sid, mu, Sigma)
+    X_sym = ctx.expand(sid, mu, Sigma)
+    ctx.close()
+    assert np.array_equal(X_chol_default, X_sym)               # the nodes always come from the symmetric root
+    Z, w = oracle_table(d, p)
+    r = o.batched_moments(Z, w, mu, Sigma, psi, temp)
+    for kk in range(K):
+        lim = TIGHT if kk < K - 1 else 1e-7                    # the ill-conditioned one
+        for a, b, c, scale in ((got[0], sym[0], r["E_phi"], 1), (got[1], sym[1], r["Vdmu"], 1), (got[2], sym[2], r["Vddmu"], 10)):
+            assert rel(a[kk], b[kk]) < lim * scale and rel(a[kk], c[kk]) < lim * scale, (kk, rel(a[kk], b[kk]), rel(a[kk], c[kk]))
+        assert rel(cost[kk], sym_cost[kk]) < lim and rel(cost[kk], r["cost"][kk]) < lim
+    assert np.array_equal(got[2], np.transpose(got[2], (0, 2, 1)))
+
+
+def test_cholesky_route_ngd_iterations_match_symmetric_root():
+    """Five device-resident NGD iterations of BASELINE configs[1] with S = chol(Sigma) and with the symmetric root: the
+    iterates agree to rounding (same accepted steps, costs to 1e-11)."""
+    ch = make_chain("c2")
+    ctx, ids = api.context_for_chain(ch)
+    logs = []
+    for chol in (1, 0):
+        ctx.set_option("chol_sqrt", chol)
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        logs.append([ctx.ngd_step(0.9, 10) for _ in range(5)])
+    ctx.close()
+    for a, b in zip(*logs):
+        assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"]
+        assert abs(a["new_cost"] - b["new_cost"]) < 1e-11 * abs(b["new_cost"])
+
+
 def test_asymmetric_user_table_keeps_the_unpaired_kernel():
     """gvi_factors_set_table with a table that is NOT mirror-symmetric (one weight perturbed): the +-pairing must not be
     used; results follow the oracle on that very table."""
