@@ -164,6 +164,7 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-step-calls", action="store_true", help="one gvi_ngd_step call per iteration from Python instead of gvi_ngd_run blocks")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 register (LDS operands), 3 operand-resident, 5 register (SGPR operands), 6 sign-orbit")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong (default, BASELINE configs[3]): the same chain over N GPUs (128 factors per GPU at N = 8: bounded "
@@ -270,16 +271,30 @@ def main():
     ctx.ngd_counters(reset=True)
     t0 = time.perf_counter()
     kern_ms, log = [], []
-    for i in range(args.steps):
-        if pos == args.restart_every:
-            restart(); pos = 0                          # timed: host upload + one refresh of the chain products
-        r = step_fn(); pos += 1
-        log.append(r)
-        if i % 8 == 7 or i == args.steps - 1:
+    if single and not args.per_step_calls:
+        # the iteration loop of GVIGH::optimize as ONE C call per block of steps (gvi_ngd_run): no interpreter between the
+        # decision of an iteration and the launches of the next
+        done = 0
+        while done < args.steps:
+            if pos == args.restart_every:
+                restart(); pos = 0                      # timed: host upload + one refresh of the chain products
+            blk = ctx.ngd_run(min(args.steps - done, args.restart_every - pos, 64), 0.55, 10)
+            log.extend(blk); done += len(blk); pos += len(blk)
             try:
-                kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch (sampled: every 8th)
+                kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch of the block
             except api.GviError:
                 pass
+    else:
+        for i in range(args.steps):
+            if pos == args.restart_every:
+                restart(); pos = 0                          # timed: host upload + one refresh of the chain products
+            r = step_fn(); pos += 1
+            log.append(r)
+            if i % 8 == 7 or i == args.steps - 1:
+                try:
+                    kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch (sampled: every 8th)
+                except api.GviError:
+                    pass
     barrier()
     elapsed = time.perf_counter() - t0
     n_full, n_cost = ctx.ngd_counters()
@@ -299,10 +314,14 @@ def main():
         ctx.ngd_counters(reset=True)
         tf0 = time.perf_counter()
         flog = []
-        for i in range(args.steps):
+        while len(flog) < args.steps:
             if fpos == args.restart_every:
                 ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"]); fpos = 0
-            flog.append(ctx.ngd_step(0.55, 10)); fpos += 1
+            if args.per_step_calls:
+                blk = [ctx.ngd_step(0.55, 10)]
+            else:
+                blk = ctx.ngd_run(min(args.steps - len(flog), args.restart_every - fpos, 64), 0.55, 10)
+            flog.extend(blk); fpos += len(blk)
         torch.cuda.synchronize()
         tf = time.perf_counter() - tf0
         f_full, f_cost = ctx.ngd_counters()

@@ -67,6 +67,7 @@ SIGNATURES = {
     "gvi_ngd_trial": [C.c_void_p, C.c_double, c_double_p],
     "gvi_ngd_accept": [C.c_void_p],
     "gvi_ngd_step": [C.c_void_p, C.c_double, C.c_int, c_double_p, C.POINTER(C.c_int), c_double_p, C.POINTER(C.c_int)],
+    "gvi_ngd_run": [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)],
     "gvi_ngd_set_mode": [C.c_void_p, C.c_int, C.c_int],
     "gvi_ngd_counters": [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int],
     "gvi_ngd_gradients_local": [C.c_void_p],

@@ -298,6 +298,17 @@ class Context:
                                        C.byref(c1), C.byref(ntr)))
         return dict(cost_iter=c0.value, accepted=bool(ok.value), new_cost=c1.value, ntrials=ntr.value)
 
+    def ngd_run(self, max_iters, step_size_base=0.55, max_backtrack=10):
+        """Up to max_iters iterations in one C call (the loop of GVIGH::optimize); returns a list of the per-iteration
+        records gvi_ngd_step reports.  Stops after an iteration whose backtracking was exhausted."""
+        c0 = np.zeros(max_iters); c1 = np.zeros(max_iters)
+        ok = np.zeros(max_iters, dtype=np.int32); ntr = np.zeros(max_iters, dtype=np.int32)
+        done = C.c_int()
+        self._ck(self.lib.gvi_ngd_run(self.h, int(max_iters), step_size_base, max_backtrack, _p(c0), _p(ok), _p(c1), _p(ntr),
+                                      C.byref(done)))
+        return [dict(cost_iter=float(c0[i]), accepted=bool(ok[i]), new_cost=float(c1[i]), ntrials=int(ntr[i]))
+                for i in range(done.value)]
+
     def ngd_set_mode(self, speculate=True, fuse_trial=2):
         """fuse_trial: 0 separate cost pass, 1 fused (full pass at the trial point), 2 adaptive (default)."""
         self._ck(self.lib.gvi_ngd_set_mode(self.h, int(speculate), int(fuse_trial)))

@@ -1793,7 +1793,7 @@ static EpiList make_epi_list(gvi_ctx* ctx, int full, int* dmax_out) {
 static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1) {
   int dmax = 0;
   const EpiList L = make_epi_list(ctx, full, &dmax);
-  const size_t lds = std::max<size_t>(epilogue_lds_doubles(dmax) * 8, 256 * 8);
+  const size_t lds = (epilogue_lds_doubles(dmax) + 256) * 8;       // + the tail's 256-leaf tree
   if (L.koff[L.nsets] == 0) return GVI_OK;
   EpiTail tail;
   tail.on = 0; tail.acc = nullptr; tail.half_logdet = nullptr; tail.host_out = nullptr; tail.seq = 0.0; tail.counter = nullptr;
@@ -2496,6 +2496,27 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
   if (accepted) *accepted = ok;
   if (new_cost) *new_cost = ok ? c1 : c0;
   if (ntrials) *ntrials = cnt;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_run(gvi_ctx* ctx, int max_iters, double step_size_base, int max_backtrack, double* cost_iter,
+                       int* accepted, double* new_cost, int* ntrials, int* iters_done) {
+  GVICK(ngd_check(ctx));
+  if (max_iters < 0) return fail(ctx, GVI_ERR_ARG, "max_iters < 0");
+  int done = 0;
+  for (int i = 0; i < max_iters; ++i) {
+    double c0 = 0.0, c1 = 0.0;
+    int ok = 0, nt = 0;
+    const gvi_status st = gvi_ngd_step(ctx, step_size_base, max_backtrack, &c0, &ok, &c1, &nt);
+    if (st != GVI_OK) { if (iters_done) *iters_done = done; return st; }
+    if (cost_iter) cost_iter[i] = c0;
+    if (accepted) accepted[i] = ok;
+    if (new_cost) new_cost[i] = c1;
+    if (ntrials) ntrials[i] = nt;
+    ++done;
+    if (!ok) break;
+  }
+  if (iters_done) *iters_done = done;
   return GVI_OK;
 }
 

@@ -1913,8 +1913,9 @@ __host__ __device__ inline size_t epilogue_lds_doubles(int d) { return (size_t)n
 // back-transform (Sinv, Lam; S for the raw integrals) are fetched into LDS in one round trip at the top -- with the
 // loads inside the d-long inner loops every product paid d dependent global round trips (profiles/r02_e: 15 us for
 // what is ~2 us of arithmetic).  Summation orders are unchanged (c ascending, chunk index ascending).
+// phase 0: everything; 1: chunk sums, E[psi] and cost only (Ms stays in LDS); 2: the back-transform after a phase-1 call
 template <int DT>
-__device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm) {
+__device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm, int phase) {
   const FactorDev& f = a.f;
   const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x;
   const int npo = a.full ? npairs(d) : 1;
@@ -1924,13 +1925,14 @@ __device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm) {
   double* Sv = Tm + dd;         // [d][d] Sinv
   double* Lv = Sv + dd;         // [d][d] Lam
   const double* P = a.partial + (size_t)k * a.nchunk * npo;
+  const double Tk = f.temperature[k];                     // issued with the other loads, used after the chunk sums
   const bool want_v = a.full && (a.Vdmu || a.Vddmu);
-  if (want_v) {
+  if (want_v && phase != 2) {
     const double* Sinv = f.Sinv + (size_t)k * dd;
     const double* Lam = f.Lam + (size_t)k * dd;
     for (int e = lane; e < dd; e += 64) { Sv[e] = Sinv[e]; Lv[e] = Lam[e]; }
   }
-  for (int j = lane; j < npo; j += 64) {
+  for (int j = lane; j < npo && phase != 2; j += 64) {
     double s = 0.0;
     for (int c0 = 0; c0 < a.nchunk; c0 += 8) {                   // eight loads in flight, then the ordered sum
       double pv[8];
@@ -1943,13 +1945,12 @@ __device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm) {
   }
   wave_lds_sync();
   const double m0 = Ms[0];
-  const double Tk = f.temperature[k];
   const double costk = m0 / Tk;
-  if (lane == 0) {
+  if (lane == 0 && phase != 2) {
     if (a.Ephi) a.Ephi[k] = m0;
     if (a.cost) a.cost[k] = costk;
   }
-  if (!a.full) return costk;
+  if (!a.full || phase == 1) return costk;
   for (int e = lane; e < dd; e += 64) {
     const int i = e / d, j = e % d;
     M2[e] = i <= j ? Ms[pair_index(d, i, j)] : Ms[pair_index(d, j, i)];
@@ -2019,11 +2020,11 @@ __device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm) {
 }
 
 // the chain shapes of BASELINE.json get unrolled instances; everything else runs the runtime-d body
-__device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm) {
+__device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm, int phase = 0) {
   switch (a.f.d) {
-    case 6: return epilogue_body_t<6>(a, k, sm);
-    case 12: return epilogue_body_t<12>(a, k, sm);
-    default: return epilogue_body_t<0>(a, k, sm);
+    case 6: return epilogue_body_t<6>(a, k, sm, phase);
+    case 12: return epilogue_body_t<12>(a, k, sm, phase);
+    default: return epilogue_body_t<0>(a, k, sm, phase);
   }
 }
 
@@ -2114,8 +2115,12 @@ __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tai
   int si = 0;
   while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
   const int kf = (int)blockIdx.x - L.koff[si];
-  const double costk = epilogue_body(L.e[si], kf, sm);
-  if (!tail.on) return;
+  if (!tail.on) { epilogue_body(L.e[si], kf, sm); return; }
+  // With the tail on, the factor's cost goes out FIRST (phase 1: chunk sums only), the last block to arrive sums and
+  // publishes, and only then does every block do its back-transform (phase 2): the host has the trial cost -- and
+  // launches the next iteration's chain kernels -- while the epilogue's products and the assemble are still running,
+  // instead of ~10 us after them.
+  const double costk = epilogue_body(L.e[si], kf, sm, 1);
   // Cross-block hand-over WITHOUT device-scope fences: on this multi-XCD part a release fence writes the XCD's whole L2
   // back (the epilogue has just dirtied megabytes: 2049 blocks x __threadfence() cost ~45 us, measured).  Only the
   // factor's cost has to be seen by the last block, so it is stored write-through at agent scope, the wave waits for
@@ -2138,27 +2143,38 @@ __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tai
     last = l;
   }
   wave_lds_sync();
-  if (!last) return;
+  if (!last) { epilogue_body(L.e[si], kf, sm, 2); return; }
   const int lane = threadIdx.x;
-  double* sh = sm;                                      // [256]
+  double* sh = sm + epilogue_lds_doubles(L.e[si].f.d);  // [256] behind this factor's epilogue area (phase 2 still needs it)
   double total = 0.0;
+  // The summation order is that of cost_sum_all_kernel (256 strided partial sums, then a fixed 256-leaf tree per set).
+  // All loads of a set's first 8 x 256 factors (per lane: 4 virtual threads x 8) are issued before the first add: the
+  // tail is one wave on the critical path of the iteration, and one round trip per virtual thread cost ~6 us.
   for (int s2 = 0; s2 < L.nsets; ++s2) {
     const double* cost = L.e[s2].cost;
     const int K = L.e[s2].f.K;
+    double p[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = lane + 64 * j + q * 256;
+        p[j][q] = k < K ? __hip_atomic_load(cost + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                       // virtual thread v = lane + 64 j of the 256-thread kernel
       double s = 0.0;
-      for (int k0 = lane + 64 * j; k0 < K; k0 += 8 * 256) {
-        // device-scope relaxed loads (the other blocks' stores, made visible by their fences): eight in flight, then the
-        // ordered sum (x + 0.0 == x)
-        double p[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += p[j][q];         // ordered (x + 0.0 == x)
+      for (int k0 = lane + 64 * j + 8 * 256; k0 < K; k0 += 8 * 256) {   // K > 2048: further batches of eight
+        double pp[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int k = k0 + q * 256;
-          p[q] = k < K ? __hip_atomic_load(cost + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          pp[q] = k < K ? __hip_atomic_load(cost + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s += p[q];
+        for (int q = 0; q < 8; ++q) s += pp[q];
       }
       sh[lane + 64 * j] = s;
     }
@@ -2181,6 +2197,8 @@ __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tai
       publish_to_host(tail.host_out, total + tail.half_logdet[0], tail.seq);
     }
   }
+  wave_lds_sync();
+  epilogue_body(L.e[si], kf, sm, 2);
 }
 
 // X[k][a][i] = mu_a + sum_b S_ab z_b[i]  (reference CUDA-path layout [factor][dim][point])

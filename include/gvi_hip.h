@@ -202,6 +202,14 @@ gvi_status gvi_ngd_accept(gvi_ctx* ctx);
  * cost at entry; accepted/new_cost/ntrials report the outcome. */
 gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter,
                         int* accepted, double* new_cost, int* ntrials);
+/* The iteration loop of GVIGH::optimize (gvibase/GVI-GH-impl.h:38-112) without its recorder and temperature schedule:
+ * up to max_iters calls of gvi_ngd_step in one C call, so that no host-language overhead sits between the decision of
+ * one iteration and the launches of the next.  Stops early after an iteration whose backtracking was exhausted
+ * (accepted = 0): optimize() then switches the temperature or declares convergence (:96-108) -- the caller's move.
+ * Outputs are per iteration, any may be NULL; *iters_done counts the iterations run.  Same numbers as the same sequence
+ * of gvi_ngd_step calls. */
+gvi_status gvi_ngd_run(gvi_ctx* ctx, int max_iters, double step_size_base, int max_backtrack, double* cost_iter,
+                       int* accepted, double* new_cost, int* ntrials, int* iters_done);
 /* Scheduling of gvi_ngd_step (results are identical in every mode):
  *   speculate  1 (default): the next iteration's gradients are queued behind the first trial, so the
  *              device does not idle while the host reads the cost; 0: strictly trial-then-decide;

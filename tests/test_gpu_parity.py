@@ -1121,6 +1121,25 @@ def test_cholesky_route_ngd_iterations_match_symmetric_root():
         assert abs(a["new_cost"] - b["new_cost"]) < 1e-11 * abs(b["new_cost"])
 
 
+def test_ngd_run_equals_the_same_sequence_of_steps():
+    """gvi_ngd_run (the loop of GVIGH::optimize in one C call) returns exactly what the same sequence of gvi_ngd_step
+    calls returns -- with an aggressive step base, so that some iterations backtrack -- and leaves the same state."""
+    ch = make_chain("c2")
+    ctx, ids = api.context_for_chain(ch)
+    for base in (0.55, 3.5):
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        ref = [ctx.ngd_step(base, 10) for _ in range(12)]
+        st_ref = ctx.ngd_get_state()
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        got = ctx.ngd_run(5, base, 10) + ctx.ngd_run(7, base, 10)
+        st = ctx.ngd_get_state()
+        assert got == ref
+        assert all(np.array_equal(st[k], st_ref[k]) for k in st_ref)
+        if base > 1.0:
+            assert max(r["ntrials"] for r in ref) > 1           # the backtracking path was exercised
+    ctx.close()
+
+
 def test_asymmetric_user_table_keeps_the_unpaired_kernel():
     """gvi_factors_set_table with a table that is NOT mirror-symmetric (one weight perturbed): the +-pairing must not be
     used; results follow the oracle on that very table."""
