@@ -10,7 +10,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         for row in csv.DictReader(fh):
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, cs in acc.items():
-        if "kernel<12" not in k:
+        if "gvi::" not in k:                      # the library's kernels (moments / chain / prep / epilogue), not torch's
             continue
         d = out.setdefault(k, {})
         for c, v in cs.items():
