@@ -349,7 +349,7 @@ def main():
         km = float(np.mean(kern_ms)) * 1e-3 if kern_ms else float("nan")
         sreg_shapes = (4, 8, 12)
         if geo["variant"] == 6:
-            kernel_name = f"moments_orbit{'_pair' if len(ctx.sets) == 2 else ''}_kernel<{m0}, full>"
+            kernel_name = f"moments_orbit{'_pair' if len(ctx.sets) == 2 else ''}_kernel<{m0}, {4 if p0 <= 5 else 6}, full>"
         elif geo["variant"] == 5:
             kernel_name = f"moments_sreg_pair_kernel<{d0}, {m0}, {m0}, {m0}, full>"
         elif geo["variant"] == 2:
@@ -386,12 +386,18 @@ def main():
         exec_flop = sum(2 * ops_of(d, m, sg) * K * N for K, d, m, N, sg in sets_in_launch)
         alg_flop = sum(alg_flops(d, m) * K * N for K, d, m, N, sg in sets_in_launch)
         alg_bytes = sum(K * N * (d + 1) * 8 for K, d, m, N, sg in sets_in_launch)   # (d+1) s bytes per eval
-        traffic, traffic_source = None, None
+        traffic, traffic_source, valu_issue = None, None, None
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if args.config == "c3" and world == 1 and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                traffic_source = TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+                tj = json.load(open(tpath))
+                if kernel_name.split("<")[0] in tj.get("kernel", ""):     # counters of the kernel that actually ran
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+                    valu_issue = {"busy_frac": tj["derived"]["valu_pipe_busy"], "valu_instructions_per_launch": tj["sq"]["SQ_INSTS_VALU"],
+                                  "wait_frac_of_wave_cycles": tj["derived"]["wait_fraction_of_wave_cycles"],
+                                  "source": TRAFFIC_FILE + " (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles; counts every VALU "
+                                            "instruction, fp64 or integer -- the resource this kernel is bound by)"}
             except Exception:
                 traffic = None
         base_metric = "sigma-point psi-evals/sec + NGD iters/sec, 1024-factor d=12 p=5 chain"
@@ -436,7 +442,7 @@ def main():
             "roofline": {"bound": "mfma", "pipe": "valu_f64 (v_fma_f64 / v_add_f64; zero MFMA instructions)",
                          "achieved": exec_flop / km / 1e12, "peak": FP64_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": exec_flop / km / FP64_PEAK,
-                         "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic": traffic, "traffic_source": traffic_source, "valu_issue": valu_issue,
                          "kernel": kernel_name, "kernel_ms": km * 1e3, "evals_per_launch": evals_launch,
                          "executed_fp64_ops_per_eval": {f"d={d},m={m}": ops_of(d, m, sg) for K, d, m, N, sg in sets_in_launch},
                          "note": "achieved/frac = EXECUTED fp64 VALU instructions of the bracketed launch (every set in it), each "
@@ -456,7 +462,7 @@ def main():
         if world > 1:
             # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU kernel times of this round
             # (profiles/): factor work W shards, the chain recursions R are replicated, two exchanges X are added.
-            W, R, X = 0.120, 0.100, 0.040                     # ms, DESIGN section 5 (profiles/r02_c_kernel_stats.csv)
+            W, R, X = 0.048, 0.092, 0.040                     # ms, DESIGN section 5 (profiles/r02_f_kernel_stats.csv)
             out["strong_scaling_model"] = {"W_ms_sharded": W, "R_ms_replicated": R, "X_ms_exchange": X,
                                            "expected_speedup_at_n": (W + R) / (W / world + R + X),
                                            "note": "t(N) = W / N + R + X; the ceiling as N grows is (W + R) / (R + X)"}

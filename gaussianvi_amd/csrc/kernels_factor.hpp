@@ -400,13 +400,16 @@ template <int EPLP>
 __device__ inline void prep_body_d(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
   if (f.chol) {
     switch (f.d) {
+      case 2: prep_chol_body<2>(f, mu, Sigma, k, sm, kin); return;
       case 4: prep_chol_body<4>(f, mu, Sigma, k, sm, kin); return;
       case 6: prep_chol_body<6>(f, mu, Sigma, k, sm, kin); return;
       case 8: prep_chol_body<8>(f, mu, Sigma, k, sm, kin); return;
       case 12: prep_chol_body<12>(f, mu, Sigma, k, sm, kin); return;
     }
   }
-  if (EPLP == 1 && f.d == 6) prep_body<EPLP, 6>(f, mu, Sigma, k, sm, kin);
+  if (EPLP == 1 && f.d == 2) prep_body<EPLP, 2>(f, mu, Sigma, k, sm, kin);
+  else if (EPLP == 1 && f.d == 4) prep_body<EPLP, 4>(f, mu, Sigma, k, sm, kin);
+  else if (EPLP == 1 && f.d == 6) prep_body<EPLP, 6>(f, mu, Sigma, k, sm, kin);
   else if (EPLP == 4 && f.d == 6) prep_body<EPLP, 6>(f, mu, Sigma, k, sm, kin);
   else if (EPLP == 4 && f.d == 12) prep_body<EPLP, 12>(f, mu, Sigma, k, sm, kin);
   else prep_body<EPLP, 0>(f, mu, Sigma, k, sm, kin);
@@ -2022,7 +2025,10 @@ __device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm, in
 // the chain shapes of BASELINE.json get unrolled instances; everything else runs the runtime-d body
 __device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm, int phase = 0) {
   switch (a.f.d) {
+    case 2: return epilogue_body_t<2>(a, k, sm, phase);
+    case 4: return epilogue_body_t<4>(a, k, sm, phase);
     case 6: return epilogue_body_t<6>(a, k, sm, phase);
+    case 8: return epilogue_body_t<8>(a, k, sm, phase);
     case 12: return epilogue_body_t<12>(a, k, sm, phase);
     default: return epilogue_body_t<0>(a, k, sm, phase);
   }

@@ -1059,7 +1059,7 @@ def test_sign_orbit_kernel_indefinite_weight():
     assert rel(cost, r["cost"]) < TIGHT
 
 
-@pytest.mark.parametrize("kind,d,p,K", [("quad", 12, 5, 9), ("fixed", 6, 5, 7), ("quad", 8, 4, 5), ("quad", 4, 3, 6), ("fixed", 12, 3, 4)])
+@pytest.mark.parametrize("kind,d,p,K", [("quad", 12, 5, 9), ("fixed", 6, 5, 7), ("quad", 8, 4, 5), ("quad", 4, 3, 6), ("fixed", 12, 3, 4), ("fixed", 2, 3, 6)])
 def test_cholesky_factor_route_matches_symmetric_root(kind, d, p, K):
     """Sum-of-squares psi on a degree >= 3 table: the quadrature of psi {1, z, z z^T} is exact, so the moments do not
     depend on which factor S S^T = Sigma maps the nodes.  The default route takes S = chol(Sigma) (prep_chol_body, no Jacobi

@@ -15,3 +15,7 @@ run FETCH FETCH_SIZE || echo FETCH failed
 run WRITE WRITE_SIZE || echo WRITE failed
 run TCC TCC_HIT_sum TCC_MISS_sum || echo TCC failed
 python3 tools/summarize_pmc.py gpurun_out/r02/pmc > gpurun_out/r02/pmc/summary.json; head -c 3000 gpurun_out/r02/pmc/summary.json
+rm -rf gpurun_out/r02/trace_c2
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02/trace_c2 -- python3 bench.py --config c2 --steps 300 --warmup 30 --no-cpu-baseline > gpurun_out/r02/trace_c2.log 2>&1 || tail -5 gpurun_out/r02/trace_c2.log
+find gpurun_out/r02/trace_c2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r02/kernel_stats_c2.csv
+head -14 gpurun_out/r02/kernel_stats_c2.csv | cut -c1-150
