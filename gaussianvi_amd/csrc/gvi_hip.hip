@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cassert>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -954,11 +955,14 @@ SegArgs make_seg_args(gvi_ctx* c, const BcrWs& w, const double* D, const double*
                       double* SigD, double* SigU, double* x, double* hld, bool with_mix) {
   SegArgs a;
   a.T = c->T; a.n = c->n; a.need_E = need_E ? 1 : 0;
-  a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.w = w;
+  a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale;
+  a.w.base = w.E; a.w.bad = w.bad;                          // one allocation, arrays in ensure_chain_ws's order
   a.SigD = SigD; a.SigU = SigU; a.x = x; a.hld = hld;
   a.level0 = a.m = a.S = a.prev0 = a.top = 0;
-  a.mixVD = with_mix ? c->mix.VD : nullptr; a.mixVU = with_mix ? c->mix.VU : nullptr;
-  a.mixOutD = with_mix ? c->mix.outD : nullptr; a.mixOutU = with_mix ? c->mix.outU : nullptr; a.mix_step = with_mix ? c->mix.step : 0.0;
+  // the mixed-in matrix and its output are [D | U] in one buffer each (ngd_trial_state): the kernels derive the U parts
+  a.mixVD = with_mix ? c->mix.VD : nullptr;
+  a.mixOutD = with_mix ? c->mix.outD : nullptr; a.mix_step = with_mix ? c->mix.step : 0.0;
+  assert(!(with_mix && c->mix.VD) || (c->mix.VU == c->mix.VD + (size_t)c->T * nn_(c) && c->mix.outU == c->mix.outD + (size_t)c->T * nn_(c)));
   return a;
 }
 

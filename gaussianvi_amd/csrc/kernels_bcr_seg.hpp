@@ -42,6 +42,14 @@ __device__ int gvi_bcr_dbg_on;
 #define GVI_ESTAMP(idx) do { } while (0)
 #endif
 
+// The chain workspace is ONE allocation (ensure_chain_ws: nine [T][n][n] arrays, four [T][n] arrays, logp[T]); the kernels
+// carry its base and derive the arrays.  Fifteen separate pointers per chain operation (two operations in the dual
+// kernels) overflowed the scalar register file: the element phase of an elimination reloaded spilled SGPRs 114 times.
+struct SegWs {
+  double* base;
+  int* bad;                // [T]
+};
+
 struct SegArgs {
   int T, n;
   int level0;        // first level of this pass; node spacing st = 1 << level0
@@ -54,19 +62,38 @@ struct SegArgs {
   const double* U;
   const double* rhs;     // null: factor; else solve
   double rhs_scale;
-  BcrWs w;
+  SegWs w;
   double* SigD;      // [T][n][n]   (marginals)
   double* SigU;      // [T-1][n][n]
   double* x;         // [T][n]      (solve)
   double* hld;       // [1]
   // optional fused trial precision (first pass only): the chain operated on is D + mix_step (mixV - D), and it is
-  // written to mix_out ([D | U] layouts like D / U) -- replaces the separate trial_kernel launch
+  // written to mix_out -- replaces the separate trial_kernel launch.  Both are [D[T] | U[T-1]] in ONE buffer (the U part
+  // starts at block T), so one pointer each
   const double* mixVD;
-  const double* mixVU;
   double* mixOutD;
-  double* mixOutU;
   double mix_step;
 };
+
+__device__ __forceinline__ double* ws_mat(const SegArgs& a, int idx) { return a.w.base + (size_t)idx * a.T * (a.n * a.n); }
+__device__ __forceinline__ double* ws_vec(const SegArgs& a, int idx) {
+  return a.w.base + (size_t)9 * a.T * (a.n * a.n) + (size_t)idx * a.T * a.n;
+}
+__device__ __forceinline__ double* ws_E(const SegArgs& a) { return ws_mat(a, 0); }
+__device__ __forceinline__ double* ws_GA(const SegArgs& a) { return ws_mat(a, 1); }
+__device__ __forceinline__ double* ws_GB(const SegArgs& a) { return ws_mat(a, 2); }
+__device__ __forceinline__ double* ws_CL(const SegArgs& a) { return ws_mat(a, 3); }
+__device__ __forceinline__ double* ws_CR(const SegArgs& a) { return ws_mat(a, 4); }
+__device__ __forceinline__ double* ws_NU(const SegArgs& a) { return ws_mat(a, 5); }
+__device__ __forceinline__ double* ws_SL(const SegArgs& a) { return ws_mat(a, 6); }
+__device__ __forceinline__ double* ws_SR(const SegArgs& a) { return ws_mat(a, 7); }
+__device__ __forceinline__ double* ws_Deff(const SegArgs& a) { return ws_mat(a, 8); }
+__device__ __forceinline__ double* ws_v(const SegArgs& a) { return ws_vec(a, 0); }
+__device__ __forceinline__ double* ws_yL(const SegArgs& a) { return ws_vec(a, 1); }
+__device__ __forceinline__ double* ws_yR(const SegArgs& a) { return ws_vec(a, 2); }
+__device__ __forceinline__ double* ws_yeff(const SegArgs& a) { return ws_vec(a, 3); }
+__device__ __forceinline__ double* ws_logp(const SegArgs& a) { return ws_vec(a, 4); }
+__device__ __forceinline__ int* ws_bad(const SegArgs& a) { return a.w.bad; }
 
 // forward kernel LDS: 5 block arrays (+3 factor arrays in the top pass), rhs vectors, one elimination tile
 // per wave, reduction area
@@ -166,8 +193,8 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
       mp *= __builtin_amdgcn_frexp_mant(pivs[p]);
       es += __builtin_amdgcn_frexp_exp(pivs[p]);
     }
-    a.w.logp[x] = mp;                    // in [2^-N, 1) for positive pivots
-    a.w.bad[x] = es * 2 + bad;           // exponent sum and the non-positive-pivot flag
+    ws_logp(a)[x] = mp;                    // in [2^-N, 1) for positive pivots
+    ws_bad(a)[x] = es * 2 + bad;           // exponent sum and the non-positive-pivot flag
   }
   GVI_ESTAMP(3);
   // ---- park the reduced tile [I | E | GA | GB | v] in LDS, then finish element-wise on all lanes ----
@@ -179,17 +206,17 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
   GVI_ESTAMP(4);
   for (int el = lane; el < nn; el += 64) {
     const int r = el / N, c = el % N;
-    if (a.need_E) { const double ev = Tl[r * NC + cE + c]; a.w.E[(size_t)x * nn + el] = ev; if (Es) Es[el] = ev; }
+    if (a.need_E) { const double ev = Tl[r * NC + cE + c]; ws_E(a)[(size_t)x * nn + el] = ev; if (Es) Es[el] = ev; }
     if (has_a) {
-      { const double gv = Tl[r * NC + cA + c]; a.w.GA[(size_t)x * nn + el] = gv; if (GAs) GAs[el] = gv; }
+      { const double gv = Tl[r * NC + cA + c]; ws_GA(a)[(size_t)x * nn + el] = gv; if (GAs) GAs[el] = gv; }
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) v = fma(Ua[r * N + k], Tl[k * NC + cA + c], v);
       CLs[el] = v;
-      a.w.CL[(size_t)x * nn + el] = v;
+      ws_CL(a)[(size_t)x * nn + el] = v;
     }
     if (has_b) {
-      { const double gv = Tl[r * NC + cB + c]; a.w.GB[(size_t)x * nn + el] = gv; if (GBs) GBs[el] = gv; }
+      { const double gv = Tl[r * NC + cB + c]; ws_GB(a)[(size_t)x * nn + el] = gv; if (GBs) GBs[el] = gv; }
       double v = 0.0, u = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) {
@@ -198,27 +225,27 @@ __device__ inline void seg_eliminate(const SegArgs& a, int x, const double* Dl_e
         if (has_a) u = fma(Ua[r * N + k], gb, u);
       }
       CRs[el] = v;
-      a.w.CR[(size_t)x * nn + el] = v;
-      if (has_a) { NUs[el] = -u; a.w.NU[(size_t)x * nn + el] = -u; }
+      ws_CR(a)[(size_t)x * nn + el] = v;
+      if (has_a) { NUs[el] = -u; ws_NU(a)[(size_t)x * nn + el] = -u; }
     }
   }
   GVI_ESTAMP(5);
   if (rhs && lane < N) {
     const int r = lane;
-    { const double vv = Tl[r * NC + cY]; a.w.v[(size_t)x * N + r] = vv; if (vs) vs[r] = vv; }
+    { const double vv = Tl[r * NC + cY]; ws_v(a)[(size_t)x * N + r] = vv; if (vs) vs[r] = vv; }
     if (has_a) {
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) v = fma(Ua[r * N + k], Tl[k * NC + cY], v);
       yLs[r] = v;
-      a.w.yL[(size_t)x * N + r] = v;
+      ws_yL(a)[(size_t)x * N + r] = v;
     }
     if (has_b) {
       double v = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) v = fma(Ub[k * N + r], Tl[k * NC + cY], v);
       yRs[r] = v;
-      a.w.yR[(size_t)x * N + r] = v;
+      ws_yR(a)[(size_t)x * N + r] = v;
     }
   }
   wave_lds_sync();
@@ -250,8 +277,8 @@ __device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int le
     }
     SL_s[el] = -sl;
     SR_s[el] = -sr;
-    a.w.SL[(size_t)x * nn + el] = -sl;
-    if (has_b) a.w.SR[(size_t)x * nn + el] = -sr;
+    ws_SL(a)[(size_t)x * nn + el] = -sl;
+    if (has_b) ws_SR(a)[(size_t)x * nn + el] = -sr;
   }
   wave_lds_sync();
   for (int el = lane; el < nn; el += 64) {
@@ -276,7 +303,7 @@ __device__ inline void seg_marginal_node(const SegArgs& a, int x, int xa, int le
 // caller issues the loads of all its elements before the first use, then stores).
 __device__ __forceinline__ double seg_fold_D(const SegArgs& a, int x, int el) {
   const int nn = a.n * a.n;
-  double v = (a.level0 == 0 ? a.D : a.w.Deff)[(size_t)x * nn + el];
+  double v = (a.level0 == 0 ? a.D : ws_Deff(a))[(size_t)x * nn + el];
   double mv = 0.0;
   const bool mix = a.level0 == 0 && a.mixVD;
   if (mix) mv = a.mixVD[(size_t)x * nn + el];
@@ -287,8 +314,8 @@ __device__ __forceinline__ double seg_fold_D(const SegArgs& a, int x, int el) {
   for (int q = 0; q < 5; ++q) {
     const int l = a.prev0 + q, h = 1 << l;
     const bool on = l < a.level0;
-    cr[q] = (on && x - h >= 0) ? a.w.CR[(size_t)(x - h) * nn + el] : 0.0;
-    cl[q] = (on && x + h < a.T) ? a.w.CL[(size_t)(x + h) * nn + el] : 0.0;
+    cr[q] = (on && x - h >= 0) ? ws_CR(a)[(size_t)(x - h) * nn + el] : 0.0;
+    cl[q] = (on && x + h < a.T) ? ws_CL(a)[(size_t)(x + h) * nn + el] : 0.0;
   }
   if (mix) v = v + a.mix_step * (mv - v);                         // same arithmetic as trial_kernel
 #pragma unroll
@@ -297,14 +324,14 @@ __device__ __forceinline__ double seg_fold_D(const SegArgs& a, int x, int el) {
 }
 __device__ inline double seg_fold_y(const SegArgs& a, int x, int r) {
   const int n = a.n;
-  double v = a.level0 == 0 ? a.rhs_scale * a.rhs[(size_t)x * n + r] : a.w.yeff[(size_t)x * n + r];
+  double v = a.level0 == 0 ? a.rhs_scale * a.rhs[(size_t)x * n + r] : ws_yeff(a)[(size_t)x * n + r];
   double yr[5], yl[5];
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     const int l = a.prev0 + q, h = 1 << l;
     const bool on = l < a.level0;
-    yr[q] = (on && x - h >= 0) ? a.w.yR[(size_t)(x - h) * n + r] : 0.0;
-    yl[q] = (on && x + h < a.T) ? a.w.yL[(size_t)(x + h) * n + r] : 0.0;
+    yr[q] = (on && x - h >= 0) ? ws_yR(a)[(size_t)(x - h) * n + r] : 0.0;
+    yl[q] = (on && x + h < a.T) ? ws_yL(a)[(size_t)(x + h) * n + r] : 0.0;
   }
 #pragma unroll
   for (int q = 0; q < 5; ++q) { v -= yr[q]; v -= yl[q]; }
@@ -358,8 +385,8 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
         dv[u] = seg_fold_D(a, x, el);
         hasc[u] = x + st < T;
         if (hasc[u]) {
-          cu[u] = (a.level0 == 0 ? a.U + (size_t)x * nn : a.w.NU + (size_t)(x + st / 2) * nn)[el];
-          if (a.level0 == 0 && a.mixVU) cu[u] = cu[u] + a.mix_step * (a.mixVU[(size_t)x * nn + el] - cu[u]);
+          cu[u] = (a.level0 == 0 ? a.U + (size_t)x * nn : ws_NU(a) + (size_t)(x + st / 2) * nn)[el];
+          if (a.level0 == 0 && a.mixVD) cu[u] = cu[u] + a.mix_step * (a.mixVD[(size_t)(T + x) * nn + el] - cu[u]);
         }
       }
     }
@@ -370,10 +397,10 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
         const int j = e / nn, el = e % nn, x = x0 + j * st;
         Dl[e] = dv[u];
         if (a.level0 == 0 && a.mixVD) a.mixOutD[(size_t)x * nn + el] = dv[u];
-        if (j == 0 && !a.top) a.w.Deff[(size_t)x * nn + el] = dv[u];      // the survivor's base for the next pass
+        if (j == 0 && !a.top) ws_Deff(a)[(size_t)x * nn + el] = dv[u];      // the survivor's base for the next pass
         if (hasc[u]) {
           Cl[e] = cu[u];
-          if (a.level0 == 0 && a.mixVU) a.mixOutU[(size_t)x * nn + el] = cu[u];
+          if (a.level0 == 0 && a.mixVD) a.mixOutD[(size_t)(T + x) * nn + el] = cu[u];
         }
       }
     }
@@ -383,7 +410,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
       const int j = e / N, r = e % N, x = x0 + j * st;
       const double v = seg_fold_y(a, x, r);
       yl[e] = v;
-      if (j == 0 && !a.top) a.w.yeff[(size_t)x * N + r] = v;
+      if (j == 0 && !a.top) ws_yeff(a)[(size_t)x * N + r] = v;
     }
   }
   __syncthreads();
@@ -443,8 +470,8 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
     double s = 0.0;
     int bflag = 0;
     for (int t = tid; t < T; t += blockDim.x) {
-      const int eb = a.w.bad[t];
-      s += log(a.w.logp[t]) + (double)(eb >> 1) * 0.6931471805599453094;
+      const int eb = ws_bad(a)[t];
+      s += log(ws_logp(a)[t]) + (double)(eb >> 1) * 0.6931471805599453094;
       bflag |= eb & 1;
     }
 #pragma unroll
@@ -552,11 +579,11 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
     double* GBl = GAl + S * nn;                       // [S][nn]
     for (int e = tid; e < cnt * nn; e += blockDim.x) {
       const int j = e / nn, el = e % nn, x = x0 + j * st;
-      if (j > 0) { GAl[e] = a.w.GA[(size_t)x * nn + el]; GBl[e] = a.w.GB[(size_t)x * nn + el]; }
+      if (j > 0) { GAl[e] = ws_GA(a)[(size_t)x * nn + el]; GBl[e] = ws_GB(a)[(size_t)x * nn + el]; }
     }
     for (int e = tid; e < cnt * N; e += blockDim.x) {
       const int j = e / N, r = e % N, x = x0 + j * st;
-      if (j > 0) vl[e] = a.w.v[(size_t)x * N + r];
+      if (j > 0) vl[e] = ws_v(a)[(size_t)x * N + r];
     }
     if (tid < N) xl[tid] = a.x[(size_t)x0 * N + tid];
     if (ext_right && tid >= 64 && tid < 64 + N) xl[S * N + tid - 64] = a.x[(size_t)xn * N + tid - 64];
@@ -602,9 +629,9 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
       const int j = e / nn, el = e % nn, x = x0 + j * st;
       ev[u] = gav[u] = gbv[u] = 0.0;
       if (e < cnt * nn && j > 0) {
-        ev[u] = a.w.E[(size_t)x * nn + el];
-        gav[u] = a.w.GA[(size_t)x * nn + el];
-        gbv[u] = a.w.GB[(size_t)x * nn + el];      // unused garbage when the node had no right neighbour
+        ev[u] = ws_E(a)[(size_t)x * nn + el];
+        gav[u] = ws_GA(a)[(size_t)x * nn + el];
+        gbv[u] = ws_GB(a)[(size_t)x * nn + el];      // unused garbage when the node had no right neighbour
       }
     }
 #pragma unroll
@@ -618,7 +645,7 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
     Sgl[el] = a.SigD[(size_t)x0 * nn + el];
     if (ext_right) {
       Sgl[S * nn + el] = a.SigD[(size_t)xn * nn + el];
-      SRl[el] = x0_odd ? a.w.SR[(size_t)x0 * nn + el] : a.w.SL[(size_t)xn * nn + c * N + r];
+      SRl[el] = x0_odd ? ws_SR(a)[(size_t)x0 * nn + el] : ws_SL(a)[(size_t)xn * nn + c * N + r];
     }
   }
   __syncthreads();
