@@ -894,7 +894,9 @@ bool seg_supported(int n) { return n == 1 || n == 2 || n == 3 || n == 4 || n == 
 SegPlan seg_plan(const gvi_ctx* c) {
   const int n = c->n, T = c->T;
   const int m_seg = n <= 6 ? 5 : (n <= 8 ? 4 : 3);
-  const int cap = n <= 6 ? 48 : (n <= 8 ? 24 : 8);          // top-pass nodes: 8 LDS block arrays must fit
+  // top-pass nodes: 8 LDS block arrays must fit.  Small blocks leave room for a long top pass, and a chain that fits it is
+  // done in ONE launch instead of three (the 65-state planar / configs[1] chains: launch floor, not arithmetic)
+  const int cap = n <= 2 ? 128 : (n <= 4 ? 64 : (n <= 6 ? 48 : (n <= 8 ? 24 : 8)));
   SegPlan p;
   const int nlevels = bcr_levels(T);
   int level0 = 0, prev0 = 0;
