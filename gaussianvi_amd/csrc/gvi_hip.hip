@@ -2,6 +2,7 @@
 #include "../../include/gvi_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -627,23 +628,28 @@ void launch_orbit(const OrbitArgs& a, int m, int smax, bool full, bool all_pos, 
   else launch_orbit_t<12, 6, 2>(a, full, all_pos, grid, lds, st);
 }
 
-// two sets with the same m and sgn = +1 in one launch
+// two sets with the same m and sgn = +1 in one launch.  e0 / e1 non-null: the launch itself carries the start / stop events
+// (hipExtLaunchKernel: the kernel's own begin / end timestamps, what rocprofv3 reports -- a hipEventRecord pair around a
+// 28 us launch reads ~3 us more than the kernel runs)
 template <int M, int SMAX, int WAVES>
-void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, size_t lds, hipStream_t st) {
+void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, size_t lds, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const int nbx0 = (a0.K + 3) / 4, nbx1 = (a1.K + 3) / 4;
   const int nb0 = nbx0 * a0.nchunk, nb1 = nbx1 * a1.nchunk;
   if (full)
-    hipLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, true, false, WAVES>), dim3(nb0 + nb1), dim3(256), lds, st, a0, a1, nbx0, nb0, nbx1);
+    hipExtLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, true, false, WAVES>), dim3(nb0 + nb1), dim3(256), (uint32_t)lds, st, e0, e1, 0,
+                          a0, a1, nbx0, nb0, nbx1);
   else
-    hipLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, false, false, WAVES>), dim3(nb0 + nb1), dim3(256), lds, st, a0, a1, nbx0, nb0, nbx1);
+    hipExtLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, false, false, WAVES>), dim3(nb0 + nb1), dim3(256), (uint32_t)lds, st, e0, e1, 0,
+                          a0, a1, nbx0, nb0, nbx1);
 }
 
-void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st) {
+void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st,
+                       hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const size_t lds = (size_t)4 * std::max(orbit_lds_doubles(a0.d, m, a0.copies), orbit_lds_doubles(a1.d, m, a1.copies)) * 8;
-  if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st);
-  else if (m == 6) launch_orbit_pair_t<6, 6, 2>(a0, a1, full, lds, st);
-  else if (smax <= 4) launch_orbit_pair_t<12, 4, 3>(a0, a1, full, lds, st);
-  else launch_orbit_pair_t<12, 6, 2>(a0, a1, full, lds, st);
+  if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st, e0, e1);
+  else if (m == 6) launch_orbit_pair_t<6, 6, 2>(a0, a1, full, lds, st, e0, e1);
+  else if (smax <= 4) launch_orbit_pair_t<12, 4, 3>(a0, a1, full, lds, st, e0, e1);
+  else launch_orbit_pair_t<12, 6, 2>(a0, a1, full, lds, st, e0, e1);
 }
 
 // prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
@@ -2148,11 +2154,11 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
         if (prof) {
           for (int e = 0; e < 2; ++e)
             if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
-          HIPCK(ctx, hipEventRecord(s0.ev[0][0], ctx->stream));
         }
-        launch_orbit_pair(d0.oa, d1.oa, d0.m, std::max(d0.smax, d1.smax), full != 0, ctx->stream);
+        launch_orbit_pair(d0.oa, d1.oa, d0.m, std::max(d0.smax, d1.smax), full != 0, ctx->stream,
+                          prof ? s0.ev[0][0] : nullptr, prof ? s0.ev[0][1] : nullptr);
         HIPCK(ctx, hipGetLastError());
-        if (prof) { HIPCK(ctx, hipEventRecord(s0.ev[0][1], ctx->stream)); s0.ev_set[0] = true; }
+        if (prof) s0.ev_set[0] = true;
         s0.fused_pair = s1.fused_pair = true;
         return GVI_OK;
       }
