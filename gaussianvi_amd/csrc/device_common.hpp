@@ -26,4 +26,9 @@ __device__ __forceinline__ void publish_to_host(double* host_out, double value, 
   __builtin_nontemporal_store(v, (d2*)host_out);
 }
 
+// Predicated launch (gvi_ngd_run): the kernels of a speculatively queued iteration read one device word and return at once
+// unless it holds the expected sequence number -- the previous iteration's tail writes it only when its trial was accepted.
+// pred == nullptr: unconditional.
+__device__ __forceinline__ bool pred_skip(const double* pred, double val) { return pred != nullptr && *pred != val; }
+
 }  // namespace gvi

@@ -230,6 +230,20 @@ struct gvi_ctx {
     int maxlen = 0;
     bool ranges_valid = false;
   } dist;
+  // pipelined iterations (gvi_ngd_run): predicate of the launches being queued, device-side accept decision of the tails,
+  // ring of two host slots (a speculatively queued iteration publishes into the other one)
+  const double* cur_pred = nullptr;
+  double cur_pred_val = 0.0;
+  DevMem pipe_dev;                    // doubles: [0..1] accept words (ring), [2..3] cost of the state in NGD slot 0 / 1
+  // GVI_PIPELINE=1 / option "pipeline": gvi_ngd_run queues iteration i + 1 (predicated) before it has read the cost of
+  // iteration i.  Off by default: measured per-iteration time is the same (129.7 vs 130.5 us at C3) because the early
+  // publish of the trial cost already gives the host its ~20 us; it removes the 4-7 us gaps that appear when the host
+  // is slowed down (e.g. under rocprofv3).
+  bool pipeline = false;
+  bool pipe_tail = false;             // tails take the accept decision on the device
+  bool pipe_c0_imm = true;            // current cost as an immediate (known to the host) or from pipe_dev
+  double pipe_c0 = 0.0;
+  int pub_ring = 0;                   // host slot the next publish goes to
   double* host_slot = nullptr;        // host-mapped {cost value, sequence}: one 16-byte device store (publish_to_host)
   // kernels whose dynamic-LDS limit was raised on THIS context's device (the attribute is per device, and a
   // process may hold contexts on several devices)
@@ -598,6 +612,7 @@ gvi_status orbit_args(gvi_ctx* c, FactorSet& s, int full, OrbitArgs* out) {
   OrbitArgs a;
   a.H = s.H.d(); a.u0 = s.u0.d(); a.sgn = s.sgn.d(); a.partial = s.partial.d();
   a.K = s.K; a.d = s.d; a.nchunk = s.nchunk;
+  a.pred = c->cur_pred; a.pred_val = c->cur_pred_val;
   // private accumulator copies: as many as the kernel's occupancy leaves LDS for (160 KB per CU, 64 KB per block), capped by orbit_copies
   const int waves = (s.m == 6 && t.orb.smax <= 4) ? 4 : ((s.m == 12 && t.orb.smax <= 4) ? 3 : 2);   // launch_orbit's occupancy
   const size_t lds_cap = std::min<size_t>(64 * 1024, 160 * 1024 / waves);
@@ -967,6 +982,7 @@ SegArgs make_seg_args(gvi_ctx* c, const BcrWs& w, const double* D, const double*
   a.w.base = w.E; a.w.bad = w.bad;                          // one allocation, arrays in ensure_chain_ws's order
   a.SigD = SigD; a.SigU = SigU; a.x = x; a.hld = hld;
   a.level0 = a.m = a.S = a.prev0 = a.top = 0;
+  a.pred = c->cur_pred; a.pred_val = c->cur_pred_val;
   // the mixed-in matrix and its output are [D | U] in one buffer each (ngd_trial_state): the kernels derive the U parts
   a.mixVD = with_mix ? c->mix.VD : nullptr;
   a.mixOutD = with_mix ? c->mix.outD : nullptr; a.mix_step = with_mix ? c->mix.step : 0.0;
@@ -1117,6 +1133,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
+  if (const char* w = getenv("GVI_PIPELINE")) c->pipeline = atoi(w) != 0;
   if (const char* w = getenv("GVI_CHOL_SQRT")) c->chol_sqrt = atoi(w) != 0;
   if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
   if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
@@ -1139,7 +1156,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
       hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
     return fail(nullptr, GVI_ERR_HIP, "event / host-mapped slot allocation failed");
-  c->host_slot[0] = c->host_slot[1] = c->host_slot[2] = 0.0;
+  for (int q = 0; q < 8; ++q) c->host_slot[q] = 0.0;
   *out = c.release();
   return GVI_OK;
 }
@@ -1731,6 +1748,7 @@ static gvi_status ngd_prep_all(gvi_ctx* ctx, int i) {
   L.nsets = 0;
   L.koff[0] = 0;
   L.gather = 0;
+  L.pred = ctx->cur_pred; L.pred_val = ctx->cur_pred_val;
   int dmax = 0;
   bool all = true;
   for (auto& s : ctx->sets) {
@@ -1809,6 +1827,8 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1
   if (L.koff[L.nsets] == 0) return GVI_OK;
   EpiTail tail;
   tail.on = 0; tail.acc = nullptr; tail.half_logdet = nullptr; tail.host_out = nullptr; tail.seq = 0.0; tail.counter = nullptr;
+  tail.pred = ctx->cur_pred; tail.pred_val = ctx->cur_pred_val;
+  tail.accept = nullptr; tail.cost_dev = nullptr; tail.slot_cur = tail.slot_trial = 0; tail.c0_use_imm = 1; tail.c0_imm = 0.0;
   if (publish_slot >= 0) {
     const size_t need = (size_t)128 * (2 + (size_t)L.koff[L.nsets] / EPI_GROUP);
     if (ctx->epi_counter.bytes < need) {
@@ -1818,7 +1838,12 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1
     }
     ctx->seq += 1.0;
     tail.on = 1; tail.acc = ctx->ngd.exch1.d(); tail.half_logdet = ctx->ngd.hld[publish_slot].d();
-    tail.host_out = ctx->host_slot_dev; tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
+    tail.host_out = ctx->host_slot_dev + 2 * ctx->pub_ring; tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
+    if (ctx->pipe_tail) {
+      tail.accept = ctx->pipe_dev.d() + ctx->pub_ring; tail.cost_dev = ctx->pipe_dev.d() + 2;   // accept word of THIS ring slot
+      tail.slot_cur = 1 - publish_slot; tail.slot_trial = publish_slot;
+      tail.c0_use_imm = ctx->pipe_c0_imm ? 1 : 0; tail.c0_imm = ctx->pipe_c0;
+    }
   }
   hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L, tail);
   HIPCK(ctx, hipGetLastError());
@@ -1885,7 +1910,7 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
     HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
     if (publish) {
       ctx->seq += 1.0;
-      hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev, ctx->seq);
+      hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev + 2 * ctx->pub_ring, ctx->seq);
       HIPCK(ctx, hipGetLastError());
     }
     return GVI_OK;
@@ -1902,7 +1927,7 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
   for (auto& s : ctx->sets) nfac = std::max<int64_t>(nfac, s->K);
   const unsigned nblk = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, (nfac + 255) / 256));
   hipLaunchKernelGGL(cost_tail_kernel, dim3(nblk), dim3(256), 0, ctx->stream, make_epi_list(ctx, 0, nullptr), g.exch1.d(),
-                     g.hld[i].d(), publish ? ctx->host_slot_dev : nullptr, ctx->seq, (unsigned*)ctx->tail_counter.p);
+                     g.hld[i].d(), publish ? ctx->host_slot_dev + 2 * ctx->pub_ring : nullptr, ctx->seq, (unsigned*)ctx->tail_counter.p);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -1910,8 +1935,8 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
 static gvi_status ngd_cost_publish(gvi_ctx* ctx, int i) {
   NgdState& g = ctx->ngd;
   ctx->seq += 1.0;
-  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev,
-                     ctx->seq);
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(),
+                     ctx->host_slot_dev + 2 * ctx->pub_ring, ctx->seq);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -1926,16 +1951,18 @@ static inline void cpu_relax() {
 #endif
 }
 
-static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
+static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out, double seq_expected = -1.0, int ring = -1) {
   NgdState& g = ctx->ngd;
+  const double want = seq_expected >= 0.0 ? seq_expected : ctx->seq;
+  const int rg = ring >= 0 ? ring : ctx->pub_ring;
   // Spin on the host-mapped sequence word: a blocking stream sync costs tens of us of wake-up latency and would
   // also wait for the speculative work queued behind the publish.  The spin is bounded by WALL TIME (2 ms -- an
   // iteration is < 1 ms); past that the wait sleeps between polls (below).
-  volatile double* slot = ctx->host_slot;
+  volatile double* slot = ctx->host_slot + 2 * rg;
   bool seen = false;
   const auto t0 = std::chrono::steady_clock::now();
   for (long spins = 0;; ++spins) {
-    if (slot[1] == ctx->seq) { seen = true; break; }
+    if (slot[1] == want) { seen = true; break; }
     cpu_relax();
     if ((spins & 1023) == 1023 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(ctx->spin_ms)) break;
@@ -1944,7 +1971,7 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
     // long passes (config 5: seconds per pass): sleep-poll the word and, every millisecond, the stream itself, so a
     // device fault or a drained stream without a publish ends the wait with an error instead of spinning
     for (long polls = 0;; ++polls) {
-      if (slot[1] == ctx->seq) { seen = true; break; }
+      if (slot[1] == want) { seen = true; break; }
       std::this_thread::sleep_for(std::chrono::microseconds(20));
       if ((polls & 63) == 63) {
         const hipError_t q = hipStreamQuery(ctx->stream);
@@ -1952,11 +1979,11 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out) {
         if (q != hipErrorNotReady) return fail(ctx, GVI_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
       }
     }
-    if (!seen && slot[1] != ctx->seq)
+    if (!seen && slot[1] != want)
       return fail(ctx, GVI_ERR_STATE, "cost publish did not arrive (sequence word stale after the stream drained)");
   }
   __sync_synchronize();
-  const double v = ctx->host_slot[0];                          // cost_value = sum of factor costs + 1/2 log det (added on the device)
+  const double v = slot[0];                          // cost_value = sum of factor costs + 1/2 log det (added on the device)
   g.cost[i] = v;
   g.cost_valid[i] = true;
   if (out) *out = v;
@@ -2075,6 +2102,7 @@ gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const d
   }
   g.gcur = 0; g.grad_valid = false; g.grad_slot = -1;
   ctx->solve_deferred[0] = ctx->solve_deferred[1] = false;
+  ctx->last_first_accepted = true;                 // adaptive fusing starts afresh: the pass order of a run must not depend on the previous problem
   HIPCK(ctx, g.exch1.ensure(8));
   HIPCK(ctx, g.dmu.ensure(T * n * 8));
   HIPCK(ctx, g.dLam.ensure(bt * 8));
@@ -2216,7 +2244,7 @@ static gvi_status ngd_scatter(gvi_ctx* ctx, int slot, int gb) {
   double* eU = eD + T * nn;
   const int64_t total = (int64_t)T * (n + 2 * nn);
   hipLaunchKernelGGL(bt_scatter_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     make_set_list(ctx, slot), ctx->T, ctx->n, eg, eD, eU);
+                     make_set_list(ctx, slot), ctx->T, ctx->n, eg, eD, eU, ctx->cur_pred, ctx->cur_pred_val);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -2438,18 +2466,13 @@ gvi_status gvi_ngd_accept(gvi_ctx* ctx) {
   return GVI_OK;
 }
 
-gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter, int* accepted,
-                        double* new_cost, int* ntrials) {
-  GVICK(ngd_check(ctx));
-  if (ctx->update_rule != GVI_RULE_NGD) return fail(ctx, GVI_ERR_STATE, "proximal rule selected: use gvi_prox_step");
-  HIPCK(ctx, hipSetDevice(ctx->device));
+// The backtracking loop of one iteration from trial number `cnt` on (step = the step of the LAST trial taken, or the base
+// before the first): step *= 0.75 per trial, first decrease accepted, give up after max_backtrack + 1 trials.
+static gvi_status ngd_linesearch(gvi_ctx* ctx, double c0, double step, int cnt, int max_backtrack, double* c1_out, int* ok_out,
+                                 int* cnt_out) {
   NgdState& g = ctx->ngd;
-  double c0 = 0.0;
-  GVICK(gvi_ngd_cost(ctx, &c0));
-  if (cost_iter) *cost_iter = c0;
-  if (!(g.grad_valid && g.grad_slot == g.cur)) GVICK(gvi_ngd_gradients(ctx));   // else: computed speculatively
-  double step = step_size_base, c1 = c0;
-  int cnt = 0, ok = 0;
+  double c1 = c0;
+  int ok = 0;
   while (true) {
     step *= 0.75;                                  // gvibase/GVI-GH-impl.h:83
     const int t = 1 - g.cur;
@@ -2505,31 +2528,208 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
     }
     if (cnt > max_backtrack) break;
   }
+  *c1_out = c1; *ok_out = ok; *cnt_out = cnt;
+  return GVI_OK;
+}
+
+gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, double* cost_iter, int* accepted,
+                        double* new_cost, int* ntrials) {
+  GVICK(ngd_check(ctx));
+  if (ctx->update_rule != GVI_RULE_NGD) return fail(ctx, GVI_ERR_STATE, "proximal rule selected: use gvi_prox_step");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
+  double c0 = 0.0;
+  GVICK(gvi_ngd_cost(ctx, &c0));
+  if (cost_iter) *cost_iter = c0;
+  if (!(g.grad_valid && g.grad_slot == g.cur)) GVICK(gvi_ngd_gradients(ctx));   // else: computed speculatively
+  double c1 = c0;
+  int cnt = 0, ok = 0;
+  GVICK(ngd_linesearch(ctx, c0, step_size_base, 0, max_backtrack, &c1, &ok, &cnt));
   if (accepted) *accepted = ok;
   if (new_cost) *new_cost = ok ? c1 : c0;
   if (ntrials) *ntrials = cnt;
   return GVI_OK;
 }
 
+// ---- gvi_ngd_run: the iteration loop, pipelined one iteration deep ----
+// gvi_ngd_step queues an iteration, waits for its trial cost on the host, decides, and only then queues the next one: the
+// device idles for the host's wake-up + launch latency (4-7 us of a 0.14 ms iteration in the kernel trace).  Here the launches
+// of iteration i + 1 are queued BEFORE the host has read the cost of iteration i, assuming its first trial is accepted (it
+// is, in the steady state); they are PREDICATED on a device word that the tail of iteration i sets only if its cost
+// decreased (same comparison, same doubles as the host's), so a rejected trial turns them into no-ops, the host rolls its
+// bookkeeping back and continues that iteration's backtracking exactly as gvi_ngd_step would.  Same numbers either way
+// (tests/test_gpu_parity.py::test_ngd_run_equals_the_same_sequence_of_steps, with rejected first trials).
+namespace {
+struct PipeSnapshot {
+  int cur, gcur, grad_slot;
+  bool grad_valid, have_trial, spec_ready, cost_valid[2], solve_deferred[2], solve_pending[2], last_first_accepted;
+  double cost[2];
+  NgdState::GatherPending gpend[2];
+  int64_t n_full, n_cost;
+  long profile_count;
+  std::vector<int> prep_slot, warm_count;
+};
+
+void pipe_save(const gvi_ctx* c, PipeSnapshot& p) {
+  const NgdState& g = c->ngd;
+  p.cur = g.cur; p.gcur = g.gcur; p.grad_slot = g.grad_slot; p.grad_valid = g.grad_valid; p.have_trial = g.have_trial;
+  p.spec_ready = g.spec_ready; p.last_first_accepted = c->last_first_accepted;
+  for (int i = 0; i < 2; ++i) {
+    p.cost_valid[i] = g.cost_valid[i]; p.cost[i] = g.cost[i]; p.gpend[i] = g.gpend[i];
+    p.solve_deferred[i] = c->solve_deferred[i]; p.solve_pending[i] = c->solve_pending[i];
+  }
+  p.n_full = c->n_full_pass; p.n_cost = c->n_cost_pass; p.profile_count = c->profile_count;
+  p.prep_slot.clear(); p.warm_count.clear();
+  for (const auto& s : c->sets) { p.prep_slot.push_back(s->prep_slot); p.warm_count.push_back(s->warm_count); }
+}
+
+void pipe_restore(gvi_ctx* c, const PipeSnapshot& p) {
+  NgdState& g = c->ngd;
+  g.cur = p.cur; g.gcur = p.gcur; g.grad_slot = p.grad_slot; g.grad_valid = p.grad_valid; g.have_trial = p.have_trial;
+  g.spec_ready = p.spec_ready; c->last_first_accepted = p.last_first_accepted;
+  for (int i = 0; i < 2; ++i) {
+    g.cost_valid[i] = p.cost_valid[i]; g.cost[i] = p.cost[i]; g.gpend[i] = p.gpend[i];
+    c->solve_deferred[i] = p.solve_deferred[i]; c->solve_pending[i] = p.solve_pending[i];
+  }
+  c->n_full_pass = p.n_full; c->n_cost_pass = p.n_cost; c->profile_count = p.profile_count;
+  for (size_t i = 0; i < c->sets.size(); ++i) { c->sets[i]->prep_slot = p.prep_slot[i]; c->sets[i]->warm_count = p.warm_count[i]; }
+}
+
+// every launch of a queued iteration must be one of the predicated kernels: the dual chain launches, the prep launch with
+// the fused gather, the two-set sign-orbit launch, the epilogue with its tail, the assemble
+bool pipe_ok(const gvi_ctx* c) {
+  if (!c->pipeline || dist_on(c) || c->update_rule != GVI_RULE_NGD || !c->speculate || c->fuse_trial == 0) return false;
+  if (!(c->dual_chain && c->side_solve && seg_supported(c->n) && c->bcr_variant != 1 && c->T > 1)) return false;
+  if (!c->fuse_gather || !c->pair_fuse || c->profile_all || c->sets.size() != 2) return false;
+  const FactorSet& s0 = *c->sets[0];
+  const FactorSet& s1 = *c->sets[1];
+  return orbit_supported(c, s0) && orbit_supported(c, s1) && s0.m == s1.m && s0.all_pos && s1.all_pos && !s0.closed_form &&
+         !s1.closed_form && s0.K > 0 && s1.K > 0;
+}
+}  // namespace
+
+// one iteration's launches with a fused first trial (the non-sharded branch of ngd_linesearch, first trial)
+static gvi_status pipe_enqueue(gvi_ctx* ctx, double step) {
+  NgdState& g = ctx->ngd;
+  const int t = 1 - g.cur;
+  GVICK(ngd_trial_state(ctx, step));
+  GVICK(ngd_moments_full(ctx, t, t));
+  GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
+  return ngd_grad_finish(ctx, 1 - g.gcur);
+}
+
 gvi_status gvi_ngd_run(gvi_ctx* ctx, int max_iters, double step_size_base, int max_backtrack, double* cost_iter,
                        int* accepted, double* new_cost, int* ntrials, int* iters_done) {
   GVICK(ngd_check(ctx));
   if (max_iters < 0) return fail(ctx, GVI_ERR_ARG, "max_iters < 0");
+  if (ctx->update_rule != GVI_RULE_NGD) return fail(ctx, GVI_ERR_STATE, "proximal rule selected: use gvi_prox_step");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  NgdState& g = ctx->ngd;
   int done = 0;
-  for (int i = 0; i < max_iters; ++i) {
-    double c0 = 0.0, c1 = 0.0;
-    int ok = 0, nt = 0;
-    const gvi_status st = gvi_ngd_step(ctx, step_size_base, max_backtrack, &c0, &ok, &c1, &nt);
-    if (st != GVI_OK) { if (iters_done) *iters_done = done; return st; }
-    if (cost_iter) cost_iter[i] = c0;
-    if (accepted) accepted[i] = ok;
-    if (new_cost) new_cost[i] = c1;
-    if (ntrials) ntrials[i] = nt;
+  auto record = [&](double c0, int ok, double c1, int nt) {
+    if (cost_iter) cost_iter[done] = c0;
+    if (accepted) accepted[done] = ok;
+    if (new_cost) new_cost[done] = c1;
+    if (ntrials) ntrials[done] = nt;
     ++done;
+  };
+  auto finish = [&](gvi_status st) {
+    ctx->cur_pred = nullptr; ctx->pipe_tail = false; ctx->pipe_c0_imm = true; ctx->pub_ring = 0;
+    if (iters_done) *iters_done = done;
+    return st;
+  };
+  bool pending = false;          // the launches of iteration `done` are already queued (speculatively; their predicate held)
+  double pend_seq = 0.0;
+  int pend_ring = 0;
+  const double step1 = step_size_base * 0.75;
+  while (done < max_iters) {
+    const bool fused_first = ctx->fuse_trial == 1 || (ctx->fuse_trial == 2 && ctx->last_first_accepted);
+    if (!pending && !(pipe_ok(ctx) && fused_first)) {           // the plain iteration
+      double c0 = 0.0, c1 = 0.0;
+      int ok = 0, nt = 0;
+      const gvi_status st = gvi_ngd_step(ctx, step_size_base, max_backtrack, &c0, &ok, &c1, &nt);
+      if (st != GVI_OK) return finish(st);
+      record(c0, ok, c1, nt);
+      if (!ok) break;
+      continue;
+    }
+    double c0 = 0.0, seq_i = 0.0;
+    int ring_i = 0;
+    if (!pending) {
+      gvi_status st = gvi_ngd_cost(ctx, &c0);
+      if (st == GVI_OK && !(g.grad_valid && g.grad_slot == g.cur)) st = gvi_ngd_gradients(ctx);
+      if (st != GVI_OK) return finish(st);
+      if (!ctx->solve_deferred[g.gcur]) {                       // not in the dual-launch state: one plain iteration
+        double c1 = 0.0;
+        int ok = 0, nt = 0;
+        st = gvi_ngd_step(ctx, step_size_base, max_backtrack, &c0, &ok, &c1, &nt);
+        if (st != GVI_OK) return finish(st);
+        record(c0, ok, c1, nt);
+        if (!ok) break;
+        continue;
+      }
+      if (!ctx->pipe_dev.p) {
+        HIPCK(ctx, ctx->pipe_dev.ensure(64));
+        HIPCK(ctx, hipMemsetAsync(ctx->pipe_dev.p, 0, 64, ctx->stream));
+      }
+      ctx->cur_pred = nullptr; ctx->pipe_tail = true; ctx->pipe_c0_imm = true; ctx->pipe_c0 = c0; ctx->pub_ring = 0;
+      st = pipe_enqueue(ctx, step1);
+      ctx->pipe_tail = false;
+      if (st != GVI_OK) return finish(st);
+      seq_i = ctx->seq; ring_i = 0;
+    } else {
+      c0 = g.cost[g.cur]; seq_i = pend_seq; ring_i = pend_ring;
+    }
+    // queue iteration i + 1 behind it, predicated on the acceptance of trial i
+    const bool spec_next = done + 1 < max_iters;
+    PipeSnapshot snap;
+    double seq_n = 0.0;
+    if (spec_next) {
+      pipe_save(ctx, snap);
+      gvi_status st = gvi_ngd_accept(ctx);                      // provisional: cur <- trial slot
+      if (st != GVI_OK) return finish(st);
+      g.gcur = 1 - g.gcur; g.grad_valid = true; g.grad_slot = g.cur;
+      ctx->last_first_accepted = true;
+      // (the accept words alternate like the host slots: this iteration's own tail writes the OTHER word, so its assemble,
+      // which runs after that tail, still sees the predicate it was queued under)
+      ctx->cur_pred = ctx->pipe_dev.d() + ring_i; ctx->cur_pred_val = seq_i;
+      ctx->pipe_tail = true; ctx->pipe_c0_imm = false; ctx->pub_ring = 1 - ring_i;
+      st = pipe_enqueue(ctx, step1);
+      ctx->cur_pred = nullptr; ctx->pipe_tail = false; ctx->pipe_c0_imm = true; ctx->pub_ring = 0;
+      if (st != GVI_OK) return finish(st);
+      seq_n = ctx->seq;
+    }
+    const int ti = spec_next ? g.cur : 1 - g.cur;                // NGD slot of trial i
+    double c1 = 0.0;
+    {
+      const gvi_status st = ngd_cost_wait(ctx, ti, &c1, seq_i, ring_i);
+      if (st != GVI_OK) return finish(st);
+    }
+    if (c1 < c0) {                                               // accepted (NaN compares false)
+      ctx->last_first_accepted = true;
+      if (!spec_next) {
+        const gvi_status st = gvi_ngd_accept(ctx);
+        if (st != GVI_OK) return finish(st);
+        g.gcur = 1 - g.gcur; g.grad_valid = true; g.grad_slot = g.cur;
+      }
+      record(c0, 1, c1, 1);
+      pending = spec_next; pend_seq = seq_n; pend_ring = 1 - ring_i;
+      continue;
+    }
+    // first trial rejected: the device skipped everything queued for iteration i + 1
+    if (spec_next) pipe_restore(ctx, snap);
+    pending = false;
+    ctx->last_first_accepted = false;
+    double c1b = c0;
+    int ok = 0, cnt = 1;
+    if (cnt <= max_backtrack) {
+      const gvi_status st = ngd_linesearch(ctx, c0, step1, 1, max_backtrack, &c1b, &ok, &cnt);
+      if (st != GVI_OK) return finish(st);
+    }
+    record(c0, ok, ok ? c1b : c0, cnt);
     if (!ok) break;
   }
-  if (iters_done) *iters_done = done;
-  return GVI_OK;
+  return finish(GVI_OK);
 }
 
 gvi_status gvi_ngd_set_update_rule(gvi_ctx* ctx, int rule) {
@@ -2816,6 +3016,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "no_scost") ctx->no_scost = value != 0;
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);
   else if (n == "orbit") ctx->orbit = value != 0;
+  else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") { ctx->jacobi_tol = std::pow(10.0, (double)std::min(-20, value)); for (auto& s : ctx->sets) s->jtol = ctx->jacobi_tol; }
   else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);

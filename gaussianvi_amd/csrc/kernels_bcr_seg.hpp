@@ -73,6 +73,8 @@ struct SegArgs {
   const double* mixVD;
   double* mixOutD;
   double mix_step;
+  const double* pred;    // predicated launch (device_common.hpp, pred_skip) or null
+  double pred_val;
 };
 
 __device__ __forceinline__ double* ws_mat(const SegArgs& a, int idx) { return a.w.base + (size_t)idx * a.T * (a.n * a.n); }
@@ -540,6 +542,7 @@ __device__ __forceinline__ void bcr_seg_forward_body(const SegArgs& a, const int
 template <bool PIVOT, int N>
 __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
   extern __shared__ double sm[];
+  if (pred_skip(a.pred, a.pred_val)) return;
   bcr_seg_forward_body<PIVOT, N>(a, (int)blockIdx.x, sm);
 }
 
@@ -551,6 +554,7 @@ __global__ __launch_bounds__(1024) void bcr_seg_forward_kernel(SegArgs a) {
 template <int N>
 __global__ __launch_bounds__(1024) void bcr_seg_forward_dual_kernel(SegArgs a0, SegArgs a1, int nb0) {
   extern __shared__ double sm[];
+  if (pred_skip(a0.pred, a0.pred_val)) return;
   if ((int)blockIdx.x < nb0) bcr_seg_forward_body<false, N>(a0, (int)blockIdx.x, sm);
   else bcr_seg_forward_body<true, N>(a1, (int)blockIdx.x - nb0, sm);
 }
@@ -679,12 +683,14 @@ __device__ __forceinline__ void bcr_seg_backward_body(const SegArgs& a, const in
 template <int N>
 __global__ __launch_bounds__(1024) void bcr_seg_backward_kernel(SegArgs a) {
   extern __shared__ double sm[];
+  if (pred_skip(a.pred, a.pred_val)) return;
   bcr_seg_backward_body<N>(a, (int)blockIdx.x, sm);
 }
 
 template <int N>
 __global__ __launch_bounds__(1024) void bcr_seg_backward_dual_kernel(SegArgs a0, SegArgs a1, int nb0) {
   extern __shared__ double sm[];
+  if (pred_skip(a0.pred, a0.pred_val)) return;
   if ((int)blockIdx.x < nb0) bcr_seg_backward_body<N>(a0, (int)blockIdx.x, sm);
   else bcr_seg_backward_body<N>(a1, (int)blockIdx.x - nb0, sm);
 }

@@ -644,7 +644,9 @@ struct SetList { int nsets; SetDesc s[MAX_SETS]; };
 // assemble over ALL sets: every output element is written once (ordered: set after set, factor
 // index ascending), so no memset and no second launch
 __global__ __launch_bounds__(256) void bt_scatter_all_kernel(SetList L, int T, int n, double* __restrict__ g,
-                                                             double* __restrict__ D, double* __restrict__ U) {
+                                                             double* __restrict__ D, double* __restrict__ U,
+                                                             const double* pred, double pred_val) {
+  if (pred_skip(pred, pred_val)) return;
   const int nn = n * n, per = n + 2 * nn;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= (int64_t)T * per) return;

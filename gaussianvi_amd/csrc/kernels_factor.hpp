@@ -500,12 +500,15 @@ struct PrepList {
   const int32_t* start[MAX_FSETS];
   double* mu_k[MAX_FSETS];
   double* Sigma_k[MAX_FSETS];
+  const double* pred;    // predicated launch (device_common.hpp, pred_skip) or null
+  double pred_val;
 };
 
 template <int EPLP>
 __global__ __launch_bounds__(64) void prep_all_kernel(PrepList L) {
   extern __shared__ double sm[];
   const int lane = threadIdx.x;
+  if (pred_skip(L.pred, L.pred_val)) return;
   if ((int)blockIdx.x >= L.koff[L.nsets]) {                      // chain-level trial mean (gather mode only)
     const int64_t j = (int64_t)((int)blockIdx.x - L.koff[L.nsets]) * 64 + lane;
     if (j < L.nmu) L.mu_out[j] = L.gmu[j] + L.gstep * L.gdmu[j];
@@ -2114,10 +2117,21 @@ struct EpiTail {
   double* host_out;            // host-mapped {cost_sum, half_logdet, sequence} or null
   double seq;
   unsigned* counter;           // [32 (1 + ceil(blocks / EPI_GROUP))] arrival counters, 128 B apart, zero before the launch
+  // pipelined iterations (gvi_ngd_run): the accept decision is ALSO taken on the device, so that the next iteration's
+  // launches -- queued before the host has read this cost -- can be predicated on it.  accept[0] <- seq if
+  // cost < current cost else 0; cost_dev[slot_trial] <- cost; the current cost is c0_imm or cost_dev[slot_cur].
+  const double* pred;          // predicate of THIS launch (device_common.hpp, pred_skip) or null
+  double pred_val;
+  double* accept;              // null: no device-side decision
+  double* cost_dev;            // [2] cost of the state in slot 0 / 1
+  int slot_cur, slot_trial;
+  int c0_use_imm;
+  double c0_imm;
 };
 
 __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tail) {
   extern __shared__ double sm[];
+  if (pred_skip(tail.pred, tail.pred_val)) return;
   int si = 0;
   while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
   const int kf = (int)blockIdx.x - L.koff[si];
@@ -2199,8 +2213,12 @@ __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tai
   if (lane == 0) {
     __hip_atomic_store(tail.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     tail.acc[0] = total;
-    if (tail.host_out) {
-      publish_to_host(tail.host_out, total + tail.half_logdet[0], tail.seq);
+    const double c1 = total + tail.half_logdet[0];
+    if (tail.host_out) publish_to_host(tail.host_out, c1, tail.seq);
+    if (tail.accept) {                                    // same comparison as the host's (NaN compares false: rejected)
+      const double c0 = tail.c0_use_imm ? tail.c0_imm : tail.cost_dev[tail.slot_cur];
+      tail.cost_dev[tail.slot_trial] = c1;
+      tail.accept[0] = c1 < c0 ? tail.seq : 0.0;
     }
   }
   wave_lds_sync();

@@ -47,6 +47,8 @@ struct OrbitArgs {
   double* partial;           // [K][nchunk][npairs(d)] (full) or [K][nchunk] (cost)
   int K, d, nchunk;
   int copies;                // private copies of every accumulator entry (power of two <= 16), selected by lane % copies
+  const double* pred;        // predicated launch (device_common.hpp, pred_skip) or null
+  double pred_val;
   OrbitDev ob;
 };
 
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(256, WAVES) void moments_orbit_kernel(OrbitArgs a) 
   extern __shared__ double sm[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int k = (int)blockIdx.x * 4 + wave;
+  if (pred_skip(a.pred, a.pred_val)) return;
   if (k >= a.K) return;                          // no block-level barrier below
   orbit_wave<M, SMAX, FULL, SIGNED>(a, k, (int)blockIdx.y, sm + (size_t)wave * orbit_lds_doubles(a.d, M, a.copies));
 }
@@ -241,6 +244,7 @@ template <int M, int SMAX, bool FULL, bool SIGNED, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void moments_orbit_pair_kernel(OrbitArgs a0, OrbitArgs a1, int nbx0, int nb0, int nbx1) {
   extern __shared__ double sm[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (pred_skip(a0.pred, a0.pred_val)) return;
   int id = (int)blockIdx.x;
   const bool second = id >= nb0;
   if (second) id -= nb0;
