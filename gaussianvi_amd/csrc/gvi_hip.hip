@@ -2114,8 +2114,9 @@ gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const d
   GVICK(h2d(ctx, g.mu[0].p, mu, T * n * 8));
   GVICK(h2d(ctx, g.Lam[0].p, D, T * nn * 8));
   if (T > 1) GVICK(h2d(ctx, g.Lam[0].d() + T * nn, U, (T - 1) * nn * 8));
-  GVICK(ngd_refresh(ctx, 0));
-  GVICK(sync(ctx));
+  GVICK(sync(ctx));                                // the caller's buffers are free on return
+  GVICK(ngd_refresh(ctx, 0));                      // stream-ordered before everything that follows: not waited for
+  HIPCK(ctx, hipGetLastError());
   g.ready = true;
   return GVI_OK;
 }
@@ -2466,6 +2467,25 @@ gvi_status gvi_ngd_accept(gvi_ctx* ctx) {
   return GVI_OK;
 }
 
+// Cost and gradients at the current state for the start of an iteration.  When NEITHER is there yet (first iteration after
+// gvi_ngd_init) one full moments pass serves both -- its m0 column is the cost, exactly as in a fused trial -- instead of a
+// cost-only pass followed by the gradient pass.
+static gvi_status ngd_iteration_entry(gvi_ctx* ctx, double* c0) {
+  NgdState& g = ctx->ngd;
+  const bool have_grad = g.grad_valid && g.grad_slot == g.cur;
+  if (!g.cost_valid[g.cur] && !have_grad && ctx->fuse_trial != 0 && !dist_on(ctx) && !ctx->sets.empty()) {
+    ctx->solve_deferred[g.gcur] = false;
+    GVICK(ngd_moments_full(ctx, g.cur, g.cur));          // epilogue + ordered cost sum + publish in one launch
+    GVICK(ngd_scatter(ctx, g.cur, g.gcur));
+    GVICK(ngd_grad_finish(ctx, g.gcur));
+    g.grad_valid = true; g.grad_slot = g.cur;
+    return ngd_cost_wait(ctx, g.cur, c0);
+  }
+  GVICK(gvi_ngd_cost(ctx, c0));
+  if (!have_grad) GVICK(gvi_ngd_gradients(ctx));         // else: computed speculatively
+  return GVI_OK;
+}
+
 // The backtracking loop of one iteration from trial number `cnt` on (step = the step of the LAST trial taken, or the base
 // before the first): step *= 0.75 per trial, first decrease accepted, give up after max_backtrack + 1 trials.
 static gvi_status ngd_linesearch(gvi_ctx* ctx, double c0, double step, int cnt, int max_backtrack, double* c1_out, int* ok_out,
@@ -2539,9 +2559,8 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
   HIPCK(ctx, hipSetDevice(ctx->device));
   NgdState& g = ctx->ngd;
   double c0 = 0.0;
-  GVICK(gvi_ngd_cost(ctx, &c0));
+  GVICK(ngd_iteration_entry(ctx, &c0));
   if (cost_iter) *cost_iter = c0;
-  if (!(g.grad_valid && g.grad_slot == g.cur)) GVICK(gvi_ngd_gradients(ctx));   // else: computed speculatively
   double c1 = c0;
   int cnt = 0, ok = 0;
   GVICK(ngd_linesearch(ctx, c0, step_size_base, 0, max_backtrack, &c1, &ok, &cnt));
@@ -2656,8 +2675,7 @@ gvi_status gvi_ngd_run(gvi_ctx* ctx, int max_iters, double step_size_base, int m
     double c0 = 0.0, seq_i = 0.0;
     int ring_i = 0;
     if (!pending) {
-      gvi_status st = gvi_ngd_cost(ctx, &c0);
-      if (st == GVI_OK && !(g.grad_valid && g.grad_slot == g.cur)) st = gvi_ngd_gradients(ctx);
+      gvi_status st = ngd_iteration_entry(ctx, &c0);
       if (st != GVI_OK) return finish(st);
       if (!ctx->solve_deferred[g.gcur]) {                       // not in the dual-launch state: one plain iteration
         double c1 = 0.0;
