@@ -34,3 +34,13 @@ import json
 d=json.load(open("$O/bench_rehearsal2.json"))
 print("rehearsal n=2 final", d["final_cost"], "ms/step", d["ms_per_step"])
 PY
+# steady-state iteration time p and restart cost R from two restart periods: t(r) = r p + R
+for r in 15 30; do
+  timeout -k 10 200 python bench.py --steps 600 --warmup 30 --restart-every $r --no-cpu-baseline > $O/bench_restart$r.json 2>/dev/null || exit 1
+done
+python - <<PY
+import json
+t = {r: json.load(open("$O/bench_restart%d.json" % r))["ms_per_step"] * r for r in (15, 30)}
+p = (t[30] - t[15]) / 15.0
+print("steady-state iteration p = %.2f us, restart R = %.1f us" % (1e3 * p, 1e3 * (t[15] - 15 * p)))
+PY
