@@ -188,6 +188,7 @@ struct gvi_ctx {
   // sum-of-squares sets: per-pass products from the Cholesky factor of the marginal instead of its symmetric square root
   // (same moments -- the quadrature is exact there -- without the Jacobi sweeps); GVI_CHOL_SQRT=0 / option "chol_sqrt"
   bool chol_sqrt = true;
+  int orbit_min_tiles = 6;            // GVI_ORBIT_MIN_TILES
   int orbit_copies = 8;               // private LDS copies of the accumulators (1, 2, 4, 8, 16; fewer when LDS is short)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
@@ -703,7 +704,11 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   else if (orbit) {
     reg = false;
     const int64_t tiles = (int64_t)s.table->orb.tile_s.size();
-    s.nchunk = (int)std::min<int64_t>(tiles, std::max<int64_t>(1, (c->orbit_waves + s.K - 1) / s.K));
+    // chunks: enough waves to fill the chip, but at least orbit_min_tiles tiles per wave -- a wave's prologue (H into LDS,
+    // zeroing the accumulator copies) and its reduction of the copies cost about as much as two tiles
+    const int64_t by_waves = std::max<int64_t>(1, (c->orbit_waves + s.K - 1) / s.K);
+    const int64_t by_tiles = std::max<int64_t>(1, tiles / std::max(1, c->orbit_min_tiles));
+    s.nchunk = (int)std::min<int64_t>(tiles, std::min(by_waves, by_tiles));
     s.chunk = s.table->Np;
   } else if (split) {
     const int64_t tiles = s.table->Np / 64;                          // ~2 blocks per CU: K * nchunk >= 1024
@@ -1137,6 +1142,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_CHOL_SQRT")) c->chol_sqrt = atoi(w) != 0;
   if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
   if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
+  if (const char* w = getenv("GVI_ORBIT_MIN_TILES")) c->orbit_min_tiles = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_ORBIT_COPIES")) c->orbit_copies = std::min(16, std::max(1, atoi(w)));
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
   if (const char* w = getenv("GVI_MIRROR")) c->mirror = atoi(w) != 0;
@@ -3038,6 +3044,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") { ctx->jacobi_tol = std::pow(10.0, (double)std::min(-20, value)); for (auto& s : ctx->sets) s->jtol = ctx->jacobi_tol; }
   else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);
+  else if (n == "orbit_min_tiles") ctx->orbit_min_tiles = std::max(1, value);
   else if (n == "orbit_copies") ctx->orbit_copies = std::min(16, std::max(1, value));
   else return fail(ctx, GVI_ERR_ARG, "unknown option: " + n);
   for (auto& s : ctx->sets) s->prep_slot = -1;
