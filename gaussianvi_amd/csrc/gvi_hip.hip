@@ -595,7 +595,8 @@ void dispatch_scost(gvi_ctx* c, const FactorSet& s, const MomArgs& a, int nchunk
 bool orbit_supported(const gvi_ctx* c, const FactorSet& s) {
   if (!c->orbit || !(c->variant == 0 || c->variant == 6)) return false;
   if (s.kind != KIND_QUAD_PRIOR && s.kind != KIND_FIXED_PRIOR) return false;
-  if (!(s.m == 6 || s.m == 12) || s.d > 32) return false;
+  if (!(s.m == 2 || s.m == 6 || s.m == 12) || s.d > 32) return false;
+  if (s.m == 2 && s.table->orb.smax > 4) return false;          // m = 2 is instantiated for degree <= 5 only
   const OrbitHost& o = s.table->orb;
   return o.ok && o.smax >= 1 && o.smax <= ORBIT_SMAX && !o.tile_s.empty();
 }
@@ -615,7 +616,7 @@ gvi_status orbit_args(gvi_ctx* c, FactorSet& s, int full, OrbitArgs* out) {
   a.K = s.K; a.d = s.d; a.nchunk = s.nchunk;
   a.pred = c->cur_pred; a.pred_val = c->cur_pred_val;
   // private accumulator copies: as many as the kernel's occupancy leaves LDS for (160 KB per CU, 64 KB per block), capped by orbit_copies
-  const int waves = (s.m == 6 && t.orb.smax <= 4) ? 4 : ((s.m == 12 && t.orb.smax <= 4) ? 3 : 2);   // launch_orbit's occupancy
+  const int waves = ((s.m == 6 && t.orb.smax <= 4) || s.m == 2) ? 4 : ((s.m == 12 && t.orb.smax <= 4) ? 3 : 2);   // launch_orbit's occupancy
   const size_t lds_cap = std::min<size_t>(64 * 1024, 160 * 1024 / waves);
   a.copies = 1;
   while (a.copies * 2 <= c->orbit_copies && (size_t)4 * orbit_lds_doubles(s.d, s.m, a.copies * 2) * 8 <= lds_cap) a.copies *= 2;
@@ -638,7 +639,8 @@ void launch_orbit_t(const OrbitArgs& a, bool full, bool all_pos, dim3 grid, size
 void launch_orbit(const OrbitArgs& a, int m, int smax, bool full, bool all_pos, hipStream_t st) {
   const dim3 grid((a.K + 3) / 4, a.nchunk);
   const size_t lds = (size_t)4 * orbit_lds_doubles(a.d, m, a.copies) * 8;
-  if (m == 6 && smax <= 4) launch_orbit_t<6, 4, 4>(a, full, all_pos, grid, lds, st);
+  if (m == 2) launch_orbit_t<2, 4, 4>(a, full, all_pos, grid, lds, st);
+  else if (m == 6 && smax <= 4) launch_orbit_t<6, 4, 4>(a, full, all_pos, grid, lds, st);
   else if (m == 6) launch_orbit_t<6, 6, 2>(a, full, all_pos, grid, lds, st);
   else if (smax <= 4) launch_orbit_t<12, 4, 3>(a, full, all_pos, grid, lds, st);
   else launch_orbit_t<12, 6, 2>(a, full, all_pos, grid, lds, st);
@@ -662,7 +664,8 @@ void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, si
 void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st,
                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const size_t lds = (size_t)4 * std::max(orbit_lds_doubles(a0.d, m, a0.copies), orbit_lds_doubles(a1.d, m, a1.copies)) * 8;
-  if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st, e0, e1);
+  if (m == 2) launch_orbit_pair_t<2, 4, 4>(a0, a1, full, lds, st, e0, e1);
+  else if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st, e0, e1);
   else if (m == 6) launch_orbit_pair_t<6, 6, 2>(a0, a1, full, lds, st, e0, e1);
   else if (smax <= 4) launch_orbit_pair_t<12, 4, 3>(a0, a1, full, lds, st, e0, e1);
   else launch_orbit_pair_t<12, 6, 2>(a0, a1, full, lds, st, e0, e1);

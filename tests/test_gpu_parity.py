@@ -959,6 +959,7 @@ def test_hand_pipelined_body_is_bit_identical(monkeypatch, kind, d, p, K):
         psi_kind, n_state = api.PSI_FIXED_PRIOR, d
     mu, Sigma = syn.random_marginals(rng, K, d, 0.4)
     outs = []
+    monkeypatch.setenv("GVI_ORBIT", "0")                  # this test is about the lane-per-point kernels
     monkeypatch.setenv("GVI_MIRROR", "0")
     for pipe in ("0", "1"):
         monkeypatch.setenv("GVI_SREG_PIPE", pipe)
@@ -986,7 +987,8 @@ def test_hand_pipelined_body_is_bit_identical(monkeypatch, kind, d, p, K):
 
 
 @pytest.mark.parametrize("kind,d,m,p,K", [("quad", 12, 6, 5, 9), ("fixed", 6, 6, 5, 7), ("fixed", 6, 6, 7, 5), ("quad", 12, 6, 3, 6),
-                                          ("quad", 24, 12, 4, 5), ("fixed", 12, 12, 6, 3), ("quad", 12, 6, 7, 2), ("quad", 24, 12, 6, 1)])
+                                          ("quad", 24, 12, 4, 5), ("fixed", 12, 12, 6, 3), ("quad", 12, 6, 7, 2), ("quad", 24, 12, 6, 1),
+                                          ("quad", 4, 2, 5, 7), ("fixed", 2, 2, 3, 5)])
 def test_sign_orbit_kernel_vs_lane_per_point_and_oracle(kind, d, m, p, K):
     """moments_orbit_kernel (lane = sign orbit, half-orbit Gray-code walk, LDS accumulators) for support sizes 1..6 and
     m = 6 / 12 against (a) the lane-per-point kernels on the same inputs, (b) the oracle; run-to-run bit-identical (the
