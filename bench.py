@@ -419,8 +419,8 @@ def main():
                                    f"(state re-initialised inside the timed region every {args.restart_every} steps)",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": (f"factors/{world} contiguous; per pass: all-gather of each rank's state records of [g|D|U] "
-                                    f"({ctx.dist_info()['records_per_rank']} states per rank, folded in rank order) + all-gather of the partial "
-                                    f"cost sums, issued inside the library ({'gloo callback (rehearsal)' if rehearsal else 'RCCL'})") if sharded else "none",
+                                    f"({ctx.dist_info()['records_per_rank']} states per rank, folded in rank order) with the partial cost sum as one "
+                                    f"more record (one all-gather per iteration), issued inside the library ({'gloo callback (rehearsal)' if rehearsal else 'RCCL'})") if sharded else "none",
                        "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"],
                        "mirror_pairs": bool(geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"),
                        "fuse_trial": args.fuse_trial},
@@ -462,7 +462,7 @@ def main():
         if world > 1:
             # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU kernel times of this round
             # (profiles/): factor work W shards, the chain recursions R are replicated, two exchanges X are added.
-            W, R, X = 0.048, 0.092, 0.040                     # ms, DESIGN section 5 (profiles/r02_f_kernel_stats.csv)
+            W, R, X = 0.048, 0.092, 0.030                     # ms, DESIGN section 5 (profiles/r02_f_kernel_stats.csv)
             out["strong_scaling_model"] = {"W_ms_sharded": W, "R_ms_replicated": R, "X_ms_exchange": X,
                                            "expected_speedup_at_n": (W + R) / (W / world + R + X),
                                            "note": "t(N) = W / N + R + X; the ceiling as N grows is (W + R) / (R + X)"}

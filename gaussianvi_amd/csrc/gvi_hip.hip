@@ -2052,14 +2052,14 @@ static gvi_status dist_ranges(gvi_ctx* ctx) {
   HIPCK(ctx, hipMemcpyAsync(d.ranges.p, packed.data(), packed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCK(ctx, hipStreamSynchronize(ctx->stream));
   const size_t per = (size_t)ctx->n + 2 * nn_(ctx);
-  HIPCK(ctx, d.send.ensure((size_t)d.maxlen * per * 8));
-  HIPCK(ctx, d.recv.ensure(std::max<size_t>((size_t)W * d.maxlen * per * 8, (size_t)2 * W * 8)));
+  HIPCK(ctx, d.send.ensure((size_t)(d.maxlen + 1) * per * 8));                     // + the cost record of the fused trial
+  HIPCK(ctx, d.recv.ensure(std::max<size_t>((size_t)W * (d.maxlen + 1) * per * 8, (size_t)2 * W * 8)));
   d.ranges_valid = true;
   return GVI_OK;
 }
 
 // exchange 0 on gradient buffer gb: pack own records -> all-gather -> fold in rank order back into exch0[gb]
-static gvi_status dist_exchange0(gvi_ctx* ctx, int gb) {
+static gvi_status dist_exchange0(gvi_ctx* ctx, int gb, bool with_cost = false) {
   if (!dist_on(ctx)) return GVI_OK;
   GVICK(dist_ranges(ctx));
   gvi_ctx::Dist& d = ctx->dist;
@@ -2068,14 +2068,17 @@ static gvi_status dist_exchange0(gvi_ctx* ctx, int gb) {
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
   const int lo = d.lo[d.rank], len = d.hi[d.rank] - d.lo[d.rank] + 1;
-  const int64_t np = (int64_t)d.maxlen * per;
+  // with_cost: the rank's partial cost sum (exch1[0]) rides as one more record and comes back as the ordered total in
+  // exch1[0] -- one all-gather for the fused trial instead of exchange 0 + exchange 1
+  const int stride = d.maxlen + (with_cost ? 1 : 0);
+  const int64_t np = (int64_t)stride * per;
   hipLaunchKernelGGL(dist_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, lo, len, d.maxlen,
-                     eg, eD, eU, d.send.d());
+                     eg, eD, eU, d.send.d(), with_cost ? (const double*)ctx->ngd.exch1.d() : (const double*)nullptr);
   HIPCK(ctx, hipGetLastError());
   GVICK(dist_allgather(ctx, d.send.p, d.recv.p, np));
-  const int64_t nf = (int64_t)T * per;
-  hipLaunchKernelGGL(dist_fold_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, d.world, d.maxlen,
-                     (const int32_t*)d.ranges.p, d.recv.d(), eg, eD, eU);
+  const int64_t nf = (int64_t)T * per + 1;
+  hipLaunchKernelGGL(dist_fold_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, d.world, d.maxlen, stride,
+                     (const int32_t*)d.ranges.p, d.recv.d(), eg, eD, eU, with_cost ? ctx->ngd.exch1.d() : (double*)nullptr);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -2514,20 +2517,24 @@ static gvi_status ngd_linesearch(gvi_ctx* ctx, double c0, double step, int cnt, 
       // less per accepted iteration; a rejected first trial wasted the moment accumulation.
       if (dist_on(ctx)) {
         // sharded: the local cost sum and the local [g | D | U] go through the two exchanges before publish / solve
+        // (ONE all-gather: the partial cost sum rides with the gradient records; the publish follows it)
         GVICK(ngd_moments_full(ctx, t));
         hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, t), g.exch1.d());
         HIPCK(ctx, hipGetLastError());
-        GVICK(dist_exchange1(ctx));
+        GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
+        GVICK(dist_exchange0(ctx, 1 - g.gcur, true));
         GVICK(ngd_cost_publish(ctx, t));
+        GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
       } else if (ctx->sets.empty()) {
         HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
         GVICK(ngd_cost_publish(ctx, t));
       } else {
         GVICK(ngd_moments_full(ctx, t, t));           // epilogue + ordered cost sum + publish in one launch
       }
-      GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
-      GVICK(dist_exchange0(ctx, 1 - g.gcur));
-      GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
+      if (!dist_on(ctx)) {
+        GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
+        GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
+      }
     } else {
       if (dist_on(ctx)) {
         GVICK(ngd_cost_local(ctx, t, false));

@@ -744,34 +744,45 @@ __global__ __launch_bounds__(256) void trial_kernel(int64_t nmu, int64_t nlam, d
 }
 
 // ---- sharded factors: exchange 0 as an all-gather of state records ----
-// pack: the rank's state range [lo, lo + len) of [g | D | U] -> records [maxlen][n + 2 n^2] (zero padded)
+// pack: the rank's state range [lo, lo + len) of [g | D | U] -> records [maxlen][n + 2 n^2] (zero padded).  cost != null:
+// one more record whose first word is the rank's partial cost sum, so that the fused trial needs ONE all-gather per
+// iteration instead of two (the gradient records and the cost used to travel separately).
 __global__ __launch_bounds__(256) void dist_pack_kernel(int T, int n, int lo, int len, int maxlen, const double* __restrict__ g,
                                                         const double* __restrict__ D, const double* __restrict__ U,
-                                                        double* __restrict__ rec) {
+                                                        double* __restrict__ rec, const double* __restrict__ cost) {
   const int nn = n * n, per = n + 2 * nn;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (int64_t)maxlen * per) return;
+  if (gid >= (int64_t)(maxlen + (cost ? 1 : 0)) * per) return;
   const int j = (int)(gid / per), e = (int)(gid % per), t = lo + j;
   double v = 0.0;
-  if (j < len && t < T) {
+  if (j == maxlen) {
+    if (e == 0) v = cost[0];
+  } else if (j < len && t < T) {
     if (e < n) v = g[(size_t)t * n + e];
     else if (e < n + nn) v = D[(size_t)t * nn + (e - n)];
     else if (t < T - 1) v = U[(size_t)t * nn + (e - n - nn)];
   }
   rec[gid] = v;
 }
-// fold: every state sums the records of the ranks whose range holds it, in rank order -> full [g | D | U]
-__global__ __launch_bounds__(256) void dist_fold_kernel(int T, int n, int world, int maxlen, const int32_t* __restrict__ range,
+// fold: every state sums the records of the ranks whose range holds it, in rank order -> full [g | D | U]; stride = records
+// per rank in `rec` (maxlen, or maxlen + 1 with the cost record, whose ordered sum goes to cost_out[0])
+__global__ __launch_bounds__(256) void dist_fold_kernel(int T, int n, int world, int maxlen, int stride, const int32_t* __restrict__ range,
                                                         const double* __restrict__ rec, double* __restrict__ g,
-                                                        double* __restrict__ D, double* __restrict__ U) {
+                                                        double* __restrict__ D, double* __restrict__ U, double* cost_out) {
   const int nn = n * n, per = n + 2 * nn;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid == (int64_t)T * per && cost_out) {
+    double s = 0.0;
+    for (int r = 0; r < world; ++r) s += rec[((size_t)r * stride + maxlen) * per];
+    cost_out[0] = s;
+    return;
+  }
   if (gid >= (int64_t)T * per) return;
   const int t = (int)(gid / per), e = (int)(gid % per);
   double acc = 0.0;
   for (int r = 0; r < world; ++r) {
     const int lo = range[2 * r], hi = range[2 * r + 1];
-    if (t >= lo && t <= hi) acc += rec[((size_t)r * maxlen + (t - lo)) * per + e];
+    if (t >= lo && t <= hi) acc += rec[((size_t)r * stride + (t - lo)) * per + e];
   }
   if (e < n) g[(size_t)t * n + e] = acc;
   else if (e < n + nn) D[(size_t)t * nn + (e - n)] = acc;
