@@ -229,6 +229,7 @@ struct gvi_ctx {
     DevMem send, recv, ranges;           // packed state records; [world][2] state ranges (device); cost scratch
     std::vector<int32_t> lo, hi;         // owned state range [lo, hi] of every rank (records sent)
     int maxlen = 0;
+    bool rec_fresh = false;           // the last assemble wrote this rank's exchange records itself (no pack launch)
     bool ranges_valid = false;
   } dist;
   // pipelined iterations (gvi_ngd_run): predicate of the launches being queued, device-side accept decision of the tails,
@@ -2054,12 +2055,14 @@ static gvi_status dist_ranges(gvi_ctx* ctx) {
   const size_t per = (size_t)ctx->n + 2 * nn_(ctx);
   HIPCK(ctx, d.send.ensure((size_t)(d.maxlen + 1) * per * 8));                     // + the cost record of the fused trial
   HIPCK(ctx, d.recv.ensure(std::max<size_t>((size_t)W * (d.maxlen + 1) * per * 8, (size_t)2 * W * 8)));
+  HIPCK(ctx, hipMemsetAsync(d.send.p, 0, (size_t)(d.maxlen + 1) * per * 8, ctx->stream));   // padding records stay zero
+  d.rec_fresh = false;
   d.ranges_valid = true;
   return GVI_OK;
 }
 
 // exchange 0 on gradient buffer gb: pack own records -> all-gather -> fold in rank order back into exch0[gb]
-static gvi_status dist_exchange0(gvi_ctx* ctx, int gb, bool with_cost = false) {
+static gvi_status dist_exchange0(gvi_ctx* ctx, int gb, bool with_cost = false, int publish_slot = -1) {
   if (!dist_on(ctx)) return GVI_OK;
   GVICK(dist_ranges(ctx));
   gvi_ctx::Dist& d = ctx->dist;
@@ -2069,16 +2072,24 @@ static gvi_status dist_exchange0(gvi_ctx* ctx, int gb, bool with_cost = false) {
   double* eU = eD + T * nn;
   const int lo = d.lo[d.rank], len = d.hi[d.rank] - d.lo[d.rank] + 1;
   // with_cost: the rank's partial cost sum (exch1[0]) rides as one more record and comes back as the ordered total in
-  // exch1[0] -- one all-gather for the fused trial instead of exchange 0 + exchange 1
+  // exch1[0] -- one all-gather for the fused trial instead of exchange 0 + exchange 1; publish_slot >= 0: the fold launch
+  // also publishes {total + 1/2 log det of that NGD slot, sequence} to the host
   const int stride = d.maxlen + (with_cost ? 1 : 0);
   const int64_t np = (int64_t)stride * per;
-  hipLaunchKernelGGL(dist_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, lo, len, d.maxlen,
-                     eg, eD, eU, d.send.d(), with_cost ? (const double*)ctx->ngd.exch1.d() : (const double*)nullptr);
-  HIPCK(ctx, hipGetLastError());
+  if (!d.rec_fresh) {                                        // else: written by the assemble (and cost_sum_all_kernel)
+    hipLaunchKernelGGL(dist_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, lo, len, d.maxlen,
+                       eg, eD, eU, d.send.d(), with_cost ? (const double*)ctx->ngd.exch1.d() : (const double*)nullptr);
+    HIPCK(ctx, hipGetLastError());
+  }
+  d.rec_fresh = false;
   GVICK(dist_allgather(ctx, d.send.p, d.recv.p, np));
+  const bool pub = with_cost && publish_slot >= 0;
+  if (pub) ctx->seq += 1.0;
   const int64_t nf = (int64_t)T * per + 1;
   hipLaunchKernelGGL(dist_fold_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, d.world, d.maxlen, stride,
-                     (const int32_t*)d.ranges.p, d.recv.d(), eg, eD, eU, with_cost ? ctx->ngd.exch1.d() : (double*)nullptr);
+                     (const int32_t*)d.ranges.p, d.recv.d(), eg, eD, eU, with_cost ? ctx->ngd.exch1.d() : (double*)nullptr,
+                     pub ? (const double*)ctx->ngd.hld[publish_slot].d() : (const double*)nullptr,
+                     pub ? ctx->host_slot_dev + 2 * ctx->pub_ring : (double*)nullptr, ctx->seq);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -2256,9 +2267,16 @@ static gvi_status ngd_scatter(gvi_ctx* ctx, int slot, int gb) {
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
   const int64_t total = (int64_t)T * (n + 2 * nn);
+  double* rec = nullptr;                                     // sharded: the assemble writes this rank's exchange records too
+  int rlo = 0, rlen = 0;
+  if (dist_on(ctx)) {
+    GVICK(dist_ranges(ctx));
+    rec = ctx->dist.send.d(); rlo = ctx->dist.lo[ctx->dist.rank]; rlen = ctx->dist.hi[ctx->dist.rank] - rlo + 1;
+  }
   hipLaunchKernelGGL(bt_scatter_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     make_set_list(ctx, slot), ctx->T, ctx->n, eg, eD, eU, ctx->cur_pred, ctx->cur_pred_val);
+                     make_set_list(ctx, slot), ctx->T, ctx->n, eg, eD, eU, ctx->cur_pred, ctx->cur_pred_val, rec, rlo, rlen);
   HIPCK(ctx, hipGetLastError());
+  if (rec) ctx->dist.rec_fresh = true;
   return GVI_OK;
 }
 
@@ -2519,11 +2537,12 @@ static gvi_status ngd_linesearch(gvi_ctx* ctx, double c0, double step, int cnt, 
         // sharded: the local cost sum and the local [g | D | U] go through the two exchanges before publish / solve
         // (ONE all-gather: the partial cost sum rides with the gradient records; the publish follows it)
         GVICK(ngd_moments_full(ctx, t));
-        hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, t), g.exch1.d());
+        GVICK(dist_ranges(ctx));
+        hipLaunchKernelGGL(cost_sum_all_kernel, dim3(1), dim3(256), 0, ctx->stream, make_set_list(ctx, t), g.exch1.d(),
+                           ctx->dist.send.d() + (size_t)ctx->dist.maxlen * (ctx->n + 2 * nn_(ctx)));
         HIPCK(ctx, hipGetLastError());
-        GVICK(ngd_scatter(ctx, t, 1 - g.gcur));
-        GVICK(dist_exchange0(ctx, 1 - g.gcur, true));
-        GVICK(ngd_cost_publish(ctx, t));
+        GVICK(ngd_scatter(ctx, t, 1 - g.gcur));               // also writes this rank's records
+        GVICK(dist_exchange0(ctx, 1 - g.gcur, true, t));      // all-gather, fold, ordered cost total, publish
         GVICK(ngd_grad_finish(ctx, 1 - g.gcur));
       } else if (ctx->sets.empty()) {
         HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));

@@ -645,7 +645,10 @@ struct SetList { int nsets; SetDesc s[MAX_SETS]; };
 // index ascending), so no memset and no second launch
 __global__ __launch_bounds__(256) void bt_scatter_all_kernel(SetList L, int T, int n, double* __restrict__ g,
                                                              double* __restrict__ D, double* __restrict__ U,
-                                                             const double* pred, double pred_val) {
+                                                             const double* pred, double pred_val,
+                                                             double* __restrict__ rec, int rlo, int rlen) {
+  // rec != null (sharded factors): the states [rlo, rlo + rlen) this rank's factors touch are ALSO written as exchange
+  // records [state - rlo][n + 2 n^2] -- what dist_pack_kernel would copy out of (g, D, U) in a launch of its own
   if (pred_skip(pred, pred_val)) return;
   const int nn = n * n, per = n + 2 * nn;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -676,6 +679,7 @@ __global__ __launch_bounds__(256) void bt_scatter_all_kernel(SetList L, int T, i
   if (e < n) g[(size_t)t * n + e] = acc;
   else if (e < n + nn) D[(size_t)t * nn + (e - n)] = acc;
   else if (t < T - 1) U[(size_t)t * nn + (e - n - nn)] = acc;
+  if (rec && t >= rlo && t < rlo + rlen) rec[(size_t)(t - rlo) * per + e] = acc;
 }
 
 // gather (mu_k, Sigma_k) for ALL sets: blockIdx.y = set.  With dmu != null the trial mean mu + step dmu is formed on
@@ -710,7 +714,7 @@ __global__ __launch_bounds__(256) void gather_all_kernel(SetList L, int n, const
 }
 
 // ordered sum of the factor costs of ALL sets -> acc[0]; one block, fixed tree per set
-__global__ __launch_bounds__(256) void cost_sum_all_kernel(SetList L, double* acc) {
+__global__ __launch_bounds__(256) void cost_sum_all_kernel(SetList L, double* acc, double* acc2 = nullptr) {
   __shared__ double sh[256];
   double total = 0.0;
   for (int si = 0; si < L.nsets; ++si) {
@@ -725,7 +729,10 @@ __global__ __launch_bounds__(256) void cost_sum_all_kernel(SetList L, double* ac
     total += sh[0];
     __syncthreads();
   }
-  if (threadIdx.x == 0) acc[0] = total;
+  if (threadIdx.x == 0) {
+    acc[0] = total;
+    if (acc2) acc2[0] = total;            // sharded: the cost word of this rank's exchange records
+  }
 }
 
 // trial point in one launch: mu_t = mu + step dmu ; Lam_t = Lam + step (V - Lam)   (NGD: dprecision = Vddmu - Lam)
@@ -768,13 +775,15 @@ __global__ __launch_bounds__(256) void dist_pack_kernel(int T, int n, int lo, in
 // per rank in `rec` (maxlen, or maxlen + 1 with the cost record, whose ordered sum goes to cost_out[0])
 __global__ __launch_bounds__(256) void dist_fold_kernel(int T, int n, int world, int maxlen, int stride, const int32_t* __restrict__ range,
                                                         const double* __restrict__ rec, double* __restrict__ g,
-                                                        double* __restrict__ D, double* __restrict__ U, double* cost_out) {
+                                                        double* __restrict__ D, double* __restrict__ U, double* cost_out,
+                                                        const double* half_logdet, double* host_out, double seq) {
   const int nn = n * n, per = n + 2 * nn;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid == (int64_t)T * per && cost_out) {
     double s = 0.0;
     for (int r = 0; r < world; ++r) s += rec[((size_t)r * stride + maxlen) * per];
     cost_out[0] = s;
+    if (host_out) publish_to_host(host_out, s + half_logdet[0], seq);   // what publish_kernel would do in its own launch
     return;
   }
   if (gid >= (int64_t)T * per) return;
