@@ -229,15 +229,36 @@ def main():
     # N > 1 (or a forced size-1 group): both exchange steps of a pass run INSIDE the library on its own stream
     # (include/gvi_hip.h, gvi_dist_init_*): RCCL all-gathers; the rehearsal on one GPU goes through a gloo callback
     sharded = use_pg and (world > 1 or os.environ.get("GVI_FORCE_ALLREDUCE") == "1")
+    transport = "none"
     if sharded:
         if rehearsal:
             ctx.dist_init_callback(rank, world, torch_allgather(local_rank))
         else:
+            # the library's own RCCL communicator (dlopen of librccl); should that fail on ANY rank (library not found,
+            # communicator refused), every rank falls back to the callback transport over torch.distributed's RCCL group --
+            # the same all-gathers on the library's stream, one Python call each
+            ok = torch.ones(1, dtype=torch.float64, device="cuda")
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(api.dist_unique_id()), dtype=torch.uint8))
+            try:
+                my_id = api.dist_unique_id()           # every rank: also the probe that librccl loads here
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+            except Exception as e:
+                ok.zero_()
+                print(f"[bench rank {rank}] gvi_dist_unique_id failed: {e}", file=sys.stderr, flush=True)
             dist.broadcast(uid, 0)
-            ctx.dist_init_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) > 0.5:
+                try:
+                    ctx.dist_init_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
+                except Exception as e:
+                    ok.zero_()
+                    print(f"[bench rank {rank}] gvi_dist_init_rccl failed: {e}", file=sys.stderr, flush=True)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            transport = "RCCL (library communicator)"
+            if float(ok.item()) < 0.5:
+                ctx.dist_init_callback(rank, world, torch_allgather(local_rank))
+                transport = "RCCL (torch.distributed group through the callback transport)"
     ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
     # HIP events around every 8th dominant launch (a pair costs ~14 us of queue gaps); every launch for the seconds-long c5 passes
     ctx.profile_enable(1 if big else 3)
@@ -420,7 +441,7 @@ def main():
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": (f"factors/{world} contiguous; per pass: all-gather of each rank's state records of [g|D|U] "
                                     f"({ctx.dist_info()['records_per_rank']} states per rank, folded in rank order) with the partial cost sum as one "
-                                    f"more record (one all-gather per iteration), issued inside the library ({'gloo callback (rehearsal)' if rehearsal else 'RCCL'})") if sharded else "none",
+                                    f"more record (one all-gather per iteration), issued inside the library ({'gloo callback (rehearsal)' if rehearsal else transport})") if sharded else "none",
                        "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"],
                        "mirror_pairs": bool(geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"),
                        "fuse_trial": args.fuse_trial},
