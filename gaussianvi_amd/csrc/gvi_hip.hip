@@ -654,12 +654,16 @@ template <int M, int SMAX, int WAVES>
 void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, size_t lds, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const int nbx0 = (a0.K + 3) / 4, nbx1 = (a1.K + 3) / 4;
   const int nb0 = nbx0 * a0.nchunk, nb1 = nbx1 * a1.nchunk;
+  // stacked: block b takes item b of both sets (negative nbx1 tells the kernel); GVI_ORBIT_STACK=0: set 1's blocks behind set 0's
+  static const bool stack = [] { const char* w = getenv("GVI_ORBIT_STACK"); return !w || atoi(w) != 0; }();
+  const int grid = stack ? std::max(nb0, nb1) : nb0 + nb1;
+  const int nx1 = stack ? -nbx1 : nbx1;
   if (full)
-    hipExtLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, true, false, WAVES>), dim3(nb0 + nb1), dim3(256), (uint32_t)lds, st, e0, e1, 0,
-                          a0, a1, nbx0, nb0, nbx1);
+    hipExtLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, true, false, WAVES>), dim3(grid), dim3(256), (uint32_t)lds, st, e0, e1, 0,
+                          a0, a1, nbx0, nb0, nx1);
   else
-    hipExtLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, false, false, WAVES>), dim3(nb0 + nb1), dim3(256), (uint32_t)lds, st, e0, e1, 0,
-                          a0, a1, nbx0, nb0, nbx1);
+    hipExtLaunchKernelGGL((moments_orbit_pair_kernel<M, SMAX, false, false, WAVES>), dim3(grid), dim3(256), (uint32_t)lds, st, e0, e1, 0,
+                          a0, a1, nbx0, nb0, nx1);
 }
 
 void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st,

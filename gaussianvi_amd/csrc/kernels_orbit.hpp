@@ -243,9 +243,25 @@ __global__ __launch_bounds__(256, WAVES) void moments_orbit_kernel(OrbitArgs a) 
 template <int M, int SMAX, bool FULL, bool SIGNED, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void moments_orbit_pair_kernel(OrbitArgs a0, OrbitArgs a1, int nbx0, int nb0, int nbx1) {
   extern __shared__ double sm[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (pred_skip(a0.pred, a0.pred_val)) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int id = (int)blockIdx.x;
+  if (nbx1 < 0) {
+    // stacked form (grid = max(nb0, nb1)): block b takes item b of set 0 and then item b of set 1, so the light set does not
+    // run as a tail behind the single resident round of the heavy one
+    const int nx1 = -nbx1;
+    // ONE per-wave LDS region for both items (the waves of a block are not synchronised: a wave on its second item must
+    // not reach into the region of a wave still on its first)
+    const int l0 = orbit_lds_doubles(a0.d, M, a0.copies), l1 = orbit_lds_doubles(a1.d, M, a1.copies);
+    double* mine = sm + (size_t)wave * (l0 > l1 ? l0 : l1);
+    if (id < nb0) {
+      const int k = (id % nbx0) * 4 + wave, chunk = id / nbx0;
+      if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, mine);
+    }
+    const int k1 = (id % nx1) * 4 + wave, chunk1 = id / nx1;
+    if (chunk1 < a1.nchunk && k1 < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k1, chunk1, mine);
+    return;
+  }
   const bool second = id >= nb0;
   if (second) id -= nb0;
   const int nbx = second ? nbx1 : nbx0;
