@@ -189,6 +189,7 @@ struct gvi_ctx {
   // (same moments -- the quadrature is exact there -- without the Jacobi sweeps); GVI_CHOL_SQRT=0 / option "chol_sqrt"
   bool chol_sqrt = true;
   int orbit_min_tiles = 6;            // GVI_ORBIT_MIN_TILES
+  bool orbit_stack = true;            // two-set launch: block b takes item b of both sets (GVI_ORBIT_STACK=0: set 1 behind set 0)
   int orbit_copies = 8;               // private LDS copies of the accumulators (1, 2, 4, 8, 16; fewer when LDS is short)
   int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
@@ -651,11 +652,11 @@ void launch_orbit(const OrbitArgs& a, int m, int smax, bool full, bool all_pos, 
 // (hipExtLaunchKernel: the kernel's own begin / end timestamps, what rocprofv3 reports -- a hipEventRecord pair around a
 // 28 us launch reads ~3 us more than the kernel runs)
 template <int M, int SMAX, int WAVES>
-void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, size_t lds, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, size_t lds, hipStream_t st, hipEvent_t e0, hipEvent_t e1,
+                         bool stack) {
   const int nbx0 = (a0.K + 3) / 4, nbx1 = (a1.K + 3) / 4;
   const int nb0 = nbx0 * a0.nchunk, nb1 = nbx1 * a1.nchunk;
-  // stacked: block b takes item b of both sets (negative nbx1 tells the kernel); GVI_ORBIT_STACK=0: set 1's blocks behind set 0's
-  static const bool stack = [] { const char* w = getenv("GVI_ORBIT_STACK"); return !w || atoi(w) != 0; }();
+  // stacked: block b takes item b of both sets (negative nbx1 tells the kernel); else set 1's blocks behind set 0's
   const int grid = stack ? std::max(nb0, nb1) : nb0 + nb1;
   const int nx1 = stack ? -nbx1 : nbx1;
   if (full)
@@ -666,14 +667,14 @@ void launch_orbit_pair_t(const OrbitArgs& a0, const OrbitArgs& a1, bool full, si
                           a0, a1, nbx0, nb0, nx1);
 }
 
-void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st,
+void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax, bool full, hipStream_t st, bool stack,
                        hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const size_t lds = (size_t)4 * std::max(orbit_lds_doubles(a0.d, m, a0.copies), orbit_lds_doubles(a1.d, m, a1.copies)) * 8;
-  if (m == 2) launch_orbit_pair_t<2, 4, 4>(a0, a1, full, lds, st, e0, e1);
-  else if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st, e0, e1);
-  else if (m == 6) launch_orbit_pair_t<6, 6, 2>(a0, a1, full, lds, st, e0, e1);
-  else if (smax <= 4) launch_orbit_pair_t<12, 4, 3>(a0, a1, full, lds, st, e0, e1);
-  else launch_orbit_pair_t<12, 6, 2>(a0, a1, full, lds, st, e0, e1);
+  if (m == 2) launch_orbit_pair_t<2, 4, 4>(a0, a1, full, lds, st, e0, e1, stack);
+  else if (m == 6 && smax <= 4) launch_orbit_pair_t<6, 4, 4>(a0, a1, full, lds, st, e0, e1, stack);
+  else if (m == 6) launch_orbit_pair_t<6, 6, 2>(a0, a1, full, lds, st, e0, e1, stack);
+  else if (smax <= 4) launch_orbit_pair_t<12, 4, 3>(a0, a1, full, lds, st, e0, e1, stack);
+  else launch_orbit_pair_t<12, 6, 2>(a0, a1, full, lds, st, e0, e1, stack);
 }
 
 // prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
@@ -1151,6 +1152,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
   if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_ORBIT_MIN_TILES")) c->orbit_min_tiles = std::max(1, atoi(w));
+  if (const char* w = getenv("GVI_ORBIT_STACK")) c->orbit_stack = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT_COPIES")) c->orbit_copies = std::min(16, std::max(1, atoi(w)));
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
   if (const char* w = getenv("GVI_MIRROR")) c->mirror = atoi(w) != 0;
@@ -2211,7 +2213,7 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
           for (int e = 0; e < 2; ++e)
             if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
         }
-        launch_orbit_pair(d0.oa, d1.oa, d0.m, std::max(d0.smax, d1.smax), full != 0, ctx->stream,
+        launch_orbit_pair(d0.oa, d1.oa, d0.m, std::max(d0.smax, d1.smax), full != 0, ctx->stream, ctx->orbit_stack,
                           prof ? s0.ev[0][0] : nullptr, prof ? s0.ev[0][1] : nullptr);
         HIPCK(ctx, hipGetLastError());
         if (prof) s0.ev_set[0] = true;
@@ -3078,6 +3080,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "jacobi_tol_exp") { ctx->jacobi_tol = std::pow(10.0, (double)std::min(-20, value)); for (auto& s : ctx->sets) s->jtol = ctx->jacobi_tol; }
   else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);
   else if (n == "orbit_min_tiles") ctx->orbit_min_tiles = std::max(1, value);
+  else if (n == "orbit_stack") ctx->orbit_stack = value != 0;
   else if (n == "orbit_copies") ctx->orbit_copies = std::min(16, std::max(1, value));
   else return fail(ctx, GVI_ERR_ARG, "unknown option: " + n);
   for (auto& s : ctx->sets) s->prep_slot = -1;

@@ -316,7 +316,7 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * "chol_sqrt" (1: sum-of-squares sets take S = chol(Sigma) instead of the symmetric root -- the quadrature is exact there),
  * "jacobi_tol_exp" (stopping threshold 10^value of the symmetric-root solve).
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,
- * orbit, orbit_waves, orbit_min_tiles, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline. */
+ * orbit, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline. */
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus
