@@ -95,6 +95,13 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
 #pragma unroll
     for (int r = 0; r < M; ++r) v[r] = fma(-mg[j], hp[j][r], v[r]);
   }
+  // !HREG: the column of coordinate 0 -- flipped at every other step of the Gray walk -- stays in registers when H0REG
+  constexpr bool H0REG = !HREG && M * (S + 9) <= 168;     // m = 12: s <= 5 (s = 6 would spill)
+  double h0[H0REG ? M : 1];
+  if constexpr (H0REG) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) h0[r] = hp[0][r];
+  }
   double E0 = 0.0, Eij[S * (S - 1) / 2 + 1], Oi[S];
 #pragma unroll
   for (int e = 0; e < S * (S - 1) / 2 + 1; ++e) Eij[e] = 0.0;
@@ -105,7 +112,7 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
     const int jn = g + 1 < NH ? __builtin_ctz(g + 1) : 0;        // coordinate of the next flip (compile-time after unrolling)
     double hn[M];
     if constexpr (!HREG) {
-      if (g + 1 < NH) {
+      if (g + 1 < NH && !(H0REG && jn == 0)) {
         asm volatile("" : "+v"(E0) :: "memory");                // the previous point is finished before the next fetch
 #pragma unroll
         for (int r = 0; r < M; ++r) asm volatile("" : "+v"(v[r]) :: "memory");
@@ -134,7 +141,7 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
       sig[jn] = -sig[jn];
       const double t2 = (sig[jn] > 0 ? 2.0 : -2.0) * mg[jn];
 #pragma unroll
-      for (int r = 0; r < M; ++r) v[r] = fma(t2, HREG ? hcol[jn][r] : hn[r], v[r]);
+      for (int r = 0; r < M; ++r) v[r] = fma(t2, HREG ? hcol[jn][r] : ((H0REG && jn == 0) ? h0[r] : hn[r]), v[r]);
     }
   }
   const double wp = w + w;
@@ -187,8 +194,8 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
 #pragma unroll
   for (int r = 0; r < M; ++r) {
     const double u = a.u0[(size_t)k * M + r];
-    sg[r] = a.sgn[(size_t)k * M + r];
-    su0[r] = sg[r] * u;
+    sg[r] = SIGNED ? a.sgn[(size_t)k * M + r] : 1.0;
+    su0[r] = SIGNED ? sg[r] * u : u;               // unsigned: u0 itself -- a wave-uniform scalar load, it stays in SGPRs
     k0 = fma(su0[r], u, k0);
   }
   wave_lds_sync();
