@@ -133,7 +133,9 @@ def orbit_exec_ops(d: int, p: int, m: int, full: bool, signed: bool = False) -> 
     """fp64 VALU instructions per EVALUATION of the sign-orbit kernel (csrc/kernels_orbit.hpp), averaged over the (d, p)
     table: an orbit of support size s costs  s m (start corner)  +  2^(s-1) half-points x [q: m (+ m signed), l: m, c+ and
     its sum: 2, sign-weighted sums: s + s (s - 1) / 2]  +  (2^(s-1) - 1) flips x (m + 1)  +  the per-orbit scaling
-    (3 + 5 s + 2 s (s - 1) / 2 multiplies); the cost pass keeps q, c+ and the flips only.  The LDS atomics that fold an
+    (3 + 5 s + 2 s (s - 1) / 2 multiplies); the cost pass keeps q, c+ and the flips only.  For s <= 4 the full pass forms
+    the sign-weighted sums by a butterfly after the walk instead (checked against the ISA: 251 fp64 instructions in the s = 4
+    tile body, 130 at s = 3).  The LDS atomics that fold an
     orbit into the factor's accumulators are not VALU instructions."""
     import numpy as np
     from gaussianvi_amd import api
@@ -145,8 +147,15 @@ def orbit_exec_ops(d: int, p: int, m: int, full: bool, signed: bool = False) -> 
         n = int(np.sum(sizes == sz))
         nh = 2 ** (sz - 1)
         sq = 2 * m if signed else m
-        per_point = sq + 2 + ((m + sz + sz * (sz - 1) // 2) if full else 0)
-        per_orbit = sz * m + nh * per_point + (nh - 1) * (m + 1) + ((3 + 5 * sz + sz * (sz - 1)) if full else 2)
+        if full and 2 <= sz <= 4:
+            # the two scalars of every half-point are kept and one Walsh-Hadamard butterfly per scalar gives the sign-weighted
+            # sums (dead outputs pruned): c+ needs every mask of <= 2 coordinates, l the empty mask and the singletons
+            log2nh = sz - 1
+            wht = nh * log2nh - (1 if sz == 4 else 0) + {2: 2, 4: 7, 8: 18}[nh]
+            per_orbit = sz * m + nh * (sq + m + 1) + (nh - 1) * (m + 1) + wht + (3 + 5 * sz + sz * (sz - 1))
+        else:
+            per_point = sq + 2 + ((m + sz + sz * (sz - 1) // 2) if full else 0)
+            per_orbit = sz * m + nh * per_point + (nh - 1) * (m + 1) + ((3 + 5 * sz + sz * (sz - 1)) if full else 2)
         total += n * per_orbit
     return total / len(w)
 

@@ -28,6 +28,10 @@
 
 namespace gvi {
 
+#ifndef ORBIT_WHT
+#define ORBIT_WHT 1      // 0: per-point accumulation of the sign-weighted sums for every support size (A/B build)
+#endif
+
 struct OrbitDev {
   const uint64_t* cpk;       // [norb_p] support coordinates, one byte each
   const double* mag;         // [smax][norb_p]
@@ -102,6 +106,11 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
 #pragma unroll
     for (int r = 0; r < M; ++r) h0[r] = hp[0][r];
   }
+  // Sign-weighted (Walsh) sums.  Up to 8 half-points (s <= 4, full pass) the two scalars of every point are kept and ONE
+  // Walsh-Hadamard butterfly per scalar yields all sums: 2 x 24 additions instead of 8 x (1 + 6 + 4) at s = 4 (unused
+  // outputs of the butterfly are dead code).  Larger supports accumulate per point: 2 x 32 kept values would not fit.
+  constexpr bool WHT = FULL && S >= 2 && S <= 4 && ORBIT_WHT;
+  double cpv[WHT ? NH : 1], lv[WHT ? NH : 1];
   double E0 = 0.0, Eij[S * (S - 1) / 2 + 1], Oi[S];
 #pragma unroll
   for (int e = 0; e < S * (S - 1) / 2 + 1; ++e) Eij[e] = 0.0;
@@ -127,14 +136,23 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
       if (FULL) l = fma(su0[r], v[r], l);
     }
     const double cp = q + k0;
-    E0 += cp;
-    if (FULL) {
-      int e = 0;
+    if constexpr (WHT) {
+      // keep (c+, l) of this sign pattern; the sign-weighted sums come out of one butterfly after the walk
+      int b = 0;
 #pragma unroll
-      for (int i = 0; i < S; ++i) {
-        Oi[i] = sig[i] > 0 ? Oi[i] + l : Oi[i] - l;
+      for (int j = 0; j < S - 1; ++j) b |= (sig[j] > 0 ? 1 : 0) << j;          // compile-time after unrolling
+      cpv[b] = cp;
+      lv[b] = l;
+    } else {
+      E0 += cp;
+      if (FULL) {
+        int e = 0;
 #pragma unroll
-        for (int j = i + 1; j < S; ++j) { Eij[e] = sig[i] * sig[j] > 0 ? Eij[e] + cp : Eij[e] - cp; ++e; }
+        for (int i = 0; i < S; ++i) {
+          Oi[i] = sig[i] > 0 ? Oi[i] + l : Oi[i] - l;
+#pragma unroll
+          for (int j = i + 1; j < S; ++j) { Eij[e] = sig[i] * sig[j] > 0 ? Eij[e] + cp : Eij[e] - cp; ++e; }
+        }
       }
     }
     if (g + 1 < NH) {
@@ -142,6 +160,29 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
       const double t2 = (sig[jn] > 0 ? 2.0 : -2.0) * mg[jn];
 #pragma unroll
       for (int r = 0; r < M; ++r) v[r] = fma(t2, HREG ? hcol[jn][r] : ((H0REG && jn == 0) ? h0[r] : hn[r]), v[r]);
+    }
+  }
+  if constexpr (WHT) {
+    // butterfly over the sign bits of coordinates 0 .. S-2: (x[bit = 0], x[bit = 1]) -> (x0 + x1, x1 - x0); afterwards the
+    // array index is the MASK of coordinates whose signs multiply the summand
+#pragma unroll
+    for (int j = 0; j < S - 1; ++j) {
+#pragma unroll
+      for (int b = 0; b < NH; ++b) {
+        if (!(b & (1 << j))) {
+          const double c0v = cpv[b], c1v = cpv[b | (1 << j)], l0v = lv[b], l1v = lv[b | (1 << j)];
+          cpv[b] = c0v + c1v; cpv[b | (1 << j)] = c1v - c0v;
+          lv[b] = l0v + l1v; lv[b | (1 << j)] = l1v - l0v;
+        }
+      }
+    }
+    E0 = cpv[0];
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      Oi[i] = i < S - 1 ? lv[1 << i] : lv[0];                    // sigma_{S-1} = +1 throughout
+#pragma unroll
+      for (int j = i + 1; j < S; ++j) { Eij[e] = j < S - 1 ? cpv[(1 << i) | (1 << j)] : cpv[1 << i]; ++e; }
     }
   }
   const double wp = w + w;
