@@ -106,11 +106,16 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
 #pragma unroll
     for (int r = 0; r < M; ++r) h0[r] = hp[0][r];
   }
-  // Sign-weighted (Walsh) sums.  Up to 8 half-points (s <= 4, full pass) the two scalars of every point are kept and ONE
-  // Walsh-Hadamard butterfly per scalar yields all sums: 2 x 24 additions instead of 8 x (1 + 6 + 4) at s = 4 (unused
-  // outputs of the butterfly are dead code).  Larger supports accumulate per point: 2 x 32 kept values would not fit.
-  constexpr bool WHT = FULL && S >= 2 && S <= 4 && ORBIT_WHT;
-  double cpv[WHT ? NH : 1], lv[WHT ? NH : 1];
+  // Sign-weighted (Walsh) sums.  The two scalars of 8 consecutive half-points (a reflected Gray code walks the low three
+  // coordinates through all their sign patterns before it touches a higher one) are kept and ONE Walsh-Hadamard butterfly
+  // per scalar yields their sums over every mask of those coordinates: 2 x 24 additions instead of 8 x (1 + 6 + 4) at
+  // s = 4 (unused outputs are dead code); the signs of the higher coordinates are constant inside a block and multiply the
+  // block's sums.  WHT_BIG: also for s = 5, 6 (needs the registers: not at m = 12).
+  constexpr bool WHT_BIG = M <= 6;
+  constexpr bool WHT = FULL && S >= 2 && ORBIT_WHT && (S <= 4 || WHT_BIG);
+  constexpr int LB = S - 1 < 3 ? S - 1 : 3;          // coordinates whose signs vary inside a block of 2^LB consecutive Gray steps
+  constexpr int BLK = 1 << LB;
+  double cpv[WHT ? BLK : 1], lv[WHT ? BLK : 1];
   double E0 = 0.0, Eij[S * (S - 1) / 2 + 1], Oi[S];
 #pragma unroll
   for (int e = 0; e < S * (S - 1) / 2 + 1; ++e) Eij[e] = 0.0;
@@ -137,12 +142,44 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
     }
     const double cp = q + k0;
     if constexpr (WHT) {
-      // keep (c+, l) of this sign pattern; the sign-weighted sums come out of one butterfly after the walk
+      // keep (c+, l) of this sign pattern of the low coordinates; at the end of a block: butterfly, then add the block's
+      // sums into the accumulators with the (compile-time) signs of the higher coordinates
       int b = 0;
 #pragma unroll
-      for (int j = 0; j < S - 1; ++j) b |= (sig[j] > 0 ? 1 : 0) << j;          // compile-time after unrolling
+      for (int j = 0; j < LB; ++j) b |= (sig[j] > 0 ? 1 : 0) << j;             // compile-time after unrolling
       cpv[b] = cp;
       lv[b] = l;
+      if ((g & (BLK - 1)) == BLK - 1) {
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+#pragma unroll
+          for (int bb = 0; bb < BLK; ++bb) {
+            if (!(bb & (1 << j))) {            // (x[bit = 0], x[bit = 1]) -> (x0 + x1, x1 - x0): index = mask of multiplying signs
+              const double c0v = cpv[bb], c1v = cpv[bb | (1 << j)], l0v = lv[bb], l1v = lv[bb | (1 << j)];
+              cpv[bb] = c0v + c1v; cpv[bb | (1 << j)] = c1v - c0v;
+              lv[bb] = l0v + l1v; lv[bb | (1 << j)] = l1v - l0v;
+            }
+          }
+        }
+        const bool first = g == BLK - 1;
+        E0 = first ? cpv[0] : E0 + cpv[0];
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          {
+            const double t = i < LB ? lv[1 << i] : lv[0];
+            const bool pos = i < LB || sig[i] > 0;
+            Oi[i] = first ? (pos ? t : -t) : (pos ? Oi[i] + t : Oi[i] - t);
+          }
+#pragma unroll
+          for (int j = i + 1; j < S; ++j) {
+            const double t = j < LB ? cpv[(1 << i) | (1 << j)] : (i < LB ? cpv[1 << i] : cpv[0]);
+            const bool pos = (j < LB ? 1 : sig[j]) * (i < LB ? 1 : sig[i]) > 0;
+            Eij[e] = first ? (pos ? t : -t) : (pos ? Eij[e] + t : Eij[e] - t);
+            ++e;
+          }
+        }
+      }
     } else {
       E0 += cp;
       if (FULL) {
@@ -160,29 +197,6 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
       const double t2 = (sig[jn] > 0 ? 2.0 : -2.0) * mg[jn];
 #pragma unroll
       for (int r = 0; r < M; ++r) v[r] = fma(t2, HREG ? hcol[jn][r] : ((H0REG && jn == 0) ? h0[r] : hn[r]), v[r]);
-    }
-  }
-  if constexpr (WHT) {
-    // butterfly over the sign bits of coordinates 0 .. S-2: (x[bit = 0], x[bit = 1]) -> (x0 + x1, x1 - x0); afterwards the
-    // array index is the MASK of coordinates whose signs multiply the summand
-#pragma unroll
-    for (int j = 0; j < S - 1; ++j) {
-#pragma unroll
-      for (int b = 0; b < NH; ++b) {
-        if (!(b & (1 << j))) {
-          const double c0v = cpv[b], c1v = cpv[b | (1 << j)], l0v = lv[b], l1v = lv[b | (1 << j)];
-          cpv[b] = c0v + c1v; cpv[b | (1 << j)] = c1v - c0v;
-          lv[b] = l0v + l1v; lv[b | (1 << j)] = l1v - l0v;
-        }
-      }
-    }
-    E0 = cpv[0];
-    int e = 0;
-#pragma unroll
-    for (int i = 0; i < S; ++i) {
-      Oi[i] = i < S - 1 ? lv[1 << i] : lv[0];                    // sigma_{S-1} = +1 throughout
-#pragma unroll
-      for (int j = i + 1; j < S; ++j) { Eij[e] = j < S - 1 ? cpv[(1 << i) | (1 << j)] : cpv[1 << i]; ++e; }
     }
   }
   const double wp = w + w;
