@@ -101,3 +101,20 @@ def test_wide_table_weight_cancellation(lib, p, lo, hi):
     ratio = np.abs(w).sum() / abs(w.sum())
     assert lo < ratio < hi, ratio
     assert abs(w.sum() - 1.0) < 1e-9
+
+
+def test_documented_option_names_are_the_implemented_ones():
+    """include/gvi_hip.h lists the names gvi_set_option accepts; the list must be the set the implementation compares
+    against (a name documented but not implemented, or the other way round, is a drifted header)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "gvi_hip.h")).read()
+    m = re.search(r"Names:(.*?)\*/\s*gvi_status gvi_set_option", header, re.S)
+    assert m, "option list not found in the header"
+    documented = set(re.findall(r"[a-z][a-z0-9_]+", m.group(1).replace("*", " ")))
+    src = open(os.path.join(root, "gaussianvi_amd", "csrc", "gvi_hip.hip")).read()
+    body = src[src.index("gvi_status gvi_set_option("):]
+    body = body[:body.index("return fail(ctx, GVI_ERR_ARG, \"unknown option")]
+    implemented = set(re.findall(r'n == "([a-z0-9_]+)"', body))
+    assert documented == implemented, (sorted(documented - implemented), sorted(implemented - documented))
