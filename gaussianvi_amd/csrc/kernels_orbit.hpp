@@ -56,6 +56,11 @@ struct OrbitArgs {
   OrbitDev ob;
 };
 
+// Column stride of H in LDS.  The lanes of a tile read DIFFERENT columns with 16-byte loads: at m = 12 a stride of 12
+// doubles (24 banks) maps the columns onto 8 bank offsets (8-way conflicts), 14 doubles (28 banks, still 16-byte aligned)
+// onto 16.  m <= 6: 12 banks, conflict-free up to 16 columns.
+__host__ __device__ constexpr int orbit_hstride(int M) { return M == 12 ? 14 : M; }
+
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -77,7 +82,7 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
   const double* hp[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) {
-    hp[j] = Hl + c[j] * M;
+    hp[j] = Hl + c[j] * orbit_hstride(M);
     if constexpr (HREG) {
 #pragma unroll
       for (int r = 0; r < M; ++r) hcol[j][r] = hp[j][r];
@@ -239,9 +244,9 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   // ds_add_f64 whose lanes hit one address costs ~3 cycles per lane (64-way: 192 cycles, tools/ubench/lds_atomic.hip);
   // with the copies and the strided orbit order (orbits.hpp) a wave instruction stays near the 8-cycle floor.
   const int C = a.copies;
-  double* accl = Hl + d * M;
+  double* accl = Hl + d * orbit_hstride(M);
   const double* Hg = a.H + (size_t)k * M * d;    // stored [d][M] by the prep kernel
-  for (int e = lane; e < d * M; e += 64) Hl[e] = Hg[e];
+  for (int e = lane; e < d * M; e += 64) Hl[(e / M) * orbit_hstride(M) + e % M] = Hg[e];
   if (FULL)
     for (int e = lane; e < NP * C; e += 64) accl[e] = 0.0;
   double* accme = accl + (lane & (C - 1));
@@ -285,7 +290,9 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
 }
 
 // LDS doubles per wave
-__host__ __device__ inline int orbit_lds_doubles(int d, int M, int copies) { return d * M + copies * (d + 1) * (d + 2) / 2; }
+__host__ __device__ inline int orbit_lds_doubles(int d, int M, int copies) {
+  return (d * orbit_hstride(M) + copies * (d + 1) * (d + 2) / 2 + 1) & ~1;      // even: every wave's H stays 16-byte aligned
+}
 
 // grid (ceil(K / 4), nchunk) x 256: four waves = four factors on the same chunk of orbit tiles.
 // SMAX: largest support instantiated (4: degree <= 5; 6: degree <= 7); SIGNED: some sgn entry is not +1;
