@@ -283,8 +283,10 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   if (lane == 0) out[0] = m0;
   if (FULL)
     for (int e = 1 + lane; e < NP; e += 64) {
-      double t = accl[e * C];
-      for (int q = 1; q < C; ++q) t += accl[e * C + q];        // fixed order
+      // copies in a fixed, lane-rotated order: with every lane starting at copy 0 each fourth lane sits on the same banks
+      const int rot = (lane >> 2) & (C - 1);
+      double t = accl[e * C + rot];
+      for (int q = 1; q < C; ++q) t += accl[e * C + ((q + rot) & (C - 1))];
       out[e] = t;
     }
 }
