@@ -468,25 +468,6 @@ void launch_reg(const MomArgs& a, dim3 grid, hipStream_t st) {
   else hipLaunchKernelGGL((moments_reg_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
 }
 
-template <int D, typename Psi>
-void launch_wide(const MomArgs& a, dim3 grid, hipStream_t st) {
-  if (a.full) hipLaunchKernelGGL((moments_wide_kernel<D, Psi, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((moments_wide_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
-}
-
-template <int D, typename Psi>
-void launch_tile(const MomArgs& a, dim3 grid, hipStream_t st) {
-  if (a.full) hipLaunchKernelGGL((moments_tile_kernel<D, Psi, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((moments_tile_kernel<D, Psi, false>), grid, dim3(256), 0, st, a);
-}
-
-// LDS-staged-table kernel (variant 4): instantiated for the headline shape
-bool dispatch_tile(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
-  if (s.kind == KIND_QUAD_PRIOR && s.d == 12) { launch_tile<12, PsiQuad<12, 6>>(a, grid, st); return true; }
-  if (s.kind == KIND_FIXED_PRIOR && s.d == 6) { launch_tile<6, PsiQuad<6, 6>>(a, grid, st); return true; }
-  return false;
-}
-
 template <int D, int M>
 void launch_sreg(const MomArgs& a, dim3 grid, hipStream_t st, bool pipe) {
   if (a.full && pipe) hipLaunchKernelGGL((moments_sreg_kernel<D, M, true, true>), grid, dim3(256), 0, st, a);
@@ -525,23 +506,6 @@ bool dispatch_sreg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t 
     switch (s.d) {
       case 6: launch_sreg<6, 6>(a, grid, st, pipe); return true;
       case 12: launch_sreg<12, 12>(a, grid, st, false); return true;   // M = 12: the pipelined body does not fit 256 registers
-    }
-  }
-  return false;
-}
-
-// operand-resident kernel: instantiated for the shapes of the BASELINE configs
-bool dispatch_wide(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t st) {
-  if (s.kind == KIND_QUAD_PRIOR) {
-    switch (s.d) {
-      case 4: launch_wide<4, PsiQuad<4, 2>>(a, grid, st); return true;
-      case 12: launch_wide<12, PsiQuad<12, 6>>(a, grid, st); return true;
-    }
-  }
-  if (s.kind == KIND_FIXED_PRIOR) {
-    switch (s.d) {
-      case 2: launch_wide<2, PsiQuad<2, 2>>(a, grid, st); return true;
-      case 6: launch_wide<6, PsiQuad<6, 6>>(a, grid, st); return true;
     }
   }
   return false;
@@ -780,7 +744,6 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   } else if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
-    if (c->variant == 4) done = dispatch_tile(s, a, grid, st);       // LDS-staged table (experimental)
     // auto: psi operands from SGPRs where instantiated (fastest for both passes); otherwise the operand-
     // resident kernel for the cost pass and the LDS-operand kernel for the full pass
     if ((c->variant == 5 || c->variant == 0) && !full && scost_supported(s) && !c->no_scost) {
@@ -796,7 +759,6 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
       return GVI_OK;
     }
     if (!done && (c->variant == 5 || c->variant == 0)) done = dispatch_sreg(s, a, grid, st, c->sreg_pipe && s.table->Zq.p);
-    if (!done && (c->variant == 3 || (c->variant == 0 && !full))) done = dispatch_wide(s, a, grid, st);
     if (!done && !dispatch_reg(s, a, grid, st)) return fail(c, GVI_ERR_UNSUPPORTED, "dispatch_reg");
   } else {
     if (s.d > 32) return fail(c, GVI_ERR_UNSUPPORTED, "generic kernel supports d <= 32");
@@ -2746,7 +2708,7 @@ gvi_status gvi_ngd_run(gvi_ctx* ctx, int max_iters, double step_size_base, int m
     if (spec_next) {
       pipe_save(ctx, snap);
       gvi_status st = gvi_ngd_accept(ctx);                      // provisional: cur <- trial slot
-      if (st != GVI_OK) return finish(st);
+      if (st != GVI_OK) { pipe_restore(ctx, snap); return finish(st); }
       g.gcur = 1 - g.gcur; g.grad_valid = true; g.grad_slot = g.cur;
       ctx->last_first_accepted = true;
       // (the accept words alternate like the host slots: this iteration's own tail writes the OTHER word, so its assemble,
@@ -2755,14 +2717,14 @@ gvi_status gvi_ngd_run(gvi_ctx* ctx, int max_iters, double step_size_base, int m
       ctx->pipe_tail = true; ctx->pipe_c0_imm = false; ctx->pub_ring = 1 - ring_i;
       st = pipe_enqueue(ctx, step1);
       ctx->cur_pred = nullptr; ctx->pipe_tail = false; ctx->pipe_c0_imm = true; ctx->pub_ring = 0;
-      if (st != GVI_OK) return finish(st);
+      if (st != GVI_OK) { pipe_restore(ctx, snap); return finish(st); }   // undo the provisional accept (cur / gcur flipped)
       seq_n = ctx->seq;
     }
     const int ti = spec_next ? g.cur : 1 - g.cur;                // NGD slot of trial i
     double c1 = 0.0;
     {
       const gvi_status st = ngd_cost_wait(ctx, ti, &c1, seq_i, ring_i);
-      if (st != GVI_OK) return finish(st);
+      if (st != GVI_OK) { if (spec_next) pipe_restore(ctx, snap); return finish(st); }
     }
     if (c1 < c0) {                                               // accepted (NaN compares false)
       ctx->last_first_accepted = true;
@@ -2909,12 +2871,15 @@ struct RcclApi {
 };
 bool load_rccl(RcclApi& r, std::string& err) {
   const char* names[] = {getenv("GVI_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  std::string why;                                   // dlerror() clears the message it returns: read it ONCE per failed dlopen
   for (const char* nm : names) {
     if (!nm || !*nm) continue;
     r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
     if (r.lib) break;
+    const char* e = dlerror();
+    why = e ? e : "?";
   }
-  if (!r.lib) { err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return false; }
+  if (!r.lib) { err = "cannot load librccl: " + (why.empty() ? std::string("no candidate name") : why); return false; }
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
   r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
@@ -3077,7 +3042,13 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "orbit") ctx->orbit = value != 0;
   else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
-  else if (n == "jacobi_tol_exp") { ctx->jacobi_tol = std::pow(10.0, (double)std::min(-20, value)); for (auto& s : ctx->sets) s->jtol = ctx->jacobi_tol; }
+  else if (n == "jacobi_tol_exp") {
+    // the threshold compares SQUARED off-diagonal mass with squared diagonal mass: anything looser than 1e-20 (1e-10 relative)
+    // would break the 1e-9 operator parity, so it is refused rather than silently clamped
+    if (value > -20) return fail(ctx, GVI_ERR_ARG, "jacobi_tol_exp must be <= -20 (threshold 10^value on squared magnitudes)");
+    ctx->jacobi_tol = std::pow(10.0, (double)value);
+    for (auto& s : ctx->sets) s->jtol = ctx->jacobi_tol;
+  }
   else if (n == "orbit_waves") ctx->orbit_waves = std::max(1, value);
   else if (n == "orbit_min_tiles") ctx->orbit_min_tiles = std::max(1, value);
   else if (n == "orbit_stack") ctx->orbit_stack = value != 0;
@@ -3102,7 +3073,7 @@ gvi_status gvi_debug_bcr_stamps(gvi_ctx* ctx, unsigned long long* out) {
 #endif
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 6) return GVI_ERR_ARG;
+  if (!ctx || variant < 0 || variant > 6 || variant == 3 || variant == 4) return GVI_ERR_ARG;
   ctx->variant = variant;
   return GVI_OK;
 }

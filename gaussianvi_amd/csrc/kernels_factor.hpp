@@ -963,90 +963,6 @@ __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// moments_wide_kernel<D, Psi, FULL>: same decomposition as moments_reg_kernel, different register
-// economy.  With the wave index made uniform (readfirstlane) the psi operands are loop-invariant, so
-// the compiler keeps all of them in VGPRs: no LDS traffic inside the loop.  FULL needs ~400 VGPRs
-// (91 accumulators + 78 operands + double-buffered z) = ONE wave per SIMD, latency hidden by an
-// explicit prefetch of the next 64 points; the cost pass fits two waves.
-//   Z rows are addressed as wave-uniform row base + one 32-bit per-lane byte offset (saddr form).
-// ---------------------------------------------------------------------------------------------
-template <int D, typename Psi, bool FULL>
-__global__ __launch_bounds__(256, FULL ? 1 : 2) void moments_wide_kernel(MomArgs a) {
-  constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
-  constexpr int NB = (NP + 15) / 16;
-  __shared__ double hs[4][Psi::LDS];
-  __shared__ double red[4][16][65];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int kq = blockIdx.x * 4 + wave;
-  const bool active = kq < a.f.K;
-  const int k = active ? kq : a.f.K - 1;                    // wave-uniform; inactive waves redo the last factor
-  Psi::load(a, k, hs[wave], lane);
-  __syncthreads();
-  double acc[NP];
-#pragma unroll
-  for (int j = 0; j < NP; ++j) acc[j] = 0.0;
-  const int64_t Np = a.f.Np;
-  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
-  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
-  const char* __restrict__ Zb = (const char*)a.f.Zt;
-  const char* __restrict__ wb = (const char*)a.f.w;
-  const size_t rowb = (size_t)Np * 8;
-  const unsigned nvalid = (unsigned)a.f.N;
-  unsigned idx = (unsigned)(i0 + lane);
-  const unsigned iend = (unsigned)i1;
-  double zn[D], wn = 0.0;
-#pragma unroll
-  for (int c = 0; c < D; ++c) zn[c] = 0.0;
-  if (idx < iend) {
-#pragma unroll
-    for (int c = 0; c < D; ++c) zn[c] = *(const double*)(Zb + c * rowb + (size_t)idx * 8u);
-    wn = *(const double*)(wb + (size_t)idx * 8u);
-  }
-  for (; idx < iend; idx += 64) {
-    double z[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) z[c] = zn[c];
-    const double wi = wn;                                   // padded tail: w = 0, z = 0
-    const unsigned nxt = idx + 64;
-    if (nxt < iend) {                                       // software prefetch of the next 64 points
-#pragma unroll
-      for (int c = 0; c < D; ++c) zn[c] = *(const double*)(Zb + c * rowb + (size_t)nxt * 8u);
-      wn = *(const double*)(wb + (size_t)nxt * 8u);
-    }
-    const double psi = Psi::eval(z, hs[wave], a);
-    // GUARD kinds may be non-finite at the padded z = 0 (x = mu): keep 0 * inf out of the sums
-    const double cw = Psi::GUARD ? (idx < nvalid ? wi * psi : 0.0) : wi * psi;
-    acc[0] += cw;
-    if (FULL) {
-      int q = 1 + D;
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        const double t = cw * z[c];
-        acc[1 + c] += t;
-#pragma unroll
-        for (int e = c; e < D; ++e) { acc[q] = fma(t, z[e], acc[q]); ++q; }
-      }
-    }
-  }
-  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * NP;
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (bb * 16 + j < NP) red[wave][j][lane] = acc[bb * 16 + j];
-    __syncthreads();
-    const int j = lane & 15, part = lane >> 4;
-    double s = 0.0;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) s += red[wave][j][part * 16 + t];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // moments_split_kernel<D, FULL>: factor dimensions whose (D+1)(D+2)/2 accumulators do not fit one
 // lane (D = 16, 20, 24; BASELINE configs[4]).  Block = 4 waves on ONE factor and the SAME 64 points per
 // step:  (1) every wave decodes z from the table's 8-bit node codes through a 256-entry LDS look-up
@@ -1789,111 +1705,6 @@ __global__ __launch_bounds__(256) void moments_scost_pair_kernel(MomArgs a0, Mom
   const int b = blockIdx.x;
   if (b < nb0) scost_body<D0, M0, F>(a0, b % nbx0, b / nbx0, us);
   else scost_body<D1, M1, F>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us);
-}
-
-// ---------------------------------------------------------------------------------------------
-// moments_tile_kernel<D, Psi, FULL>: the sigma-point table is staged through LDS.
-//   The four waves of a block (four factors) walk the same range of points, so a tile of TP = 256
-//   points x (D + 1) rows [z_0 .. z_{D-1}, w] is fetched ONCE per block by LDS-DMA
-//   (global_load_lds_dwordx4: 1 KiB = 128 points of one row per wave instruction, no VGPR staging),
-//   double-buffered: tile t+1 is in flight while tile t is consumed.  Per-lane z / w then come from
-//   conflict-free ds_read_b64 -- no global-load latency inside the point loop, a quarter of the
-//   L1 / L2 traffic.  Accumulation, psi operands and the final reduction as in moments_reg_kernel
-//   (the reduction scratch aliases the tile buffers).  Np is padded to a multiple of TP (z = 0, w = 0).
-// ---------------------------------------------------------------------------------------------
-constexpr int TILE_PTS = 256;
-
-template <int D, typename Psi, bool FULL>
-__global__ __launch_bounds__(256, 2) void moments_tile_kernel(MomArgs a) {
-  constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
-  constexpr int NB = (NP + 15) / 16;
-  constexpr int TP = TILE_PTS, ROWS = D + 1;
-  constexpr int NINSTR = 2 * ROWS;                       // 1 KiB DMA pieces per tile (two per row)
-  constexpr int PER_WAVE = (NINSTR + 3) / 4;             // issued by every wave (padded with re-loads)
-  constexpr int TILE_D = ROWS * TP;                      // doubles per tile
-  constexpr int RED_D = 4 * 16 * 65;
-  constexpr int BUF_D = 2 * TILE_D > RED_D ? 2 * TILE_D : RED_D;
-  __shared__ __attribute__((aligned(16))) double buf[BUF_D];
-  __shared__ double hs[4][Psi::LDS];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int kq = blockIdx.x * 4 + wave;
-  const bool active = kq < a.f.K;
-  const int k = active ? kq : a.f.K - 1;
-  Psi::load(a, k, hs[wave], lane);
-  double acc[NP];
-#pragma unroll
-  for (int j = 0; j < NP; ++j) acc[j] = 0.0;
-  const int64_t Np = a.f.Np;
-  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
-  const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
-  const int ntiles = (int)((i1 - i0) / TP);              // chunk and Np are multiples of TP
-  const unsigned nvalid = (unsigned)a.f.N;
-  // one DMA piece: row r (D = the weights), half hf: 128 points = 64 lanes x 16 B
-  auto issue_tile = [&](int t, int b) {
-#pragma unroll
-    for (int q = 0; q < PER_WAVE; ++q) {
-      int id = wave + 4 * q;
-      if (id >= NINSTR) id -= NINSTR;                    // padding: re-load an early piece (harmless)
-      const int r = id >> 1, hf = id & 1;
-      const double* src = (r < D ? a.f.Zt + (size_t)r * Np : a.f.w) + i0 + (int64_t)t * TP + hf * 128 + lane * 2;
-      double* dst = buf + b * TILE_D + r * TP + hf * 128;   // wave-uniform; lanes land at + lane * 16 B
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-  if (ntiles > 0) issue_tile(0, 0);
-  for (int t = 0; t < ntiles; ++t) {
-    const int b = t & 1;
-    if (t + 1 < ntiles) {
-      issue_tile(t + 1, b ^ 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");   // tile t landed, tile t+1 in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    const double* zt = buf + b * TILE_D;
-#pragma unroll 1
-    for (int it = 0; it < TP / 64; ++it) {
-      double z[D];
-#pragma unroll
-      for (int c = 0; c < D; ++c) z[c] = zt[c * TP + it * 64 + lane];
-      const double wi = zt[D * TP + it * 64 + lane];
-      int woff = wave * Psi::LDS;                          // FULL: keep the psi operands in LDS (see moments_reg_kernel)
-      if (FULL) asm volatile("" : "+s"(woff));
-      const double psi = Psi::eval(z, &hs[0][0] + woff, a);
-      const unsigned idx = (unsigned)(i0 + (int64_t)t * TP + it * 64 + lane);
-      const double cw = Psi::GUARD ? (idx < nvalid ? wi * psi : 0.0) : wi * psi;
-      acc[0] += cw;
-      if (FULL) {
-        int q = 1 + D;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          const double tt = cw * z[c];
-          acc[1 + c] += tt;
-#pragma unroll
-          for (int e = c; e < D; ++e) { acc[q] = fma(tt, z[e], acc[q]); ++q; }
-        }
-      }
-    }
-    __syncthreads();                                       // everyone is done with buffer b before it is refilled
-  }
-  double(*red)[16][65] = (double(*)[16][65])buf;
-  double* out = a.partial + ((size_t)k * a.nchunk + blockIdx.y) * NP;
-#pragma unroll
-  for (int bb = 0; bb < NB; ++bb) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (bb * 16 + j < NP) red[wave][j][lane] = acc[bb * 16 + j];
-    __syncthreads();
-    const int j = lane & 15, part = lane >> 4;
-    double sred = 0.0;
-#pragma unroll
-    for (int tt = 0; tt < 16; ++tt) sred += red[wave][j][part * 16 + tt];
-    sred += __shfl_xor(sred, 16);
-    sred += __shfl_xor(sred, 32);
-    if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = sred;
-    __syncthreads();
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

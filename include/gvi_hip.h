@@ -305,16 +305,17 @@ gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kerne
  * 5 register kernel fused with the chain's other set in one launch, 6 sign-orbit kernel), chunks. */
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk);
 /* Kernel variant override for A/B runs: 0 = auto (sum-of-squares sets with m = 6 / 12 on a table that decomposes into sign
- * orbits take the sign-orbit kernel; otherwise 5 / 3 / 2 / 1 as instantiated), 1 = generic LDS kernel, 2 = register kernel
- * (psi operands in LDS), 3 = operand-resident, 4 = LDS-staged table (experimental), 5 = register kernel with psi operands in
- * SGPRs, 6 = sign-orbit kernel where supported. */
+ * orbits take the sign-orbit kernel; otherwise 5 / 2 / 1 as instantiated), 1 = generic LDS kernel, 2 = register kernel
+ * (psi operands in LDS), 5 = register kernel with psi operands in SGPRs, 6 = sign-orbit kernel where supported.  3 and 4
+ * (round-1 A/B variants, removed) return GVI_ERR_ARG. */
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
 /* Runtime form of the A/B environment switches read at gvi_ctx_create.  Results are identical in every
  * setting of the scheduling switches; the switches that select another summation order or another (mathematically
  * equivalent) route agree to rounding: "split_flush" (d = 16 / 20 / 24 kernel; 0 = plain recursive sums), "mirror",
  * "orbit" / "orbit_waves" / "orbit_copies" (sign-orbit kernel, its chunking and its private accumulator copies),
  * "chol_sqrt" (1: sum-of-squares sets take S = chol(Sigma) instead of the symmetric root -- the quadrature is exact there),
- * "jacobi_tol_exp" (stopping threshold 10^value of the symmetric-root solve).
+ * "jacobi_tol_exp" (stopping threshold 10^value of the symmetric-root solve, on SQUARED off-diagonal / diagonal mass; values
+ * above -20 return GVI_ERR_ARG -- the environment form GVI_JACOBI_TOL_EXP clamps to -20 instead).
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,
  * orbit, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline. */
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
