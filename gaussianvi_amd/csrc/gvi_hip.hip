@@ -21,9 +21,10 @@
 
 #include "host_linalg.hpp"
 #include "kernels_bt.hpp"
-#include "kernels_bcr_seg.hpp"
+#include "chain_launch.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_orbit.hpp"
+#include "kernels_fused.hpp"
 #include "orbits.hpp"
 #include "spgh.hpp"
 
@@ -168,7 +169,6 @@ struct gvi_ctx {
   bool last_first_accepted = true;
   int64_t n_full_pass = 0, n_cost_pass = 0;   // psi passes launched over all sets (gvi_ngd_counters)
   bool speculate = true;              // gvi_ngd_step: queue the next gradients behind the first trial
-  int bcr_variant = 0;                // 0 auto (segmented where instantiated), 1 per-level kernels
   bool profile = false;
   bool profile_all = false;           // events around every moments / cost launch (else: set 0, full pass only)
   int profile_every = 1;              // on = 3: bracket only every 8th dominant launch (an event pair costs ~14 us of queue gaps)
@@ -181,6 +181,9 @@ struct gvi_ctx {
   // sum-of-squares sets on the sign-orbit kernel (kernels_orbit.hpp) when the table decomposes; GVI_ORBIT=0: the
   // lane-per-point kernels (A/B; results agree to rounding)
   bool orbit = true;
+  // full moments pass of the resident iteration as ONE launch (kernels_fused.hpp) where every set runs the sign-orbit kernel;
+  // GVI_FUSED=0 / option "fused": the three-launch route prep -> psi -> epilogue (A/B; same numbers at four chunks per factor)
+  bool fused = true;
   int orbit_waves = 4096;             // waves the orbit launch of one set aims for (chunks = orbit_waves / K, <= tiles)
   // prep: cyclic Jacobi stops when (sum of squared off-diagonals) <= jacobi_tol * (sum of squared diagonals); option
   // "jacobi_tol_exp" / GVI_JACOBI_TOL_EXP sets 10^value
@@ -213,7 +216,7 @@ struct gvi_ctx {
   DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
   DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
   DevMem epi_counter;                 // two-level arrival counters of epilogue_all_kernel's tail
-  // trial precision formed inside the first BCR pass of the next run_seg call (see SegArgs::mix*)
+  // trial precision formed inside the first pass of the next factorisation (see ChainArgs::mix*)
   struct Mix { const double* VD = nullptr; const double* VU = nullptr; double* outD = nullptr; double* outU = nullptr; double step = 0.0; } mix;
   hipStream_t chain_stream = nullptr; // stream of the chain launches being queued (null: ctx->stream)
   int chain_ws = 0;
@@ -641,6 +644,14 @@ void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax
   else launch_orbit_pair_t<12, 6, 2>(a0, a1, full, lds, st, e0, e1, stack);
 }
 
+// the full pass of the resident iteration as one launch (kernels_fused.hpp)
+template <int M, int SMAX, int WAVES, int EPLP>
+gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
+  if (lds > 64 * 1024) GVICK(allow_lds(c, (const void*)factor_fused_kernel<M, SMAX, WAVES, EPLP>, (int)lds));
+  hipExtLaunchKernelGGL((factor_fused_kernel<M, SMAX, WAVES, EPLP>), dim3(grid), dim3(256), (uint32_t)lds, c->stream, e0, e1, 0, A);
+  return GVI_OK;
+}
+
 // prep (sqrt / inverse / psi operands) for one set at (mu, Sigma) device pointers
 gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Sigma, int slot = -1,
                     hipStream_t st = nullptr) {
@@ -802,256 +813,56 @@ gvi_status ensure_set_buffers(gvi_ctx* c, FactorSet& s) {
   return GVI_OK;
 }
 
-gvi_status ensure_chain_ws(gvi_ctx* c, BcrWs& w) {
-  const size_t T = c->T, nn = nn_(c), n = c->n;
-  const size_t words = 9 * T * nn + 4 * T * n + T;
+// workspace of one chain operation (kernels_chain.hpp); two operations are in flight together in the dual launches
+struct ChainWs { double* ws; int* wsi; };
+gvi_status ensure_chain_ws(gvi_ctx* c, ChainWs& w) {
+  const int NP = chain_padded(c->n);
+  if (!NP) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
   DevMem& Wb = c->chain_ws ? c->Wbuf2 : c->Wbuf;
   DevMem& Ib = c->chain_ws ? c->Ibuf2 : c->Ibuf;
-  HIPCK(c, Wb.ensure(words * 8));
-  HIPCK(c, Ib.ensure(T * sizeof(int)));
-  double* p = Wb.d();
-  w.E = p; p += T * nn;  w.GA = p; p += T * nn; w.GB = p; p += T * nn; w.CL = p; p += T * nn;
-  w.CR = p; p += T * nn; w.NU = p; p += T * nn; w.SL = p; p += T * nn; w.SR = p; p += T * nn;
-  w.Deff = p; p += T * nn;
-  w.v = p; p += T * n;   w.yL = p; p += T * n;  w.yR = p; p += T * n; w.yeff = p; p += T * n;
-  w.logp = p;
-  w.bad = (int*)Ib.p;
+  HIPCK(c, Wb.ensure(chain_ws_doubles(c->T, NP) * 8));
+  HIPCK(c, Ib.ensure(chain_lp_entries(c->T) * sizeof(int)));
+  w.ws = Wb.d();
+  w.wsi = (int*)Ib.p;
   return GVI_OK;
 }
 
-int bcr_levels(int T) {
-  int L = 0;
-  while ((1 << L) < T) ++L;
-  return L;
-}
-
-struct BcrPlan { int nlevels, tail_from, waves; };
-BcrPlan bcr_plan(const gvi_ctx* c) {
-  BcrPlan p;
-  p.nlevels = bcr_levels(c->T);
-  p.waves = c->n <= 12 ? BCR_TAIL_WAVES_MAX : 8;
-  p.tail_from = p.nlevels;
-  for (int l = 0; l < p.nlevels; ++l)
-    if (bcr_count(c->T, l) <= p.waves) { p.tail_from = l; break; }
-  return p;
-}
-
-template <bool PIVOT, int NMAX>
-gvi_status launch_bcr_forward(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
-  const size_t unit = (size_t)bcr_unit_lds_doubles(c->n) * 8;
-  for (int l = 0; l < pl.tail_from; ++l) {
-    a.level = l;
-    const int blocks = bcr_count(c->T, l) + (l > 0 ? bcr_survivors(c->T, l) : 0);
-    hipLaunchKernelGGL((bcr_forward_kernel<PIVOT, NMAX>), dim3(blocks), dim3(64), unit, c->stream, a);
-  }
-  a.tail_from = pl.tail_from;
-  const size_t lds = unit * pl.waves;
-  GVICK(allow_lds(c, (const void*)bcr_forward_tail_kernel<PIVOT, NMAX>, 160 * 1024));
-  hipLaunchKernelGGL((bcr_forward_tail_kernel<PIVOT, NMAX>), dim3(1), dim3(64 * pl.waves), lds, c->stream, a);
-  HIPCK(c, hipGetLastError());
-  return GVI_OK;
-}
-
-template <bool PIVOT>
-gvi_status launch_bcr_forward_n(gvi_ctx* c, BcrArgs& a, const BcrPlan& pl) {
-  switch (c->n) {                      // exact sizes: register-resident elimination (kernels_bt.hpp)
-    case 1: return launch_bcr_forward<PIVOT, 101>(c, a, pl);
-    case 2: return launch_bcr_forward<PIVOT, 102>(c, a, pl);
-    case 3: return launch_bcr_forward<PIVOT, 103>(c, a, pl);
-    case 4: return launch_bcr_forward<PIVOT, 104>(c, a, pl);
-    case 6: return launch_bcr_forward<PIVOT, 106>(c, a, pl);
-    case 8: return launch_bcr_forward<PIVOT, 108>(c, a, pl);
-    case 12: return launch_bcr_forward<PIVOT, 112>(c, a, pl);
-    default: break;
-  }
-  if (c->n <= 6) return launch_bcr_forward<PIVOT, 6>(c, a, pl);
-  if (c->n <= 8) return launch_bcr_forward<PIVOT, 8>(c, a, pl);
-  if (c->n <= 12) return launch_bcr_forward<PIVOT, 12>(c, a, pl);
-  return launch_bcr_forward<PIVOT, 16>(c, a, pl);
-}
-
-// forward block cyclic reduction of (D, U) [+ rhs]: one launch per wide level + one for the tail
-gvi_status run_bcr_forward(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale,
-                           bool pivot, bool need_E, BcrWs& w, BcrPlan& pl) {
-  if (c->n > BT_MAX_N) return fail(c, GVI_ERR_UNSUPPORTED, "state_dim > 16");
-  GVICK(ensure_chain_ws(c, w));
-  pl = bcr_plan(c);
-  BcrArgs a;
-  a.T = c->T; a.n = c->n; a.nlevels = pl.nlevels; a.level = 0; a.tail_from = pl.tail_from;
-  a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale; a.need_E = need_E ? 1 : 0; a.w = w;
-  return pivot ? launch_bcr_forward_n<true>(c, a, pl) : launch_bcr_forward_n<false>(c, a, pl);
-}
-
-// ---- segmented BCR (kernels_bcr_seg.hpp): three launches instead of ~2 log2(T) ----
-struct SegPass { int level0, m, S, prev0, top; };
-struct SegPlan { std::vector<SegPass> passes; int threads; };
-
-bool seg_supported(int n) { return n == 1 || n == 2 || n == 3 || n == 4 || n == 6 || n == 8 || n == 12; }
-
-SegPlan seg_plan(const gvi_ctx* c) {
-  const int n = c->n, T = c->T;
-  const int m_seg = n <= 6 ? 5 : (n <= 8 ? 4 : 3);
-  // top-pass nodes: 8 LDS block arrays must fit.  Small blocks leave room for a long top pass, and a chain that fits it is
-  // done in ONE launch instead of three (the 65-state planar / configs[1] chains: launch floor, not arithmetic)
-  const int cap = n <= 2 ? 128 : (n <= 4 ? 64 : (n <= 6 ? 48 : (n <= 8 ? 24 : 8)));
-  SegPlan p;
-  const int nlevels = bcr_levels(T);
-  int level0 = 0, prev0 = 0;
-  auto alive = [&](int l) { return (int)(((int64_t)T + (1 << l) - 1) >> l); };
-  while (alive(level0) > cap) {
-    p.passes.push_back({level0, m_seg, 1 << m_seg, prev0, 0});
-    prev0 = level0;
-    level0 += m_seg;
-  }
-  p.passes.push_back({level0, nlevels - level0, alive(level0), prev0, 1});
-  p.threads = n <= 8 ? 1024 : 512;
-  return p;
-}
-
-template <bool PIVOT, int N>
-gvi_status launch_seg(gvi_ctx* c, SegArgs a, const SegPlan& pl) {
-  GVICK(allow_lds(c, (const void*)bcr_seg_forward_kernel<PIVOT, N>, 160 * 1024));
-  GVICK(allow_lds(c, (const void*)bcr_seg_backward_kernel<N>, 160 * 1024));
-  const bool rhs = a.rhs != nullptr;
-  hipStream_t st = c->chain_stream ? c->chain_stream : c->stream;
-  for (const SegPass& ps : pl.passes) {
-    a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.prev0 = ps.prev0; a.top = ps.top;
-    const size_t lds = seg_fwd_lds_doubles(N, ps.S, rhs, ps.top != 0, pl.threads / 64) * 8;
-    if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: LDS budget");
-    const int stride = ps.S << ps.level0;
-    const int blocks = ps.top ? 1 : (c->T + stride - 1) / stride;
-    hipLaunchKernelGGL((bcr_seg_forward_kernel<PIVOT, N>), dim3(blocks), dim3(pl.threads), lds, st, a);
-  }
-  if (rhs || a.need_E) {
-    for (int i = (int)pl.passes.size() - 2; i >= 0; --i) {
-      const SegPass& ps = pl.passes[i];
-      a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.prev0 = ps.prev0; a.top = 0;
-      const size_t lds = seg_bwd_lds_doubles(N, ps.S, rhs) * 8;
-      const int stride = ps.S << ps.level0;
-      hipLaunchKernelGGL((bcr_seg_backward_kernel<N>), dim3((c->T + stride - 1) / stride), dim3(pl.threads), lds,
-                         st, a);
-    }
-  }
-  HIPCK(c, hipGetLastError());
-  return GVI_OK;
-}
-
-template <bool PIVOT>
-gvi_status launch_seg_n(gvi_ctx* c, const SegArgs& a, const SegPlan& pl) {
-  switch (c->n) {
-    case 1: return launch_seg<PIVOT, 1>(c, a, pl);
-    case 2: return launch_seg<PIVOT, 2>(c, a, pl);
-    case 3: return launch_seg<PIVOT, 3>(c, a, pl);
-    case 4: return launch_seg<PIVOT, 4>(c, a, pl);
-    case 6: return launch_seg<PIVOT, 6>(c, a, pl);
-    case 8: return launch_seg<PIVOT, 8>(c, a, pl);
-    case 12: return launch_seg<PIVOT, 12>(c, a, pl);
-  }
-  return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: block size");
-}
-
-SegArgs make_seg_args(gvi_ctx* c, const BcrWs& w, const double* D, const double* U, const double* rhs, double scale, bool need_E,
-                      double* SigD, double* SigU, double* x, double* hld, bool with_mix) {
-  SegArgs a;
-  a.T = c->T; a.n = c->n; a.need_E = need_E ? 1 : 0;
+ChainArgs make_chain_args(gvi_ctx* c, const ChainWs& w, const double* D, const double* U, const double* rhs, double scale, bool need_back,
+                          double* SigD, double* SigU, double* x, double* hld, bool with_mix) {
+  ChainArgs a{};
+  a.T = c->T; a.n = c->n; a.need_back = need_back ? 1 : 0;
   a.D = D; a.U = U; a.rhs = rhs; a.rhs_scale = scale;
-  a.w.base = w.E; a.w.bad = w.bad;                          // one allocation, arrays in ensure_chain_ws's order
+  a.ws = w.ws; a.wsi = w.wsi;
   a.SigD = SigD; a.SigU = SigU; a.x = x; a.hld = hld;
-  a.level0 = a.m = a.S = a.prev0 = a.top = 0;
   a.pred = c->cur_pred; a.pred_val = c->cur_pred_val;
   // the mixed-in matrix and its output are [D | U] in one buffer each (ngd_trial_state): the kernels derive the U parts
-  a.mixVD = with_mix ? c->mix.VD : nullptr;
-  a.mixOutD = with_mix ? c->mix.outD : nullptr; a.mix_step = with_mix ? c->mix.step : 0.0;
+  a.mixV = with_mix ? c->mix.VD : nullptr;
+  a.mixOut = with_mix ? c->mix.outD : nullptr; a.mix_step = with_mix ? c->mix.step : 0.0;
   assert(!(with_mix && c->mix.VD) || (c->mix.VU == c->mix.VD + (size_t)c->T * nn_(c) && c->mix.outU == c->mix.outD + (size_t)c->T * nn_(c)));
   return a;
 }
 
-gvi_status run_seg(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, bool pivot,
-                   bool need_E, double* SigD, double* SigU, double* x, double* hld) {
-  BcrWs w;
-  GVICK(ensure_chain_ws(c, w));
-  const SegArgs a = make_seg_args(c, w, D, U, rhs, scale, need_E, SigD, SigU, x, hld, true);
-  const SegPlan pl = seg_plan(c);
-  return pivot ? launch_seg_n<true>(c, a, pl) : launch_seg_n<false>(c, a, pl);
-}
-
-// factorisation a0 (workspace 0, may carry the fused trial precision) and solve a1 (workspace 1) side by side in the same
-// launches (bcr_seg_*_dual_kernel)
-template <int N>
-gvi_status launch_seg_dual(gvi_ctx* c, SegArgs a0, SegArgs a1, const SegPlan& pl) {
-  GVICK(allow_lds(c, (const void*)bcr_seg_forward_dual_kernel<N>, 160 * 1024));
-  GVICK(allow_lds(c, (const void*)bcr_seg_backward_dual_kernel<N>, 160 * 1024));
-  for (const SegPass& ps : pl.passes) {
-    for (SegArgs* a : {&a0, &a1}) { a->level0 = ps.level0; a->m = ps.m; a->S = ps.S; a->prev0 = ps.prev0; a->top = ps.top; }
-    const size_t lds = std::max(seg_fwd_lds_doubles(N, ps.S, false, ps.top != 0, pl.threads / 64),
-                                seg_fwd_lds_doubles(N, ps.S, true, ps.top != 0, pl.threads / 64)) * 8;
-    if (lds > 160 * 1024) return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: LDS budget");
-    const int stride = ps.S << ps.level0;
-    const int blocks = ps.top ? 1 : (c->T + stride - 1) / stride;
-    hipLaunchKernelGGL((bcr_seg_forward_dual_kernel<N>), dim3(2 * blocks), dim3(pl.threads), lds, c->stream, a0, a1, blocks);
-  }
-  for (int i = (int)pl.passes.size() - 2; i >= 0; --i) {
-    const SegPass& ps = pl.passes[i];
-    for (SegArgs* a : {&a0, &a1}) { a->level0 = ps.level0; a->m = ps.m; a->S = ps.S; a->prev0 = ps.prev0; a->top = 0; }
-    const size_t lds = std::max(seg_bwd_lds_doubles(N, ps.S, false), seg_bwd_lds_doubles(N, ps.S, true)) * 8;
-    const int stride = ps.S << ps.level0;
-    const int blocks = (c->T + stride - 1) / stride;
-    hipLaunchKernelGGL((bcr_seg_backward_dual_kernel<N>), dim3(2 * blocks), dim3(pl.threads), lds, c->stream, a0, a1, blocks);
-  }
-  HIPCK(c, hipGetLastError());
+gvi_status run_chain(gvi_ctx* c, const ChainArgs& a0, const ChainArgs& a1, bool on0, bool on1) {
+  hipStream_t st = c->chain_stream ? c->chain_stream : c->stream;
+  const hipError_t e = chain_launch(c->n, chain_plan(c->T, c->n), a0, a1, on0, on1, st);
+  if (e == hipErrorInvalidValue) return fail(c, GVI_ERR_UNSUPPORTED, "chain kernels: block size / LDS budget");
+  HIPCK(c, e);
   return GVI_OK;
 }
 
-gvi_status launch_seg_dual_n(gvi_ctx* c, const SegArgs& a0, const SegArgs& a1, const SegPlan& pl) {
-  switch (c->n) {
-    case 1: return launch_seg_dual<1>(c, a0, a1, pl);
-    case 2: return launch_seg_dual<2>(c, a0, a1, pl);
-    case 3: return launch_seg_dual<3>(c, a0, a1, pl);
-    case 4: return launch_seg_dual<4>(c, a0, a1, pl);
-    case 6: return launch_seg_dual<6>(c, a0, a1, pl);
-    case 8: return launch_seg_dual<8>(c, a0, a1, pl);
-    case 12: return launch_seg_dual<12>(c, a0, a1, pl);
-  }
-  return fail(c, GVI_ERR_UNSUPPORTED, "segmented BCR: block size");
-}
-
-// log-det (+ optionally marginals) of the chain (D, U) device arrays
+// log-det (+ optionally marginals) of the chain (D, U) device arrays; carries the fused trial precision (ctx->mix) if set
 gvi_status run_bt_factor(gvi_ctx* c, const double* D, const double* U, double* SigD, double* SigU, double* hld) {
-  if (seg_supported(c->n) && c->bcr_variant != 1)
-    return run_seg(c, D, U, nullptr, 1.0, false, SigD != nullptr, SigD, SigU, nullptr, hld);
-  BcrWs w;
-  BcrPlan pl;
-  GVICK(run_bcr_forward(c, D, U, nullptr, 1.0, false, SigD != nullptr, w, pl));
-  hipLaunchKernelGGL(bcr_logdet_kernel, dim3(1), dim3(256), 0, c->stream, c->T, w.logp, w.bad, hld);
-  if (SigD) {
-    const size_t unit = (size_t)7 * c->n * c->n * 8;
-    GVICK(allow_lds(c, (const void*)bcr_back_marginals_head_kernel, 160 * 1024));
-    hipLaunchKernelGGL(bcr_back_marginals_head_kernel, dim3(1), dim3(64 * pl.waves), unit * pl.waves, c->stream,
-                       c->T, c->n, pl.nlevels, pl.tail_from, w, SigD, SigU);
-    for (int l = pl.tail_from - 1; l >= 0; --l)
-      hipLaunchKernelGGL(bcr_back_marginals_kernel, dim3(bcr_count(c->T, l)), dim3(64), unit, c->stream, c->T, c->n,
-                         l, w, SigD, SigU);
-  }
-  HIPCK(c, hipGetLastError());
-  return GVI_OK;
+  ChainWs w;
+  GVICK(ensure_chain_ws(c, w));
+  const ChainArgs a0 = make_chain_args(c, w, D, U, nullptr, 1.0, SigD != nullptr, SigD, SigU, nullptr, hld, true);
+  return run_chain(c, a0, a0, true, false);
 }
 
 gvi_status run_bt_solve(gvi_ctx* c, const double* D, const double* U, const double* rhs, double scale, double* x) {
-  if (seg_supported(c->n) && c->bcr_variant != 1)
-    return run_seg(c, D, U, rhs, scale, true, false, nullptr, nullptr, x, nullptr);
-  BcrWs w;
-  BcrPlan pl;
-  GVICK(run_bcr_forward(c, D, U, rhs, scale, true, false, w, pl));
-  const int n = c->n;
-  hipLaunchKernelGGL(bcr_back_solve_head_kernel, dim3(1), dim3(1024), 0, c->stream, c->T, n, pl.nlevels, pl.tail_from,
-                     w, x);
-  for (int l = pl.tail_from - 1; l >= 0; --l) {
-    const int cnt = bcr_count(c->T, l);
-    hipLaunchKernelGGL(bcr_back_solve_kernel, dim3((unsigned)((cnt * n + 255) / 256)), dim3(256), 0, c->stream,
-                       c->T, n, l, w, x);
-  }
-  HIPCK(c, hipGetLastError());
-  return GVI_OK;
+  ChainWs w;
+  GVICK(ensure_chain_ws(c, w));
+  const ChainArgs a1 = make_chain_args(c, w, D, U, rhs, scale, false, nullptr, nullptr, x, nullptr, false);
+  return run_chain(c, a1, a1, false, true);
 }
 
 gvi_status run_scatter(gvi_ctx* c, FactorSet& s, const double* Vdmu, const double* Vddmu, double* g, double* D, double* U) {
@@ -1109,6 +920,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
+  if (const char* w = getenv("GVI_FUSED")) c->fused = atoi(w) != 0;
   if (const char* w = getenv("GVI_PIPELINE")) c->pipeline = atoi(w) != 0;
   if (const char* w = getenv("GVI_CHOL_SQRT")) c->chol_sqrt = atoi(w) != 0;
   if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
@@ -1125,7 +937,6 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_DUAL_CHAIN")) c->dual_chain = atoi(w) != 0;
   if (const char* w = getenv("GVI_SCOST_F")) c->scost_f = atoi(w) == 4 ? 4 : 2;
   if (const char* w = getenv("GVI_COST_CHUNK_MULT")) c->cost_chunk_mult = std::max(1, atoi(w));
-  if (const char* w = getenv("GVI_BCR_VARIANT")) c->bcr_variant = atoi(w);
   if (const char* w = getenv("GVI_SPECULATE")) c->speculate = atoi(w) != 0;
   if (const char* w = getenv("GVI_WARM_START")) c->warm_start = atoi(w) != 0;
   if (const char* w = getenv("GVI_FUSE_TRIAL")) c->fuse_trial = std::min(2, std::max(0, atoi(w)));
@@ -1823,7 +1634,10 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1
       tail.c0_use_imm = ctx->pipe_c0_imm ? 1 : 0; tail.c0_imm = ctx->pipe_c0;
     }
   }
-  hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L, tail);
+  CostList cl{};
+  cl.nsets = L.nsets;
+  for (int si = 0; si < L.nsets; ++si) { cl.cost[si] = L.e[si].cost; cl.K[si] = L.e[si].f.K; }
+  hipLaunchKernelGGL(epilogue_all_kernel, dim3(L.koff[L.nsets]), dim3(64), lds, ctx->stream, L, tail, cl);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -2220,8 +2034,106 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
   return GVI_OK;
 }
 
+// ---- the full pass as ONE launch (kernels_fused.hpp) ----
+static bool fused_ok(const gvi_ctx* ctx, int slot) {
+  if (!ctx->fused || !ctx->pair_fuse || ctx->profile_all || ctx->sets.empty() || ctx->sets.size() > 2) return false;
+  const int m = ctx->sets[0]->m;
+  for (auto& sp : ctx->sets) {
+    const FactorSet& s = *sp;
+    if (!orbit_supported(ctx, s) || !s.all_pos || s.closed_form || s.K <= 0 || s.m != m) return false;
+    if (s.prep_slot == slot) return false;          // products already resident: the plain route skips the prep
+    if (s.table->orb.tile_s.empty()) return false;
+  }
+  return true;
+}
+
+static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
+  NgdState& g = ctx->ngd;
+  FusedArgs A{};
+  A.nsets = (int)ctx->sets.size();
+  A.koff[0] = 0;
+  int smax = 0, dmax = 0;
+  size_t lds = 0;
+  const int m = ctx->sets[0]->m;
+  for (int si = 0; si < A.nsets; ++si) {
+    FactorSet& s = *ctx->sets[si];
+    FusedSet& F = A.s[si];
+    s.prep_slot = slot;
+    s.nchunk = 4; s.chunk = s.table->Np;
+    s.use_reg = s.use_split = false; s.use_orbit = true; s.fused_pair = true;
+    F.f = s.dev();
+    if (ctx->warm_start) {                 // (symmetric-root sets only; the Cholesky route ignores it)
+      if (s.Vws.bytes == 0) { HIPCK(ctx, s.Vws.ensure((size_t)s.K * s.d * s.d * 8)); s.warm_count = 0; }
+      F.f.Vws = s.Vws.d();
+      F.f.warm = (s.warm_count % 32) != 0;
+      s.warm_count++;
+    }
+    GVICK(orbit_args(ctx, s, 1, &F.oa));
+    F.oa.partial = nullptr;
+    F.mu = s.mu_k[slot].d(); F.Sigma = s.Sigma_k[slot].d();
+    F.start = (const int32_t*)s.dstart.p; F.mu_k = s.mu_k[slot].d(); F.Sigma_k = s.Sigma_k[slot].d();
+    F.Ephi = s.Ephi.d(); F.cost = s.cost.d(); F.Vdmu = s.Vdmu.d(); F.Vddmu = s.Vddmu.d();
+    A.koff[si + 1] = A.koff[si] + s.K;
+    A.cl.cost[si] = s.cost.d(); A.cl.K[si] = s.K;
+    smax = std::max(smax, s.table->orb.smax);
+    dmax = std::max(dmax, s.d);
+    lds = std::max(lds, fused_lds_doubles(s.d, m, F.oa.copies) * 8);
+  }
+  A.cl.nsets = A.nsets;
+  if (A.nsets == 1) A.koff[2] = A.koff[1];
+  unsigned extra = 0;
+  if (g.gpend[slot].on) {
+    const size_t T = ctx->T, nn = nn_(ctx);
+    A.gather = 1; A.n = ctx->n;
+    A.gmu = g.gpend[slot].dmu ? g.gpend[slot].mu_from : g.mu[slot].d();
+    A.gdmu = g.gpend[slot].dmu; A.gstep = g.gpend[slot].step;
+    A.SigD = g.Sig[slot].d(); A.SigU = g.Sig[slot].d() + T * nn;
+    A.mu_out = g.mu[slot].d(); A.nmu = (int64_t)T * ctx->n;
+    if (A.gdmu) extra = (unsigned)((A.nmu + 255) / 256);
+    g.gpend[slot].on = false;
+  }
+  EpiTail& tail = A.tail;
+  tail.on = 0; tail.pred = ctx->cur_pred; tail.pred_val = ctx->cur_pred_val; tail.c0_use_imm = 1;
+  if (publish_slot >= 0) {
+    const size_t need = (size_t)128 * (2 + (size_t)A.koff[A.nsets] / EPI_GROUP);
+    if (ctx->epi_counter.bytes < need) {
+      HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCK(ctx, ctx->epi_counter.ensure(need));
+      HIPCK(ctx, hipMemsetAsync(ctx->epi_counter.p, 0, need, ctx->stream));
+    }
+    ctx->seq += 1.0;
+    tail.on = 1; tail.acc = g.exch1.d(); tail.half_logdet = g.hld[publish_slot].d();
+    tail.host_out = ctx->host_slot_dev + 2 * ctx->pub_ring; tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
+    if (ctx->pipe_tail) {
+      tail.accept = ctx->pipe_dev.d() + ctx->pub_ring; tail.cost_dev = ctx->pipe_dev.d() + 2;
+      tail.slot_cur = 1 - publish_slot; tail.slot_trial = publish_slot;
+      tail.c0_use_imm = ctx->pipe_c0_imm ? 1 : 0; tail.c0_imm = ctx->pipe_c0;
+    }
+  }
+  ++ctx->n_full_pass;
+  FactorSet& s0 = *ctx->sets[0];
+  const bool prof = ctx->profile && (ctx->profile_count++ % ctx->profile_every) == 0;
+  if (prof)
+    for (int e = 0; e < 2; ++e)
+      if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
+  hipEvent_t e0 = prof ? s0.ev[0][0] : nullptr, e1 = prof ? s0.ev[0][1] : nullptr;
+  const unsigned grid = (unsigned)A.koff[A.nsets] + extra;
+  if (dmax > 32) return fail(ctx, GVI_ERR_UNSUPPORTED, "factor dimension > 32");
+  if (m == 2) GVICK((launch_fused_t<2, 4, 4, 1>(ctx, A, grid, lds, e0, e1)));
+  else if (m == 6 && smax <= 4) GVICK((launch_fused_t<6, 4, 4, 4>(ctx, A, grid, lds, e0, e1)));
+  else if (m == 6) GVICK((launch_fused_t<6, 6, 2, 4>(ctx, A, grid, lds, e0, e1)));
+  else if (smax <= 4) GVICK((launch_fused_t<12, 4, 3, 16>(ctx, A, grid, lds, e0, e1)));
+  else GVICK((launch_fused_t<12, 6, 2, 16>(ctx, A, grid, lds, e0, e1)));
+  HIPCK(ctx, hipGetLastError());
+  if (prof) s0.ev_set[0] = true;
+  return GVI_OK;
+}
+
 static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot, int publish_slot = -1) {
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
+  for (auto& s : ctx->sets)
+    if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
+  if (fused_ok(ctx, slot)) return ngd_fused_full(ctx, slot, publish_slot);
   GVICK(ngd_prep_all(ctx, slot));
   GVICK(ngd_moments_launch(ctx, slot, 1));
   return ngd_epilogue_all(ctx, 1, publish_slot);
@@ -2261,11 +2173,11 @@ static gvi_status ngd_grad_finish(gvi_ctx* ctx, int gb) {
   double* eg = g.exch0[gb].d();
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
-  if (ctx->dual_chain && ctx->side_solve && seg_supported(ctx->n) && ctx->bcr_variant != 1 && ctx->T > 1) {
+  if (ctx->dual_chain && ctx->side_solve && chain_supported(ctx->n) && ctx->T > 1) {
     ctx->solve_deferred[gb] = true;                     // goes out with the next trial factorisation (ngd_trial_state)
     return GVI_OK;
   }
-  if (ctx->side_solve && seg_supported(ctx->n) && ctx->bcr_variant != 1) {
+  if (ctx->side_solve && chain_supported(ctx->n)) {
     // the solve only feeds mu_trial; the trial precision and its factorisation need Vddmu alone, so the solve goes
     // to the side stream and ngd_join_solve() waits for it right before the first reader of dmu
     if (!ctx->side) {
@@ -2341,7 +2253,7 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
     double* eg = g.exch0[g.gcur].d();
     const double* V = eg + Tn;
     ctx->mix.VD = V; ctx->mix.VU = V + Tnn; ctx->mix.outD = g.Lam[t].d(); ctx->mix.outU = g.Lam[t].d() + Tnn; ctx->mix.step = step;
-    BcrWs w0, w1;
+    ChainWs w0, w1;
     ctx->chain_ws = 0;
     gvi_status fs = ensure_chain_ws(ctx, w0);
     ctx->chain_ws = 1;
@@ -2349,9 +2261,9 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
     ctx->chain_ws = 0;
     if (fs == GVI_OK) {
       double* sD = g.Sig[t].d();
-      const SegArgs a0 = make_seg_args(ctx, w0, g.Lam[c].d(), g.Lam[c].d() + Tnn, nullptr, 1.0, true, sD, sD + Tnn, nullptr, g.hld[t].d(), true);
-      const SegArgs a1 = make_seg_args(ctx, w1, V, V + Tnn, eg, -1.0, false, nullptr, nullptr, g.dmu2[g.gcur].d(), nullptr, false);
-      fs = launch_seg_dual_n(ctx, a0, a1, seg_plan(ctx));
+      const ChainArgs a0 = make_chain_args(ctx, w0, g.Lam[c].d(), g.Lam[c].d() + Tnn, nullptr, 1.0, true, sD, sD + Tnn, nullptr, g.hld[t].d(), true);
+      const ChainArgs a1 = make_chain_args(ctx, w1, V, V + Tnn, eg, -1.0, false, nullptr, nullptr, g.dmu2[g.gcur].d(), nullptr, false);
+      fs = run_chain(ctx, a0, a1, true, true);
     }
     ctx->mix = gvi_ctx::Mix();
     GVICK(fs);
@@ -2362,7 +2274,7 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
     GVICK(gs);
   } else if (ctx->solve_pending[g.gcur]) {
     // precision part first (needs no dmu), factorise, then join the side-stream solve and form mu_trial
-    if (seg_supported(ctx->n) && ctx->bcr_variant != 1 && ctx->T > 1) {
+    if (chain_supported(ctx->n) && ctx->T > 1) {
       // Lam_trial = Lam + step (V - Lam) is formed by the first BCR pass while it loads the chain (and written to
       // Lam[t] there): factorise "Lam[c] mixed with V" instead of launching trial_kernel first
       const size_t Tnn = (size_t)ctx->T * nn_(ctx);
@@ -2560,7 +2472,6 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
   GVICK(ngd_check(ctx));
   if (ctx->update_rule != GVI_RULE_NGD) return fail(ctx, GVI_ERR_STATE, "proximal rule selected: use gvi_prox_step");
   HIPCK(ctx, hipSetDevice(ctx->device));
-  NgdState& g = ctx->ngd;
   double c0 = 0.0;
   GVICK(ngd_iteration_entry(ctx, &c0));
   if (cost_iter) *cost_iter = c0;
@@ -2621,7 +2532,7 @@ void pipe_restore(gvi_ctx* c, const PipeSnapshot& p) {
 // the fused gather, the two-set sign-orbit launch, the epilogue with its tail, the assemble
 bool pipe_ok(const gvi_ctx* c) {
   if (!c->pipeline || dist_on(c) || c->update_rule != GVI_RULE_NGD || !c->speculate || c->fuse_trial == 0) return false;
-  if (!(c->dual_chain && c->side_solve && seg_supported(c->n) && c->bcr_variant != 1 && c->T > 1)) return false;
+  if (!(c->dual_chain && c->side_solve && chain_supported(c->n) && c->T > 1)) return false;
   if (!c->fuse_gather || !c->pair_fuse || c->profile_all || c->sets.size() != 2) return false;
   const FactorSet& s0 = *c->sets[0];
   const FactorSet& s1 = *c->sets[1];
@@ -3040,6 +2951,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "no_scost") ctx->no_scost = value != 0;
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);
   else if (n == "orbit") ctx->orbit = value != 0;
+  else if (n == "fused") ctx->fused = value != 0;
   else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") {
@@ -3061,16 +2973,6 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   return GVI_OK;
 }
 
-#ifdef GVI_BCR_TIMING
-// profiling build only (kernels_bcr_seg.hpp): the [6][64] shader-clock stamps of the last chain launches
-gvi_status gvi_debug_bcr_stamps(gvi_ctx* ctx, unsigned long long* out) {
-  if (!ctx || !out) return GVI_ERR_ARG;
-  HIPCK(ctx, hipDeviceSynchronize());
-  HIPCK(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(gvi_bcr_stamps), sizeof(unsigned long long) * 6 * 64));
-  HIPCK(ctx, hipMemcpyFromSymbol(out + 6 * 64, HIP_SYMBOL(gvi_bcr_stamps_elim), sizeof(unsigned long long) * 16));
-  return GVI_OK;
-}
-#endif
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
   if (!ctx || variant < 0 || variant > 6 || variant == 3 || variant == 4) return GVI_ERR_ARG;

@@ -1731,8 +1731,9 @@ __host__ __device__ inline size_t epilogue_lds_doubles(int d) { return (size_t)n
 // loads inside the d-long inner loops every product paid d dependent global round trips (profiles/r02_e: 15 us for
 // what is ~2 us of arithmetic).  Summation orders are unchanged (c ascending, chunk index ascending).
 // phase 0: everything; 1: chunk sums, E[psi] and cost only (Ms stays in LDS); 2: the back-transform after a phase-1 call
+// P: the factor's chunk partials ([nchunk][npo]): a.partial + k nchunk npo, or LDS (factor_fused_kernel)
 template <int DT>
-__device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm, int phase) {
+__device__ __forceinline__ double epilogue_body_t(const EpiArgs& a, int k, double* sm, int phase, const double* P) {
   const FactorDev& f = a.f;
   const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x;
   const int npo = a.full ? npairs(d) : 1;
@@ -1741,7 +1742,6 @@ __device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm, in
   double* Tm = M2 + dd;         // [d][d]
   double* Sv = Tm + dd;         // [d][d] Sinv
   double* Lv = Sv + dd;         // [d][d] Lam
-  const double* P = a.partial + (size_t)k * a.nchunk * npo;
   const double Tk = f.temperature[k];                     // issued with the other loads, used after the chunk sums
   const bool want_v = a.full && (a.Vdmu || a.Vddmu);
   if (want_v && phase != 2) {
@@ -1837,15 +1837,18 @@ __device__ inline double epilogue_body_t(const EpiArgs& a, int k, double* sm, in
 }
 
 // the chain shapes of BASELINE.json get unrolled instances; everything else runs the runtime-d body
-__device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm, int phase = 0) {
+__device__ __forceinline__ double epilogue_body_p(const EpiArgs& a, int k, double* sm, int phase, const double* P) {
   switch (a.f.d) {
-    case 2: return epilogue_body_t<2>(a, k, sm, phase);
-    case 4: return epilogue_body_t<4>(a, k, sm, phase);
-    case 6: return epilogue_body_t<6>(a, k, sm, phase);
-    case 8: return epilogue_body_t<8>(a, k, sm, phase);
-    case 12: return epilogue_body_t<12>(a, k, sm, phase);
-    default: return epilogue_body_t<0>(a, k, sm, phase);
+    case 2: return epilogue_body_t<2>(a, k, sm, phase, P);
+    case 4: return epilogue_body_t<4>(a, k, sm, phase, P);
+    case 6: return epilogue_body_t<6>(a, k, sm, phase, P);
+    case 8: return epilogue_body_t<8>(a, k, sm, phase, P);
+    case 12: return epilogue_body_t<12>(a, k, sm, phase, P);
+    default: return epilogue_body_t<0>(a, k, sm, phase, P);
   }
+}
+__device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm, int phase = 0) {
+  return epilogue_body_p(a, k, sm, phase, a.partial + (size_t)k * a.nchunk * (a.full ? npairs(a.f.d) : 1));
 }
 
 __global__ __launch_bounds__(64) void epilogue_kernel(EpiArgs a) {
@@ -1940,50 +1943,47 @@ struct EpiTail {
   double c0_imm;
 };
 
-__global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tail) {
-  extern __shared__ double sm[];
-  if (pred_skip(tail.pred, tail.pred_val)) return;
-  int si = 0;
-  while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
-  const int kf = (int)blockIdx.x - L.koff[si];
-  if (!tail.on) { epilogue_body(L.e[si], kf, sm); return; }
-  // With the tail on, the factor's cost goes out FIRST (phase 1: chunk sums only), the last block to arrive sums and
-  // publishes, and only then does every block do its back-transform (phase 2): the host has the trial cost -- and
-  // launches the next iteration's chain kernels -- while the epilogue's products and the assemble are still running,
-  // instead of ~10 us after them.
-  const double costk = epilogue_body(L.e[si], kf, sm, 1);
-  // Cross-block hand-over WITHOUT device-scope fences: on this multi-XCD part a release fence writes the XCD's whole L2
-  // back (the epilogue has just dirtied megabytes: 2049 blocks x __threadfence() cost ~45 us, measured).  Only the
-  // factor's cost has to be seen by the last block, so it is stored write-through at agent scope, the wave waits for
-  // that one store (vmcnt), and the arrival counters are relaxed agent-scope atomics.  Everything else the epilogue
-  // wrote is consumed by later launches (ordinary end-of-kernel release).
-  __shared__ int last;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(L.e[si].cost + kf, costk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The factor costs of every set, as the tail sums them
+struct CostList {
+  int nsets;
+  double* cost[MAX_FSETS];
+  int K[MAX_FSETS];
+};
+
+// Tail protocol, executed by ONE wave of every block (lane = its lane index) after the block's factor cost `costk` is known:
+// store it, count the block in; the block that arrives last sums the costs of all sets and publishes.  `sh`: 256 doubles of
+// LDS, `last`: one LDS int, both private to the calling wave's block.
+// Cross-block hand-over WITHOUT device-scope fences: on this multi-XCD part a release fence writes the XCD's whole L2
+// back (the epilogue has just dirtied megabytes: 2049 blocks x __threadfence() cost ~45 us, measured).  Only the
+// factor's cost has to be seen by the last block, so it is stored write-through at agent scope, the wave waits for
+// that one store (vmcnt), and the arrival counters are relaxed agent-scope atomics.  Everything else the epilogue
+// wrote is consumed by later launches (ordinary end-of-kernel release).
+__device__ __forceinline__ void epi_tail_arrive(const CostList& cl, const EpiTail& tail, double* cost_slot, const double costk, const int lane,
+                                                const unsigned bid, const unsigned nblocks, double* sh, int* last) {
+  if (lane == 0) {
+    __hip_atomic_store(cost_slot, costk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // two-level arrival count: thousands of atomics on ONE address serialise in L2; groups of EPI_GROUP blocks count on
     // their own 128-byte-spaced word, the last of each group counts on the top word
-    const unsigned grp = blockIdx.x / EPI_GROUP, ngrp = (gridDim.x + EPI_GROUP - 1) / EPI_GROUP;
-    const unsigned in_grp = grp + 1 < ngrp ? (unsigned)EPI_GROUP : gridDim.x - grp * EPI_GROUP;
+    const unsigned grp = bid / EPI_GROUP, ngrp = (nblocks + EPI_GROUP - 1) / EPI_GROUP;
+    const unsigned in_grp = grp + 1 < ngrp ? (unsigned)EPI_GROUP : nblocks - grp * EPI_GROUP;
     unsigned* gc = tail.counter + 32u * (1u + grp);
     int l = 0;
     if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
       __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
       l = __hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
     }
-    last = l;
+    *last = l;
   }
   wave_lds_sync();
-  if (!last) { epilogue_body(L.e[si], kf, sm, 2); return; }
-  const int lane = threadIdx.x;
-  double* sh = sm + epilogue_lds_doubles(L.e[si].f.d);  // [256] behind this factor's epilogue area (phase 2 still needs it)
+  if (!*last) return;
   double total = 0.0;
   // The summation order is that of cost_sum_all_kernel (256 strided partial sums, then a fixed 256-leaf tree per set).
   // All loads of a set's first 8 x 256 factors (per lane: 4 virtual threads x 8) are issued before the first add: the
   // tail is one wave on the critical path of the iteration, and one round trip per virtual thread cost ~6 us.
-  for (int s2 = 0; s2 < L.nsets; ++s2) {
-    const double* cost = L.e[s2].cost;
-    const int K = L.e[s2].f.K;
+  for (int s2 = 0; s2 < cl.nsets; ++s2) {
+    const double* cost = cl.cost[s2];
+    const int K = cl.K[s2];
     double p[4][8];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -2033,6 +2033,23 @@ __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tai
     }
   }
   wave_lds_sync();
+}
+
+__global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tail, CostList cl) {
+  extern __shared__ double sm[];
+  if (pred_skip(tail.pred, tail.pred_val)) return;
+  int si = 0;
+  while (si + 1 < L.nsets && (int)blockIdx.x >= L.koff[si + 1]) ++si;
+  const int kf = (int)blockIdx.x - L.koff[si];
+  if (!tail.on) { epilogue_body(L.e[si], kf, sm); return; }
+  // With the tail on, the factor's cost goes out FIRST (phase 1: chunk sums only), the last block to arrive sums and
+  // publishes, and only then does every block do its back-transform (phase 2): the host has the trial cost -- and
+  // launches the next iteration's chain kernels -- while the epilogue's products and the assemble are still running,
+  // instead of ~10 us after them.
+  const double costk = epilogue_body(L.e[si], kf, sm, 1);
+  __shared__ int last;
+  double* sh = sm + epilogue_lds_doubles(L.e[si].f.d);  // [256] behind this factor's epilogue area (phase 2 still needs it)
+  epi_tail_arrive(cl, tail, L.e[si].cost + kf, costk, (int)threadIdx.x, blockIdx.x, gridDim.x, sh, &last);
   epilogue_body(L.e[si], kf, sm, 2);
 }
 

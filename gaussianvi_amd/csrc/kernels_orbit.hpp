@@ -234,8 +234,12 @@ __device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, cons
   orbit_walk<M, S, FULL, SIGNED>(d, C, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
 }
 
-template <int M, int SMAX, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, const int chunk, double* lds) {
+// out: where the chunk's partial sums go -- the set's partial array (stand-alone launches) or LDS (factor_fused_kernel).
+// FRESH: the psi operands were written earlier in THIS launch by another wave of the block (factor_fused_kernel): u0 must
+// then come through the vector path (a wave-uniform address would otherwise be served by the scalar cache, which stores of
+// this launch do not update)
+template <int M, int SMAX, bool FULL, bool SIGNED, bool FRESH = false>
+__device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, const int chunk, double* lds, double* out) {
   const OrbitDev& ob = a.ob;
   const int lane = threadIdx.x & 63, d = a.d;
   const int NP = FULL ? (d + 1) * (d + 2) / 2 : 1;
@@ -253,7 +257,7 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   double su0[M], sg[M], k0 = 0.0;
 #pragma unroll
   for (int r = 0; r < M; ++r) {
-    const double u = a.u0[(size_t)k * M + r];
+    const double u = FRESH ? __builtin_nontemporal_load(a.u0 + (size_t)k * M + r) : a.u0[(size_t)k * M + r];
     sg[r] = SIGNED ? a.sgn[(size_t)k * M + r] : 1.0;
     su0[r] = SIGNED ? sg[r] * u : u;               // unsigned: u0 itself -- a wave-uniform scalar load, it stays in SGPRs
     k0 = fma(su0[r], u, k0);
@@ -279,7 +283,6 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   for (int sh = 32; sh > 0; sh >>= 1) m0 += __shfl_xor(m0, sh);
   if (chunk == 0) m0 = fma(ob.w0, k0, m0);       // the origin: psi(0) = sum_r s_r u0_r^2
   wave_lds_sync();
-  double* out = a.partial + ((size_t)k * a.nchunk + chunk) * NP;
   if (lane == 0) out[0] = m0;
   if (FULL)
     for (int e = 1 + lane; e < NP; e += 64) {
@@ -289,6 +292,11 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
       for (int q = 1; q < C; ++q) t += accl[e * C + ((q + rot) & (C - 1))];
       out[e] = t;
     }
+}
+
+template <bool FULL>
+__device__ __forceinline__ double* orbit_out(const OrbitArgs& a, const int k, const int chunk) {
+  return a.partial + ((size_t)k * a.nchunk + chunk) * (FULL ? (a.d + 1) * (a.d + 2) / 2 : 1);
 }
 
 // LDS doubles per wave
@@ -306,7 +314,8 @@ __global__ __launch_bounds__(256, WAVES) void moments_orbit_kernel(OrbitArgs a) 
   const int k = (int)blockIdx.x * 4 + wave;
   if (pred_skip(a.pred, a.pred_val)) return;
   if (k >= a.K) return;                          // no block-level barrier below
-  orbit_wave<M, SMAX, FULL, SIGNED>(a, k, (int)blockIdx.y, sm + (size_t)wave * orbit_lds_doubles(a.d, M, a.copies));
+  orbit_wave<M, SMAX, FULL, SIGNED>(a, k, (int)blockIdx.y, sm + (size_t)wave * orbit_lds_doubles(a.d, M, a.copies),
+                                    orbit_out<FULL>(a, k, (int)blockIdx.y));
 }
 
 // two sets in one launch (the chain pattern: binary priors + unary factors): blocks [0, nb0) serve set 0 as
@@ -327,10 +336,10 @@ __global__ __launch_bounds__(256, WAVES) void moments_orbit_pair_kernel(OrbitArg
     double* mine = sm + (size_t)wave * (l0 > l1 ? l0 : l1);
     if (id < nb0) {
       const int k = (id % nbx0) * 4 + wave, chunk = id / nbx0;
-      if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, mine);
+      if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, mine, orbit_out<FULL>(a0, k, chunk));
     }
     const int k1 = (id % nx1) * 4 + wave, chunk1 = id / nx1;
-    if (chunk1 < a1.nchunk && k1 < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k1, chunk1, mine);
+    if (chunk1 < a1.nchunk && k1 < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k1, chunk1, mine, orbit_out<FULL>(a1, k1, chunk1));
     return;
   }
   const bool second = id >= nb0;
@@ -338,9 +347,9 @@ __global__ __launch_bounds__(256, WAVES) void moments_orbit_pair_kernel(OrbitArg
   const int nbx = second ? nbx1 : nbx0;
   const int k = (id % nbx) * 4 + wave, chunk = id / nbx;
   if (!second) {
-    if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a0.d, M, a0.copies));
+    if (k < a0.K) orbit_wave<M, SMAX, FULL, SIGNED>(a0, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a0.d, M, a0.copies), orbit_out<FULL>(a0, k, chunk));
   } else {
-    if (k < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a1.d, M, a1.copies));
+    if (k < a1.K) orbit_wave<M, SMAX, FULL, SIGNED>(a1, k, chunk, sm + (size_t)wave * orbit_lds_doubles(a1.d, M, a1.copies), orbit_out<FULL>(a1, k, chunk));
   }
 }
 

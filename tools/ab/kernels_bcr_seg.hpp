@@ -26,7 +26,16 @@
 
 #include "kernels_bt.hpp"
 
+// Round-2 chain kernels, kept as the A/B leg of tools/ubench/chain_bench.hip only (the library uses kernels_chain.hpp).
 namespace gvi {
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
 
 // -DGVI_BCR_TIMING: constant-clock stamps (s_memrealtime, 100 MHz) of block 0 of every pass at its phase boundaries, read back with
 // gvi_debug_bcr_stamps -- a profiling aid for the latency-bound chain kernels, compiled out of the product build.
