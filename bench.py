@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the NGD Gauss-Hermite hot path on MI355X (contract: see the round prompt).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5|c3lit]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c2|c5|c3lit|planar1k|arm7x]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -39,7 +39,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_PEAK = 78.6e12        # FLOP/s, AMD public spec sheet (vector = matrix fp64 on MI355X); not in the guide
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+
+
+def git_blob_sha1(path):
+    """What `git hash-object` prints for the file: lets a reader check which committed file a number was read from."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def ensure_library(rank: int) -> None:
@@ -59,22 +66,35 @@ def ensure_library(rank: int) -> None:
         time.sleep(0.5)
 
 
+KIND_NAMES = {0: "range-1D", 1: "quadratic-prior", 2: "fixed-prior", 4: "hinge-SDF-2D", 5: "hinge-SDF-2D-body", 6: "hinge-SDF-3D", 7: "hinge-SDF-3D-arm"}
+# fp64 VALU instructions of ONE 64-point step of the lane-per-point register kernel, counted in the ISA of the instance
+# (hipcc --save-temps of moments_reg_kernel<D, Psi, full>): (kind, d) -> count.  79 at the planar hinge: 8 (pose rows) +
+# ~45 (clamp, two fp64 divisions, floor, bilinear weights and blend) + 5 (hinge) + 21 (c = w psi, m0, m1, packed M2)
+REG_KERNEL_FP64_PER_EVAL = {(4, 4): 79}
+
+
 def api_count(d, p):
     from gaussianvi_amd import api
     return api.spgh_count(d, p)
 
 
-def cpu_baseline(chain, seconds):
+def cpu_baseline(chain, seconds, set_index=0):
     """Reference-shaped CPU port (oracle/c/gvi_oracle.c: per-factor symmetric sqrt + expand, three
     Integrate passes with psi re-evaluated through a function pointer, OpenMP over factors) timed on
     this box's host cores on a bounded sample of the SAME workload: the first factors of the prior set
     at their start-state marginals (as many as ~`seconds` of CPU work allow, at most 256), repeated."""
-    import numpy as np  # noqa: F401
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     import gvi_oracle as o
-    spec = chain["specs"][0]
+    spec = chain["specs"][set_index]
     d, n = spec["d"], chain["n"]
+    if spec["kind"] == 4:                               # HINGE_SDF_2D: the grid goes to the port once
+        c_oracle.set_sdf2d(spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
+    elif spec["kind"] not in (0, 1, 2):
+        return {"value": None, "unit": "psi-evals/s", "cores": 0, "kind": "port",
+                "sample": f"skipped: the C port has no psi kind {spec['kind']}"}
+    n_arg = n if spec["kind"] in (1, 4) else d
     Kall = len(spec["start"])
     N_est = api_count(d, spec["p"])
     if N_est * d * 8 > 2 ** 28:
@@ -85,28 +105,30 @@ def cpu_baseline(chain, seconds):
                           f"{N_est * d * 8 / 2**30:.1f} GiB per thread"}
     SD, SU = o.inverse_gbp(chain["D0"], chain["U0"])
     mk, Sk = o.gather_marginals(chain["mu0"], SD, SU, spec["start"][:min(256, Kall)], d)
+    if spec["kind"] == 4:                               # marginals that reach the obstacles (the hinge is active)
+        mk = mk.copy(); mk[:, 1] += np.linspace(0.0, 1.2, len(mk))
     Z, w = o.nwspgr(d, spec["p"])
     threads = c_oracle.max_threads()
     # size the sample from a probe of one factor per thread (all threads)
     Kp = min(Kall, threads, len(mk))
     t0 = time.perf_counter()
-    c_oracle.moments(Z, w, mk[:Kp], Sk[:Kp], spec["kind"], spec["params"][:Kp], n, fused=False)
+    c_oracle.moments(Z, w, mk[:Kp], Sk[:Kp], spec["kind"], spec["params"][:Kp], n_arg, fused=False)
     t_probe = max(time.perf_counter() - t0, 1e-6)
     K = int(max(1, min(256, Kall, len(mk), Kp * max(1, int(seconds * 0.1 / t_probe)))))
     out = {}
     for name, fused in (("reference_style", False), ("fused", True)):
-        c_oracle.moments(Z, w, mk[:min(8, K)], Sk[:min(8, K)], spec["kind"], spec["params"][:min(8, K)], n, fused=fused)   # warm
+        c_oracle.moments(Z, w, mk[:min(8, K)], Sk[:min(8, K)], spec["kind"], spec["params"][:min(8, K)], n_arg, fused=fused)   # warm
         reps, t0 = 0, time.perf_counter()
         budget = seconds * (0.7 if not fused else 0.3)
         while True:
-            c_oracle.moments(Z, w, mk[:K], Sk[:K], spec["kind"], spec["params"][:K], n, fused=fused)
+            c_oracle.moments(Z, w, mk[:K], Sk[:K], spec["kind"], spec["params"][:K], n_arg, fused=fused)
             reps += 1
             el = time.perf_counter() - t0
             if el >= budget:
                 break
         out[name] = K * len(w) * reps / el
     return {"value": out["reference_style"], "unit": "psi-evals/s", "cores": threads, "kind": "port",
-            "sample": f"{K} of the {Kall} d={d} p={spec['p']} prior factors x {len(w)} sigma points, full moments pass "
+            "sample": f"{K} of the {Kall} d={d} p={spec['p']} {KIND_NAMES.get(spec['kind'], 'kind %d' % spec['kind'])} factors x {len(w)} sigma points, full moments pass "
                       f"(3 Integrate passes, psi x3 per point) repeated for ~{seconds:.0f} s, OpenMP {threads} threads",
             "fused_single_pass_value": out["fused"]}
 
@@ -372,50 +394,88 @@ def main():
     else:
         evals_full, evals_cost = float(stats[1]), float(stats[2])
 
+    # ---- outside the timed region: per-stage event timing (chain / factor pass / assemble) and, for workloads whose
+    # dominant launch is not the bracketed one of set 0, the event time of the dominant set's moments kernel ----
+    dom = int(np.argmax([K * N for (K, d, p, N) in ctx.sets])) if ctx.sets else 0
+    chain_pattern = len(ctx.sets) <= 2 and all(spec["kind"] in (1, 2) for spec in local["specs"])
+    stages = None
+    if single and not big:
+        ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
+        for _ in range(4):
+            ctx.ngd_step(0.55, 10)
+        ctx.profile_stages(True, read=False)
+        for _ in range(16):
+            ctx.ngd_step(0.55, 10)
+        st = ctx.profile_stages(False)
+        stages = {k: {"mean_us": round(float(v[0]), 2), "brackets": int(v[1])} for k, v in st.items()}
+        if not chain_pattern:
+            ctx.profile_enable(2)
+            kern_ms = []
+            for _ in range(12):
+                ctx.ngd_step(0.55, 10)
+                try:
+                    kern_ms.append(ctx.profile_last(ids[dom], 0))
+                except api.GviError:
+                    pass
+            ctx.profile_enable(0)
+
     if rank == 0:
+        Kd, dd_, pd_, Nd = ctx.sets[dom]
         K0, d0, p0, N0 = ctx.sets[0]
         m0 = d0 // 2
-        geo = ctx.profile_geometry(ids[0])
+        geo = ctx.profile_geometry(ids[dom])
         km = float(np.mean(kern_ms)) * 1e-3 if kern_ms else float("nan")
-        sreg_shapes = (4, 8, 12)
-        if geo["variant"] == 6:
-            kernel_name = f"moments_orbit{'_pair' if len(ctx.sets) == 2 else ''}_kernel<{m0}, {4 if p0 <= 5 else 6}, full>"
-        elif geo["variant"] == 5:
-            kernel_name = f"moments_sreg_pair_kernel<{d0}, {m0}, {m0}, {m0}, full>"
-        elif geo["variant"] == 2:
-            kernel_name = {0: f"moments_sreg_kernel<{d0}, {m0}, full>" if d0 in sreg_shapes else f"moments_reg_kernel<{d0}, PsiQuad<{d0},{m0}>, full>",
-                           5: f"moments_sreg_kernel<{d0}, {m0}, full>", 2: f"moments_reg_kernel<{d0}, PsiQuad<{d0},{m0}>, full>",
-                           3: f"moments_wide_kernel<{d0}, PsiQuad<{d0},{m0}>, full>",
-                           4: f"moments_tile_kernel<{d0}, PsiQuad<{d0},{m0}>, full>"}.get(args.variant, "moments_reg_kernel")
-        elif geo["variant"] == 3:
-            kernel_name = f"moments_split_kernel<{d0}, {(m0 + 3) // 4}, full>"
-        else:
-            kernel_name = "moments_generic_kernel"
-        # work of the bracketed launch: the prior set, plus the unary set when both ride in one launch
+        kind_dom = int(local["specs"][dom]["kind"])
+
         def weights_signed(spec):                      # any negative eigenvalue of the residual weight (Q^-1 / K^-1)?
             W = spec.get("Qinv", spec.get("Kinv"))
             return bool(np.linalg.eigvalsh(0.5 * (W + np.transpose(W, (0, 2, 1)))).min() <= 0.0)
-        sg0 = weights_signed(local["specs"][0])
-        sets_in_launch = [(K0, d0, m0, N0, sg0)]
-        fused_pair = geo["variant"] in (5, 6) and len(ctx.sets) == 2
-        if fused_pair:
-            K1, d1, p1, N1 = ctx.sets[1]
-            sets_in_launch.append((K1, d1, d1, N1, weights_signed(local["specs"][1])))   # unary: psi = (x - mu0)^T Kinv (x - mu0), m = d
-        evals_launch = sum(K * N for K, d, m, N, sg in sets_in_launch)
-        mirror = geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"      # sreg kernels on a symmetric table
-        ops_of = lambda d, m, sg: exec_ops(d, m, True, sg, mirror)
-        if geo["variant"] == 6:
-            p_of = {d0: p0}
-            if len(ctx.sets) == 2:
-                p_of[ctx.sets[1][1]] = ctx.sets[1][2]
-            ops_of = lambda d, m, sg: orbit_exec_ops(d, p_of[d], m, True, sg)
-        if geo["variant"] == 3:
-            # four waves per factor (moments_split_kernel): psi rows always carry the sign multiply, every wave forms
-            # c = w psi and adds the four partial sums of psi (3 adds each)
-            ops_of = lambda d, m, sg: exec_ops(d, m, True, True) + 3 + 12
-        exec_flop = sum(2 * ops_of(d, m, sg) * K * N for K, d, m, N, sg in sets_in_launch)
-        alg_flop = sum(alg_flops(d, m) * K * N for K, d, m, N, sg in sets_in_launch)
-        alg_bytes = sum(K * N * (d + 1) * 8 for K, d, m, N, sg in sets_in_launch)   # (d+1) s bytes per eval
+
+        fused_launch = os.environ.get("GVI_FUSED", "1") != "0" and chain_pattern and geo["variant"] == 6 and geo["nchunk"] == 4 and \
+            ((m0 == 6 and d0 == 12) or (m0 == 2 and d0 == 4))
+        executed_note = None
+        if chain_pattern:
+            sets_in_launch = [(K0, d0, m0, N0, weights_signed(local["specs"][0]))]
+            both = geo["variant"] in (5, 6) and len(ctx.sets) == 2
+            if both:
+                K1, d1, p1, N1 = ctx.sets[1]
+                sets_in_launch.append((K1, d1, d1, N1, weights_signed(local["specs"][1])))   # unary: m = d
+            if geo["variant"] == 6:
+                kernel_name = (f"factor_fused_kernel<{m0}, {4 if p0 <= 5 else 6}, ..., {d0}, {ctx.sets[1][1] if both else d0 // 2}> (gather + Cholesky products + "
+                               f"sign-orbit walk + chunk sum + cost tail + back-transform in one launch)") if fused_launch else \
+                    f"moments_orbit{'_pair' if both else ''}_kernel<{m0}, {4 if p0 <= 5 else 6}, full>"
+                p_of = {d: p for (K, d, p, N) in ctx.sets}
+                ops_of = lambda d, m, sg: orbit_exec_ops(d, p_of[d], m, True, sg)
+            elif geo["variant"] == 5:
+                kernel_name = f"moments_sreg_pair_kernel<{d0}, {m0}, {m0}, {m0}, full>"
+                mirror = os.environ.get("GVI_MIRROR", "1") != "0"
+                ops_of = lambda d, m, sg: exec_ops(d, m, True, sg, mirror)
+            elif geo["variant"] == 3:
+                kernel_name = f"moments_split_kernel<{d0}, {(m0 + 3) // 4}, full>"
+                ops_of = lambda d, m, sg: exec_ops(d, m, True, True) + 3 + 12      # four waves per factor: sign multiply, 4 partial psi sums
+            else:
+                kernel_name = f"moments_reg_kernel<{d0}, PsiQuad<{d0},{m0}>, full>" if geo["variant"] == 2 else "moments_generic_kernel"
+                ops_of = lambda d, m, sg: exec_ops(d, m, True, sg, False)
+            evals_launch = sum(K * N for K, d, m, N, sg in sets_in_launch)
+            exec_flop = sum(2 * ops_of(d, m, sg) * K * N for K, d, m, N, sg in sets_in_launch)
+            alg_flop = sum(alg_flops(d, m) * K * N for K, d, m, N, sg in sets_in_launch)
+            alg_bytes = sum(K * N * (d + 1) * 8 for K, d, m, N, sg in sets_in_launch)   # (d+1) s bytes per eval
+            ops_table = {f"d={d},m={m}": ops_of(d, m, sg) for K, d, m, N, sg in sets_in_launch}
+            launch_desc = ("every factor set, all stages of the pass" if fused_launch else
+                           ("prior set + unary set in one launch" if len(sets_in_launch) == 2 else "prior set"))
+        else:
+            # non-polynomial psi (hinge on a signed-distance field ...): the lane-per-point register kernel of the dominant set
+            per = REG_KERNEL_FP64_PER_EVAL.get((kind_dom, dd_))
+            kernel_name = (f"moments_reg_kernel<{dd_}, Psi[{KIND_NAMES.get(kind_dom, kind_dom)}], full>" if geo["variant"] == 2
+                           else "moments_generic_kernel")
+            evals_launch = Kd * Nd
+            exec_flop = 2.0 * per * evals_launch if per and geo["variant"] == 2 else float("nan")
+            alg_flop = float("nan")
+            alg_bytes = evals_launch * (dd_ + 1) * 8
+            ops_table = {f"kind={KIND_NAMES.get(kind_dom, kind_dom)},d={dd_}": per}
+            launch_desc = f"set {dom} ({KIND_NAMES.get(kind_dom, kind_dom)}, d = {dd_}, p = {pd_}: the set with the most evaluations)"
+            executed_note = ("fp64 VALU instructions per 64-point step counted in the ISA of the instance (REG_KERNEL_FP64_PER_EVAL), each as one "
+                             "FMA = 2 flop; the SDF look-up adds 4 x 8 B of gathered reads per evaluation from L2")
         traffic, traffic_source, valu_issue = None, None, None
         tpath = os.path.join(ROOT, TRAFFIC_FILE)
         if args.config == "c3" and world == 1 and os.path.exists(tpath):
@@ -423,7 +483,8 @@ def main():
                 tj = json.load(open(tpath))
                 if kernel_name.split("<")[0] in tj.get("kernel", ""):     # counters of the kernel that actually ran
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not re-measured in this run)"
+                    traffic_source = (f"{TRAFFIC_FILE} (git blob {git_blob_sha1(tpath)}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command; not re-measured in this run)")
                     valu_issue = {"busy_frac": tj["derived"]["valu_pipe_busy"], "valu_instructions_per_launch": tj["sq"]["SQ_INSTS_VALU"],
                                   "wait_frac_of_wave_cycles": tj["derived"]["wait_fraction_of_wave_cycles"],
                                   "source": TRAFFIC_FILE + " (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles; counts every VALU "
@@ -435,6 +496,8 @@ def main():
             metric = base_metric
         else:
             metric = f"sigma-point psi-evals/sec + NGD iters/sec, {chain['T'] - 1}-factor d={d0} p={p0} chain ({args.config})"
+        sets_desc = "; ".join(f"{K} x {KIND_NAMES.get(int(sp['kind']), sp['kind'])} d={d} p={p} (N={N})"
+                              for (K, d, p, N), sp in zip(ctx.sets, local["specs"])) if world == 1 else None
         out = {
             "metric": metric,
             "value": (evals_full + evals_cost) / elapsed, "unit": "psi-evals/s",
@@ -444,14 +507,14 @@ def main():
             **({"rehearsal": "all ranks on cuda:0, gloo exchange: not a measurement"} if rehearsal else {}),
             **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {}),
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {chain['T'] - 1}-factor prior chain, d={d0}, sparse-GH p={p0} (N={N0}), "
-                                   f"T={chain['T']} n={chain['n']}, +{chain['T']} unary d={chain['n']} factors; one step = one device-resident NGD iteration "
-                                   f"(state re-initialised inside the timed region every {args.restart_every} steps)",
+            "config": {"workload": f"{args.config}: T={chain['T']} states of size n={chain['n']}; factor sets: {sets_desc}; one step = one "
+                                   f"device-resident NGD iteration (state re-initialised inside the timed region every {args.restart_every} steps)",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
                        "sharding": (f"factors/{world} contiguous; per pass: all-gather of each rank's state records of [g|D|U] "
                                     f"({ctx.dist_info()['records_per_rank']} states per rank, folded in rank order) with the partial cost sum as one "
                                     f"more record (one all-gather per iteration), issued inside the library ({'gloo callback (rehearsal)' if rehearsal else transport})") if sharded else "none",
                        "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"],
+                       "fused_pass": bool(fused_launch),
                        "mirror_pairs": bool(geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"),
                        "fuse_trial": args.fuse_trial},
             "ngd_iters_per_s": args.steps / elapsed,
@@ -463,41 +526,47 @@ def main():
             "trials_per_step": float(np.mean([r["ntrials"] for r in log])),
             "final_cost": log[-1]["new_cost"],
             "reference_pass_order": ab,
-            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": evals_launch / km,
-                               "launch": "prior set + unary set in one launch" if fused_pair else "prior set"},
-            # The dominant kernel streams only the (d,p) table, which is L2-resident (HBM traffic ~0.5 % of the
-            # algorithmic bytes), so the binding roof is the fp64 FMA pipe, not HBM.  The contract's compute label is
-            # "mfma"; the kernel issues NO MFMA instruction: fp64 MFMA and fp64 VALU share one pipe on MI355X and
-            # v_fma_f64 is the faster form (profiles/r01_fp64_pipes.txt), hence "pipe".
-            "roofline": {"bound": "mfma", "pipe": "valu_f64 (v_fma_f64 / v_add_f64; zero MFMA instructions)",
+            # event-timed stages of one iteration (gvi_profile_stages, 16 iterations outside the timed region): "chain" = trial
+            # factorisation || gradient solve (kernels_chain.hpp, three launches), "factors" = the factor pass, "assemble"
+            "iteration_breakdown_us": stages,
+            "chain_us": stages["chain"]["mean_us"] if stages else None,
+            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": evals_launch / km, "launch": launch_desc},
+            # The dominant kernel streams only the quadrature table, which is L2-resident (HBM traffic ~0.5 % of the algorithmic
+            # bytes), so the binding roof is the fp64 VALU pipe, not HBM; it issues NO MFMA instruction (fp64 MFMA and fp64 VALU
+            # share one pipe on MI355X and deliver the same rate: profiles/r02_fp64_pipes.txt), so the label says what runs.
+            "roofline": {"bound": "valu_fp64 (the contract's compute label would be 'mfma'; zero MFMA instructions are issued)",
                          "achieved": exec_flop / km / 1e12, "peak": FP64_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": exec_flop / km / FP64_PEAK,
                          "traffic": traffic, "traffic_source": traffic_source, "valu_issue": valu_issue,
                          "kernel": kernel_name, "kernel_ms": km * 1e3, "evals_per_launch": evals_launch,
-                         "executed_fp64_ops_per_eval": {f"d={d},m={m}": ops_of(d, m, sg) for K, d, m, N, sg in sets_in_launch},
-                         "note": "achieved/frac = EXECUTED fp64 VALU instructions of the bracketed launch (every set in it), each "
-                                 "counted as one FMA (2 flop), / HIP-event time / 78.6 TF",
-                         "algorithmic": {"flop_per_eval": alg_flops(d0, m0), "tflops": alg_flop / km / 1e12,
+                         "executed_fp64_ops_per_eval": ops_table,
+                         "note": executed_note or ("achieved/frac = EXECUTED fp64 VALU instructions of the bracketed launch (every set in it), each "
+                                                   "counted as one FMA (2 flop), / HIP-event time / 78.6 TF"
+                                                   + ("; the bracket covers the whole fused pass (products, walk, chunk sums, tail, back-transform), "
+                                                      "only the walk's instructions are counted" if fused_launch else "")),
+                         "algorithmic": {"flop_per_eval": alg_flops(d0, m0) if chain_pattern else None, "tflops": alg_flop / km / 1e12,
                                          "frac_of_peak": alg_flop / km / FP64_PEAK,
                                          "note": "SURVEY 8(d) count of the reference's x-space algorithm (expand GEMM + psi + three "
                                                  "moment passes); exceeds the executed figure because the z-space reformulation "
                                                  "removes the expand -- a statement about the algorithm, not about the pipe"},
-                         "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. "
-                                        "Measured on this pool (tools/ubench/fp64_pipes.hip): 70 TF v_fma_f64, 48 TF v_mfma_f64_16x16x4",
+                         "peak_source": "AMD MI355X spec sheet: 78.6 TF fp64 (vector = matrix); not in the local guide. Measured on this pool "
+                                        "(tools/ubench/fp64_pipes.hip, profiles/r02_fp64_pipes.txt): 66.5 TF v_fma_f64, 67 TF v_mfma_f64_16x16x4 "
+                                        "(one pipe: 62 TF interleaved)",
                          "hbm_algorithmic": {"bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / km / 1e9,
                                              "peak_GBps": HBM_PEAK / 1e9, "frac": alg_bytes / km / HBM_PEAK,
                                              "note": "BASELINE's '>= 60 % of HBM roofline' figure: (d+1)*8 B per eval over 8 TB/s; "
-                                                     "exceeds 1 because the table is served from L2"}},
+                                                     "exceeds 1 where the table is served from L2"}},
         }
         if world > 1:
-            # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU kernel times of this round
-            # (profiles/): factor work W shards, the chain recursions R are replicated, two exchanges X are added.
-            W, R, X = 0.048, 0.092, 0.030                     # ms, DESIGN section 5 (profiles/r02_f_kernel_stats.csv)
+            # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU stage times of round 3
+            # (profiles/r03_*): the factor pass W shards, the chain operations + assemble R are replicated, the exchange X is added.
+            W, R, X = 0.046, 0.062, 0.030                     # ms; round-3 constants (profiles/r03_a_kernel_stats.csv), not measured in this run
             out["strong_scaling_model"] = {"W_ms_sharded": W, "R_ms_replicated": R, "X_ms_exchange": X,
                                            "expected_speedup_at_n": (W + R) / (W / world + R + X),
+                                           "constants": "round-3 one-GPU kernel times (profiles/r03_a_kernel_stats.csv); not re-measured here",
                                            "note": "t(N) = W / N + R + X; the ceiling as N grows is (W + R) / (R + X)"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds, dom if not chain_pattern else 0)
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_pg:

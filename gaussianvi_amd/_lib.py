@@ -86,6 +86,7 @@ SIGNATURES = {
     "gvi_profile_enable": [C.c_void_p, C.c_int],
     "gvi_profile_last": [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
     "gvi_profile_geometry": [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "gvi_profile_stages": [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "gvi_set_variant": [C.c_void_p, C.c_int],
     "gvi_set_option": [C.c_void_p, C.c_char_p, C.c_int],
 }

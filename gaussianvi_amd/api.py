@@ -348,6 +348,12 @@ class Context:
         self._ck(self.lib.gvi_profile_last(self.h, sid, what, C.byref(ms)))
         return ms.value
 
+    def profile_stages(self, on, read=True):
+        """Switch the stage timing on / off; with read: {stage: (mean us, brackets)} of the records since the last call."""
+        us, cnt = (C.c_float * 3)(), (C.c_int * 3)()
+        self._ck(self.lib.gvi_profile_stages(self.h, int(on), us if read else None, cnt if read else None))
+        return {name: (us[i], cnt[i]) for i, name in enumerate(("chain", "factors", "assemble"))} if read else None
+
     def profile_geometry(self, sid):
         v, nch, ch = C.c_int(), C.c_int(), C.c_int64()
         self._ck(self.lib.gvi_profile_geometry(self.h, sid, C.byref(v), C.byref(nch), C.byref(ch)))

@@ -255,6 +255,12 @@ struct gvi_ctx {
   // process may hold contexts on several devices)
   std::set<const void*> lds_attr_done;
   double seq = 0.0;
+  // stage timing (gvi_profile_stages): event pairs around the chain launches / the factor pass / the assemble of the
+  // resident iteration.  A pair costs ~14 us of queue gaps, so it is switched on for a few iterations OUTSIDE any timed region.
+  bool stage_prof = false;
+  struct StageRec { int stage; hipEvent_t e0, e1; };
+  std::vector<StageRec> stage_recs;
+  std::vector<hipEvent_t> stage_pool;
   int spin_ms = 2;                    // wall-time bound of the host spin on the publish word (GVI_SPIN_MS)
   double* host_slot_dev = nullptr;
 };
@@ -287,6 +293,28 @@ gvi_status allow_lds(gvi_ctx* c, const void* func, int bytes) {
   c->lds_attr_done.insert(func);
   return GVI_OK;
 }
+
+// stage timing: StageScope brackets the launches queued during its lifetime with an event pair (no-op unless switched on)
+enum { STAGE_CHAIN = 0, STAGE_FACTORS = 1, STAGE_ASSEMBLE = 2, STAGE_COUNT = 3 };
+struct StageScope {
+  gvi_ctx* c;
+  int idx = -1;
+  StageScope(gvi_ctx* ctx, int stage) : c(ctx) {
+    if (!c->stage_prof || c->stage_recs.size() >= 512) return;
+    auto get = [&]() {
+      hipEvent_t e = nullptr;
+      if (!c->stage_pool.empty()) { e = c->stage_pool.back(); c->stage_pool.pop_back(); }
+      else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+      return e;
+    };
+    gvi_ctx::StageRec r{stage, get(), get()};
+    if (!r.e0 || !r.e1) return;
+    (void)hipEventRecord(r.e0, c->stream);
+    c->stage_recs.push_back(r);
+    idx = (int)c->stage_recs.size() - 1;
+  }
+  ~StageScope() { if (idx >= 0) (void)hipEventRecord(c->stage_recs[idx].e1, c->stream); }
+};
 
 size_t bt_count(const gvi_ctx* c) { return (size_t)(2 * c->T - 1) * c->n * c->n; }   // [D | U]
 size_t nn_(const gvi_ctx* c) { return (size_t)c->n * c->n; }
@@ -645,10 +673,34 @@ void launch_orbit_pair(const OrbitArgs& a0, const OrbitArgs& a1, int m, int smax
 }
 
 // the full pass of the resident iteration as one launch (kernels_fused.hpp)
-template <int M, int SMAX, int WAVES, int EPLP>
-gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t lds, hipEvent_t e0, hipEvent_t e1) {
-  if (lds > 64 * 1024) GVICK(allow_lds(c, (const void*)factor_fused_kernel<M, SMAX, WAVES, EPLP>, (int)lds));
-  hipExtLaunchKernelGGL((factor_fused_kernel<M, SMAX, WAVES, EPLP>), dim3(grid), dim3(256), (uint32_t)lds, c->stream, e0, e1, 0, A);
+template <int M, int SMAX, int WAVES, int D0, int D1>
+gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t lds, int dmax, int copies, int items, hipEvent_t e0, hipEvent_t e1) {
+  if (lds > 64 * 1024) GVICK(allow_lds(c, (const void*)factor_fused_kernel<M, SMAX, WAVES, D0, D1>, (int)lds));
+#ifdef GVI_FUSED_TIMING
+  const int dbg = getenv("GVI_FUSED_DBG") ? atoi(getenv("GVI_FUSED_DBG")) : 0;
+  static unsigned long long* stamps = nullptr;
+  static int nprint = 0;
+  if ((dbg & 8) && !stamps) { if (hipMalloc(&stamps, 256 * 8) != hipSuccess) stamps = nullptr; }
+#else
+  const int dbg = 0;
+  unsigned long long* stamps = nullptr;
+#endif
+  hipExtLaunchKernelGGL((factor_fused_kernel<M, SMAX, WAVES, D0, D1>), dim3(grid), dim3(256), (uint32_t)lds, c->stream, e0, e1, 0, A, dmax, copies, items,
+                        (dbg & 8) ? stamps : (unsigned long long*)nullptr);
+#ifdef GVI_FUSED_TIMING
+  if ((dbg & 8) && stamps && ++nprint > 200 && nprint <= 202) {          // a few warm launches, 100 MHz ticks
+    unsigned long long h[256];
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (int blk = 0; blk < 8; ++blk) if (h[blk * 32] && h[blk * 32] < t0) t0 = h[blk * 32];
+    for (int blk = 0; blk < 8; ++blk) {
+      fprintf(stderr, "[fused stamps] block %4d wave 0 (absolute, us after the first start):", blk * 146);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %.2f", (double)(long long)(h[blk * 32 + i] - t0) * 0.01);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return GVI_OK;
 }
 
@@ -844,6 +896,7 @@ ChainArgs make_chain_args(gvi_ctx* c, const ChainWs& w, const double* D, const d
 
 gvi_status run_chain(gvi_ctx* c, const ChainArgs& a0, const ChainArgs& a1, bool on0, bool on1) {
   hipStream_t st = c->chain_stream ? c->chain_stream : c->stream;
+  StageScope scope(c, STAGE_CHAIN);
   const hipError_t e = chain_launch(c->n, chain_plan(c->T, c->n), a0, a1, on0, on1, st);
   if (e == hipErrorInvalidValue) return fail(c, GVI_ERR_UNSUPPORTED, "chain kernels: block size / LDS budget");
   HIPCK(c, e);
@@ -957,6 +1010,8 @@ gvi_status gvi_ctx_destroy(gvi_ctx* ctx) {
   ctx->sets.clear();
   if (ctx->dist.comm && ctx->dist.ncclCommDestroy) (void)ctx->dist.ncclCommDestroy(ctx->dist.comm);
   if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+  for (auto& r : ctx->stage_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto& e : ctx->stage_pool) (void)hipEventDestroy(e);
   if (ctx->side) (void)hipStreamSynchronize(ctx->side);
   if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
   for (auto& e : ctx->ev_solve) if (e) (void)hipEventDestroy(e);
@@ -2035,6 +2090,15 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
 }
 
 // ---- the full pass as ONE launch (kernels_fused.hpp) ----
+// Blocks that own items: one per factor of the first (heavy) set; a longer second set wraps around (block b also takes its
+// items b + nblk, ...).  0: more than FUSED_MAX_ITEMS items per block would be needed.
+static int fused_nblk(const gvi_ctx* ctx) {
+  const int K0 = ctx->sets[0]->K, K1 = ctx->sets.size() > 1 ? ctx->sets[1]->K : 0;
+  const int nblk = K0;
+  const int per = 1 + (K1 + nblk - 1) / nblk;
+  return per <= FUSED_MAX_ITEMS ? nblk : 0;
+}
+
 static bool fused_ok(const gvi_ctx* ctx, int slot) {
   if (!ctx->fused || !ctx->pair_fuse || ctx->profile_all || ctx->sets.empty() || ctx->sets.size() > 2) return false;
   const int m = ctx->sets[0]->m;
@@ -2044,7 +2108,12 @@ static bool fused_ok(const gvi_ctx* ctx, int slot) {
     if (s.prep_slot == slot) return false;          // products already resident: the plain route skips the prep
     if (s.table->orb.tile_s.empty()) return false;
   }
-  return true;
+  // instantiated shapes: the chain patterns of BASELINE configs[1..3] (binary prior d = 2n + unary factor d = n), Cholesky route
+  const int d0 = ctx->sets[0]->d, d1 = ctx->sets.size() > 1 ? ctx->sets[1]->d : d0 / 2;
+  if (!((m == 6 && d0 == 12 && d1 == 6) || (m == 2 && d0 == 4 && d1 == 2))) return false;
+  for (auto& sp : ctx->sets)
+    if (!sp->dev().chol) return false;
+  return fused_nblk(ctx) > 0;
 }
 
 static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
@@ -2052,9 +2121,9 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
   FusedArgs A{};
   A.nsets = (int)ctx->sets.size();
   A.koff[0] = 0;
-  int smax = 0, dmax = 0;
-  size_t lds = 0;
+  int smax = 0, dmax = 0, copies = 1;
   const int m = ctx->sets[0]->m;
+  A.nblk = fused_nblk(ctx);
   for (int si = 0; si < A.nsets; ++si) {
     FactorSet& s = *ctx->sets[si];
     FusedSet& F = A.s[si];
@@ -2077,8 +2146,12 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
     A.cl.cost[si] = s.cost.d(); A.cl.K[si] = s.K;
     smax = std::max(smax, s.table->orb.smax);
     dmax = std::max(dmax, s.d);
-    lds = std::max(lds, fused_lds_doubles(s.d, m, F.oa.copies) * 8);
+    copies = std::max(copies, F.oa.copies);
   }
+  // (the walk regions are sized for the widest set with the most accumulator copies: an upper bound for every set)
+  const int items = 1 + (A.nsets > 1 ? (ctx->sets[1]->K + A.nblk - 1) / A.nblk : 0);      // most items of a block
+  const size_t lds = fused_lds_doubles(dmax, m, copies, items) * 8;
+  if (lds > 160 * 1024) return fail(ctx, GVI_ERR_UNSUPPORTED, "fused pass: LDS budget");
   A.cl.nsets = A.nsets;
   if (A.nsets == 1) A.koff[2] = A.koff[1];
   unsigned extra = 0;
@@ -2117,13 +2190,12 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
     for (int e = 0; e < 2; ++e)
       if (!s0.ev[0][e]) HIPCK(ctx, hipEventCreate(&s0.ev[0][e]));
   hipEvent_t e0 = prof ? s0.ev[0][0] : nullptr, e1 = prof ? s0.ev[0][1] : nullptr;
-  const unsigned grid = (unsigned)A.koff[A.nsets] + extra;
-  if (dmax > 32) return fail(ctx, GVI_ERR_UNSUPPORTED, "factor dimension > 32");
-  if (m == 2) GVICK((launch_fused_t<2, 4, 4, 1>(ctx, A, grid, lds, e0, e1)));
-  else if (m == 6 && smax <= 4) GVICK((launch_fused_t<6, 4, 4, 4>(ctx, A, grid, lds, e0, e1)));
-  else if (m == 6) GVICK((launch_fused_t<6, 6, 2, 4>(ctx, A, grid, lds, e0, e1)));
-  else if (smax <= 4) GVICK((launch_fused_t<12, 4, 3, 16>(ctx, A, grid, lds, e0, e1)));
-  else GVICK((launch_fused_t<12, 6, 2, 16>(ctx, A, grid, lds, e0, e1)));
+  const unsigned grid = (unsigned)A.nblk + extra;
+  const int d0 = ctx->sets[0]->d, d1 = A.nsets > 1 ? ctx->sets[1]->d : d0 / 2;
+  if (m == 6 && smax <= 4 && d0 == 12 && d1 == 6) GVICK((launch_fused_t<6, 4, 4, 12, 6>(ctx, A, grid, lds, dmax, copies, items, e0, e1)));
+  else if (m == 6 && d0 == 12 && d1 == 6) GVICK((launch_fused_t<6, 6, 2, 12, 6>(ctx, A, grid, lds, dmax, copies, items, e0, e1)));
+  else if (m == 2 && d0 == 4 && d1 == 2) GVICK((launch_fused_t<2, 4, 4, 4, 2>(ctx, A, grid, lds, dmax, copies, items, e0, e1)));
+  else return fail(ctx, GVI_ERR_UNSUPPORTED, "fused pass: shape not instantiated");
   HIPCK(ctx, hipGetLastError());
   if (prof) s0.ev_set[0] = true;
   return GVI_OK;
@@ -2133,6 +2205,7 @@ static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot, int publish_slot = -1
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
   for (auto& s : ctx->sets)
     if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
+  StageScope scope(ctx, STAGE_FACTORS);
   if (fused_ok(ctx, slot)) return ngd_fused_full(ctx, slot, publish_slot);
   GVICK(ngd_prep_all(ctx, slot));
   GVICK(ngd_moments_launch(ctx, slot, 1));
@@ -2147,6 +2220,7 @@ static gvi_status ngd_scatter(gvi_ctx* ctx, int slot, int gb) {
   double* eD = eg + T * n;
   double* eU = eD + T * nn;
   const int64_t total = (int64_t)T * (n + 2 * nn);
+  StageScope scope(ctx, STAGE_ASSEMBLE);
   double* rec = nullptr;                                     // sharded: the assemble writes this rank's exchange records too
   int rlo = 0, rlen = 0;
   if (dist_on(ctx)) {
@@ -2925,6 +2999,28 @@ gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what, float* ms) {
   if (!s->ev_set[what]) return fail(ctx, GVI_ERR_STATE, "no profiled launch recorded");
   HIPCK(ctx, hipEventSynchronize(s->ev[what][1]));
   HIPCK(ctx, hipEventElapsedTime(ms, s->ev[what][0], s->ev[what][1]));
+  return GVI_OK;
+}
+
+gvi_status gvi_profile_stages(gvi_ctx* ctx, int on, float* mean_us, int* counts) {
+  if (!ctx) return GVI_ERR_ARG;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  if (mean_us || counts) {
+    GVICK(sync(ctx));
+    double sum[STAGE_COUNT] = {0, 0, 0};
+    int cnt[STAGE_COUNT] = {0, 0, 0};
+    for (auto& r : ctx->stage_recs) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { sum[r.stage] += ms; ++cnt[r.stage]; }
+    }
+    for (int i = 0; i < STAGE_COUNT; ++i) {
+      if (mean_us) mean_us[i] = cnt[i] ? (float)(1e3 * sum[i] / cnt[i]) : 0.f;
+      if (counts) counts[i] = cnt[i];
+    }
+  }
+  for (auto& r : ctx->stage_recs) { ctx->stage_pool.push_back(r.e0); ctx->stage_pool.push_back(r.e1); }
+  ctx->stage_recs.clear();
+  ctx->stage_prof = on != 0;
   return GVI_OK;
 }
 

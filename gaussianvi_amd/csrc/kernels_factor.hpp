@@ -116,7 +116,7 @@ template <int EPLP, int DT>   // EPLP: elements of the d x d block per lane: 1 (
 // kin: index of the factor inside the (mu, Sigma) INPUT arrays (== k, or 0 when the caller staged this factor's
 // marginal in LDS); outputs always go to slot k
 __device__ inline void prep_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
-  const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x;
+  const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x & 63;      // one wave per factor (the fused kernel runs several per block)
   const int dp = d + (d & 1);
   double* A0 = sm;
   double* A1 = A0 + dd;
@@ -323,10 +323,11 @@ __device__ __forceinline__ double chol_readlane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// Zs (LDS, optional): a copy of S^-T for an epilogue in the same launch (factor_fused_kernel)
 template <int DT>
-__device__ inline void prep_chol_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
+__device__ inline void prep_chol_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin, double* Zs = nullptr) {
   constexpr int d = DT, dd = DT * DT;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;      // one wave per factor (the fused kernel runs several per block)
   double* Ll = sm;            // [d][d] L, zeros above the diagonal
   double* Xl = Ll + dd;       // [d][d] X = L^-1
   const double* Sg = Sigma + (size_t)kin * dd;
@@ -371,6 +372,7 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     f.S[(size_t)k * dd + e] = Ll[e];
     f.Sinv[(size_t)k * dd + e] = Xl[j * d + i];                                      // S^-T = X^T
     f.Lam[(size_t)k * dd + e] = lam;
+    if (Zs) Zs[e] = Xl[j * d + i];
   }
   if (f.m > 0) {
     const int m = f.m;
@@ -396,15 +398,20 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
 }
 
 // the chain shapes of BASELINE.json get unrolled instances
+// true when prep_body_d takes the Cholesky route for this set (and can leave [S^-T | Sigma^-1] in LDS)
+__device__ __forceinline__ bool prep_is_chol(const FactorDev& f) {
+  return f.chol && (f.d == 2 || f.d == 4 || f.d == 6 || f.d == 8 || f.d == 12);
+}
+
 template <int EPLP>
-__device__ inline void prep_body_d(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
+__device__ inline void prep_body_d(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin, double* Zs = nullptr) {
   if (f.chol) {
     switch (f.d) {
-      case 2: prep_chol_body<2>(f, mu, Sigma, k, sm, kin); return;
-      case 4: prep_chol_body<4>(f, mu, Sigma, k, sm, kin); return;
-      case 6: prep_chol_body<6>(f, mu, Sigma, k, sm, kin); return;
-      case 8: prep_chol_body<8>(f, mu, Sigma, k, sm, kin); return;
-      case 12: prep_chol_body<12>(f, mu, Sigma, k, sm, kin); return;
+      case 2: prep_chol_body<2>(f, mu, Sigma, k, sm, kin, Zs); return;
+      case 4: prep_chol_body<4>(f, mu, Sigma, k, sm, kin, Zs); return;
+      case 6: prep_chol_body<6>(f, mu, Sigma, k, sm, kin, Zs); return;
+      case 8: prep_chol_body<8>(f, mu, Sigma, k, sm, kin, Zs); return;
+      case 12: prep_chol_body<12>(f, mu, Sigma, k, sm, kin, Zs); return;
     }
   }
   if (EPLP == 1 && f.d == 2) prep_body<EPLP, 2>(f, mu, Sigma, k, sm, kin);
@@ -1732,19 +1739,21 @@ __host__ __device__ inline size_t epilogue_lds_doubles(int d) { return (size_t)n
 // what is ~2 us of arithmetic).  Summation orders are unchanged (c ascending, chunk index ascending).
 // phase 0: everything; 1: chunk sums, E[psi] and cost only (Ms stays in LDS); 2: the back-transform after a phase-1 call
 // P: the factor's chunk partials ([nchunk][npo]): a.partial + k nchunk npo, or LDS (factor_fused_kernel)
+// Zs: S^-T of this factor already in LDS (factor_fused_kernel, Cholesky route; Sigma^-1 = S^-T S^-1 is then re-formed
+// here by the prep's own sequence of operations: bit-identical) or null (both fetched here)
 template <int DT>
-__device__ __forceinline__ double epilogue_body_t(const EpiArgs& a, int k, double* sm, int phase, const double* P) {
+__device__ __forceinline__ double epilogue_body_t(const EpiArgs& a, int k, double* sm, int phase, const double* P, double* Zs = nullptr) {
   const FactorDev& f = a.f;
-  const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x;
+  const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x & 63;      // one wave per factor (the fused kernel runs several per block)
   const int npo = a.full ? npairs(d) : 1;
   double* Ms = sm;              // [npo]
   double* M2 = Ms + npairs(d);  // [d][d]
   double* Tm = M2 + dd;         // [d][d]
-  double* Sv = Tm + dd;         // [d][d] Sinv
-  double* Lv = Sv + dd;         // [d][d] Lam
+  double* Sv = Zs ? Zs : Tm + dd;           // [d][d] Sinv
+  double* Lv = Tm + 2 * dd;                 // [d][d] Lam (unused when Zs)
   const double Tk = f.temperature[k];                     // issued with the other loads, used after the chunk sums
   const bool want_v = a.full && (a.Vdmu || a.Vddmu);
-  if (want_v && phase != 2) {
+  if (want_v && phase != 2 && !Zs) {
     const double* Sinv = f.Sinv + (size_t)k * dd;
     const double* Lam = f.Lam + (size_t)k * dd;
     for (int e = lane; e < dd; e += 64) { Sv[e] = Sinv[e]; Lv[e] = Lam[e]; }
@@ -1796,7 +1805,13 @@ __device__ __forceinline__ double epilogue_body_t(const EpiArgs& a, int k, doubl
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < d; ++c) s += Tm[i * d + c] * Sv[j * d + c];     // (W M2) W^T, W = S^-T (symmetric root: W = Sinv)
-        const double v = (s - Lv[i * d + j] * m0) / Tk;
+        double lam;
+        if (Zs) {
+          lam = 0.0;
+#pragma unroll
+          for (int c = 0; c < d; ++c) lam = fma(Sv[i * d + c], Sv[j * d + c], lam);   // prep_chol_body: Sigma^-1 = X^T X
+        } else lam = Lv[i * d + j];
+        const double v = (s - lam * m0) / Tk;
         a.Vddmu[(size_t)k * dd + i * d + j] = v;
         a.Vddmu[(size_t)k * dd + j * d + i] = v;
       }
@@ -1837,14 +1852,14 @@ __device__ __forceinline__ double epilogue_body_t(const EpiArgs& a, int k, doubl
 }
 
 // the chain shapes of BASELINE.json get unrolled instances; everything else runs the runtime-d body
-__device__ __forceinline__ double epilogue_body_p(const EpiArgs& a, int k, double* sm, int phase, const double* P) {
+__device__ __forceinline__ double epilogue_body_p(const EpiArgs& a, int k, double* sm, int phase, const double* P, double* Zs = nullptr) {
   switch (a.f.d) {
-    case 2: return epilogue_body_t<2>(a, k, sm, phase, P);
-    case 4: return epilogue_body_t<4>(a, k, sm, phase, P);
-    case 6: return epilogue_body_t<6>(a, k, sm, phase, P);
-    case 8: return epilogue_body_t<8>(a, k, sm, phase, P);
-    case 12: return epilogue_body_t<12>(a, k, sm, phase, P);
-    default: return epilogue_body_t<0>(a, k, sm, phase, P);
+    case 2: return epilogue_body_t<2>(a, k, sm, phase, P, Zs);
+    case 4: return epilogue_body_t<4>(a, k, sm, phase, P, Zs);
+    case 6: return epilogue_body_t<6>(a, k, sm, phase, P, Zs);
+    case 8: return epilogue_body_t<8>(a, k, sm, phase, P, Zs);
+    case 12: return epilogue_body_t<12>(a, k, sm, phase, P, Zs);
+    default: return epilogue_body_t<0>(a, k, sm, phase, P, Zs);
   }
 }
 __device__ inline double epilogue_body(const EpiArgs& a, int k, double* sm, int phase = 0) {
@@ -1951,15 +1966,15 @@ struct CostList {
 };
 
 // Tail protocol, executed by ONE wave of every block (lane = its lane index) after the block's factor cost `costk` is known:
-// store it, count the block in; the block that arrives last sums the costs of all sets and publishes.  `sh`: 256 doubles of
-// LDS, `last`: one LDS int, both private to the calling wave's block.
+// store it, count the block in; the one that arrives last sums the costs of all sets and publishes.  `last`: one LDS int
+// private to the calling wave.
 // Cross-block hand-over WITHOUT device-scope fences: on this multi-XCD part a release fence writes the XCD's whole L2
 // back (the epilogue has just dirtied megabytes: 2049 blocks x __threadfence() cost ~45 us, measured).  Only the
 // factor's cost has to be seen by the last block, so it is stored write-through at agent scope, the wave waits for
 // that one store (vmcnt), and the arrival counters are relaxed agent-scope atomics.  Everything else the epilogue
 // wrote is consumed by later launches (ordinary end-of-kernel release).
 __device__ __forceinline__ void epi_tail_arrive(const CostList& cl, const EpiTail& tail, double* cost_slot, const double costk, const int lane,
-                                                const unsigned bid, const unsigned nblocks, double* sh, int* last) {
+                                                const unsigned bid, const unsigned nblocks, int* last) {
   if (lane == 0) {
     __hip_atomic_store(cost_slot, costk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1992,6 +2007,7 @@ __device__ __forceinline__ void epi_tail_arrive(const CostList& cl, const EpiTai
         const int k = lane + 64 * j + q * 256;
         p[j][q] = k < K ? __hip_atomic_load(cost + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       }
+    double vs[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                       // virtual thread v = lane + 64 j of the 256-thread kernel
       double s = 0.0;
@@ -2007,19 +2023,14 @@ __device__ __forceinline__ void epi_tail_arrive(const CostList& cl, const EpiTai
 #pragma unroll
         for (int q = 0; q < 8; ++q) s += pp[q];
       }
-      sh[lane + 64 * j] = s;
+      vs[j] = s;
     }
-    wave_lds_sync();
-    sh[lane] += sh[lane + 128]; sh[lane + 64] += sh[lane + 192];     // w = 128
-    wave_lds_sync();
-    sh[lane] += sh[lane + 64];                                        // w = 64
-    wave_lds_sync();
-    for (int w = 32; w > 0; w >>= 1) {
-      if (lane < w) sh[lane] += sh[lane + w];
-      wave_lds_sync();
-    }
-    total += sh[0];
-    wave_lds_sync();
+    // the 256-leaf tree sh[v] += sh[v + w], w = 128 ... 1, with the leaves in registers: the first two levels pair the
+    // virtual threads of one lane, the rest are lane shuffles -- the same association as the LDS tree it replaces
+    double t = (vs[0] + vs[2]) + (vs[1] + vs[3]);       // w = 128: v += v + 128 ; w = 64: v += v + 64
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) t += __shfl_down(t, w);
+    total += __shfl(t, 0);
   }
   if (lane == 0) {
     __hip_atomic_store(tail.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
@@ -2048,8 +2059,7 @@ __global__ __launch_bounds__(64) void epilogue_all_kernel(EpiList L, EpiTail tai
   // instead of ~10 us after them.
   const double costk = epilogue_body(L.e[si], kf, sm, 1);
   __shared__ int last;
-  double* sh = sm + epilogue_lds_doubles(L.e[si].f.d);  // [256] behind this factor's epilogue area (phase 2 still needs it)
-  epi_tail_arrive(cl, tail, L.e[si].cost + kf, costk, (int)threadIdx.x, blockIdx.x, gridDim.x, sh, &last);
+  epi_tail_arrive(cl, tail, L.e[si].cost + kf, costk, (int)threadIdx.x, blockIdx.x, gridDim.x, &last);
   epilogue_body(L.e[si], kf, sm, 2);
 }
 

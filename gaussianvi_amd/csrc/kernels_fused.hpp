@@ -1,22 +1,30 @@
 // factor_fused_kernel: gather -> per-pass products -> sign-orbit psi walk -> chunk sum -> cost (+ publish tail) ->
-// back-transform of ONE factor in ONE workgroup -- the full moments pass of the resident NGD iteration in a single launch.
+// back-transform, the full moments pass of the resident NGD iteration in a single launch.
 //
 // Replaces, for the sum-of-squares factor sets of a chain, the three launches prep_all_kernel -> moments_orbit_pair_kernel ->
 // epilogue_all_kernel (kernels_factor.hpp / kernels_orbit.hpp; reference: GVIFactorizedBase::update_*_from_joint,
 // gvibase/GVIFactorizedBase.h:104-122; updateGH + calculate_partial_V, ngd/NGDFactorizedBaseGH.h:50-88).  The device
 // functions are the SAME ones those kernels call (prep_body_d, orbit_wave, epilogue_body_p, epi_tail_arrive): results are
-// bit-identical to the three-launch route with four chunks per factor.  What changes:
-//   * block = the 4 chunks of one factor (wave w walks chunk w) instead of 4 factors x 1 chunk: the chunk partials meet in
-//     LDS and are summed there in chunk order -- no partial[K][nchunk][91] round trip through HBM (3.1 of the 4.2 MB the psi
-//     launch moved at C3, profiles/r02_traffic.json);
-//   * wave 0 forms the factor's products (Cholesky route: ~2 us of dependent work) while the other waves of the CU's
-//     resident blocks walk; no kernel boundary between prep, walk and epilogue (two launches and their ramps fewer);
-//   * the per-pass products still go to f.S / f.Sinv / f.Lam / f.H / f.u0 as before (a cost-only pass at the same state
-//     reuses them), the back-transform reads them back through the CU's L1 / L2.
+// bit-identical to the three-launch route with four chunks per factor.
+//
+// Block b owns a few ITEMS (factors): item b of every set, plus the items b + nblk, b + 2 nblk, ... where a set is longer
+// than the grid (the chain pattern: prior b and unary factor b; block 0 also takes the 1025th unary factor) -- at most 4.
+//   phase 1   wave i forms the per-pass products of item i (gather of (mu_k, Sigma_k) from the chain, Cholesky route: ~3 us
+//             of dependent work per item, the items side by side) and leaves S^-T in LDS for phase 3;
+//   phase 2   all four waves walk the orbit table for one item after the other, wave w = chunk w; the chunk partials stay
+//             in LDS (no partial[K][nchunk][91] round trip through HBM: 3.1 of the 4.2 MB the psi launch moved at C3,
+//             profiles/r02_traffic.json);
+//   phase 3   wave i: ordered chunk sum, cost, tail protocol (arrival count, the last one publishes), back-transform of
+//             item i from LDS operands.
+// The light set rides in the shadow of the heavy one (as in moments_orbit_pair_kernel's stacked form), the latency-bound
+// phases 1 and 3 are paid once per block instead of once per launch with its ramp, and two kernel boundaries are gone.
+// The per-pass products still go to f.S / f.Sinv / f.Lam / f.H / f.u0 (a cost-only pass at the same state reuses them).
 #pragma once
 #include "kernels_orbit.hpp"
 
 namespace gvi {
+
+constexpr int FUSED_MAX_ITEMS = 4;
 
 struct FusedSet {
   FactorDev f;
@@ -34,10 +42,11 @@ struct FusedSet {
 
 struct FusedArgs {
   int nsets;
-  int koff[3];
+  int nblk;                      // blocks that own items; the ones behind write the chain-level trial mean
+  int koff[3];                   // arrival ids of the tail: item k of set s is koff[s] + k
   FusedSet s[2];
   // fused gather (see PrepList): factor marginals pulled out of the chain arrays, the trial mean gmu + gstep gdmu formed on
-  // the fly; blocks past koff[nsets] write the chain-level trial mean
+  // the fly
   int gather, n;
   const double* gmu;
   const double* gdmu;
@@ -50,42 +59,69 @@ struct FusedArgs {
   CostList cl;
 };
 
-// dynamic LDS (doubles) of a block: the four waves' walk regions (aliased by wave 0's prep area before and its epilogue
-// area after), then the four chunk partials
-__host__ __device__ inline size_t fused_lds_doubles(int d, int M, int copies) {
+// LDS of one item's phase-1 / phase-3 work (doubles): prep area (+ gather staging) or epilogue area.  Item i works in the
+// walk region of wave i (dead outside phase 2).
+__host__ __device__ inline size_t fused_item_doubles(int d) {
   const size_t dd = (size_t)d * d, dp = d + (d & 1);
   const size_t prep = 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1 + dd + d + 2;
-  const size_t epi = epilogue_lds_doubles(d) + 256;
-  size_t w = (size_t)4 * orbit_lds_doubles(d, M, copies);
-  if (prep > w) w = prep;
-  if (epi > w) w = epi;
-  w = (w + 1) & ~(size_t)1;
-  return w + (size_t)4 * npairs(d);
+  const size_t epi = epilogue_lds_doubles(d) + 2;
+  return ((prep > epi ? prep : epi) + 1) & ~(size_t)1;
+}
+// per-wave region: the walk's H + accumulator copies, or the item area if that is larger
+__host__ __device__ inline size_t fused_region_doubles(int dmax, int M, int copies) {
+  const size_t a = (size_t)orbit_lds_doubles(dmax, M, copies), b = fused_item_doubles(dmax);
+  return ((a > b ? a : b) + 1) & ~(size_t)1;
+}
+// layout: [4 regions] [Z: items x dmax^2 (S^-T of every item)] [P: items x 4 x npairs(dmax) (chunk partials)]
+__host__ __device__ inline size_t fused_lds_doubles(int dmax, int M, int copies, int items) {
+  return 4 * fused_region_doubles(dmax, M, copies) + (size_t)items * ((size_t)dmax * dmax + 4 * (size_t)npairs(dmax));
 }
 
-template <int M, int SMAX, int WAVES, int EPLP>
-__global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A) {
+// D0 / D1: the factor dimensions of set 0 / set 1 at compile time (both sets on the Cholesky route): only the bodies of
+// these two shapes are compiled in -- with the runtime-d dispatch of prep_body_d / epilogue_body_p every shape's body was
+// inlined into one 230 KB kernel, whose phase 1 then ran at the speed of its instruction fetches (30 us instead of 4)
+template <int M, int SMAX, int WAVES, int D0, int D1>
+__global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, int dmax, int copies_max, int maxitems, [[maybe_unused]] unsigned long long* stamps) {
   extern __shared__ double sm[];
+  // -DGVI_FUSED_TIMING + GVI_FUSED_DBG=8: 100 MHz stamps of wave 0 of every 146th block at the phase boundaries
+#ifdef GVI_FUSED_TIMING
+#define FUSED_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0 && (blockIdx.x % 146) == 0) stamps[(blockIdx.x / 146) * 32 + (threadIdx.x >> 6) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FUSED_STAMP(i) do { } while (0)
+#endif
+  FUSED_STAMP(0);
   if (pred_skip(A.tail.pred, A.tail.pred_val)) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nfac = A.koff[A.nsets];
-  if ((int)blockIdx.x >= nfac) {                              // chain-level trial mean (gather mode only)
-    const int64_t j = (int64_t)((int)blockIdx.x - nfac) * 256 + threadIdx.x;
+  const int b = (int)blockIdx.x;
+  if (b >= A.nblk) {                                          // chain-level trial mean (gather mode only)
+    const int64_t j = (int64_t)(b - A.nblk) * 256 + threadIdx.x;
     if (j < A.nmu) A.mu_out[j] = A.gmu[j] + A.gstep * A.gdmu[j];
     return;
   }
-  const int si = (A.nsets > 1 && (int)blockIdx.x >= A.koff[1]) ? 1 : 0;
-  const FusedSet& S = A.s[si];
-  const FactorDev& f = S.f;
-  const int k = (int)blockIdx.x - A.koff[si];
-  const int d = f.d, dd = d * d;
-  // ---- phase 1 (wave 0): the factor's marginal and its per-pass products ----
-  if (wave == 0) {
-    const int lane = threadIdx.x;
-    if (!A.gather) prep_body_d<EPLP>(f, S.mu, S.Sigma, k, sm, k);
-    else {
+  // items of this block: set 0's b, b + nblk, ...; then set 1's
+  const int K0 = A.s[0].f.K, K1 = A.nsets > 1 ? A.s[1].f.K : 0;
+  const int c0 = K0 > b ? (K0 - b + A.nblk - 1) / A.nblk : 0;
+  const int c1 = K1 > b ? (K1 - b + A.nblk - 1) / A.nblk : 0;
+  const int nitems = c0 + c1;                                  // <= FUSED_MAX_ITEMS (host)
+  const size_t region = fused_region_doubles(dmax, M, copies_max);
+  double* Zbase = sm + 4 * region;                             // [items][dmax^2]
+  const size_t zs = (size_t)dmax * dmax, ps = (size_t)4 * npairs(dmax);
+  double* Pbase = Zbase + (size_t)maxitems * zs;               // [items][4][npairs(dmax)]
+  // ---- phase 1: wave i forms the products of item i ----
+  if (wave < nitems) {
+    const int si = wave < c0 ? 0 : 1;
+    const int k = b + (wave < c0 ? wave : wave - c0) * A.nblk;
+    const FusedSet& S = A.s[si];
+    const FactorDev& f = S.f;
+    const int d = f.d, dd = d * d, lane = threadIdx.x & 63;
+    double* area = sm + (size_t)wave * region;
+    double* Zs = Zbase + (size_t)wave * zs;
+    if (!A.gather) {
+      if (si == 0) prep_chol_body<D0>(f, S.mu, S.Sigma, k, area, k, Zs);
+      else prep_chol_body<D1>(f, S.mu, S.Sigma, k, area, k, Zs);
+    } else {
       const int dp = d + (d & 1), n = A.n, nn = n * n;
-      double* Sl = sm + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;   // behind prep_body's own LDS
+      double* Sl = area + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;   // behind prep_body's own LDS
       double* ml = Sl + dd;
       const int s = S.start[k];
       for (int e = lane; e < dd; e += 64) {
@@ -105,34 +141,46 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A) {
         S.mu_k[(size_t)k * d + e] = v;
       }
       wave_lds_sync();
-      prep_body_d<EPLP>(f, ml, Sl, k, sm, 0);
+      if (si == 0) prep_chol_body<D0>(f, ml, Sl, k, area, 0, Zs);
+      else prep_chol_body<D1>(f, ml, Sl, k, area, 0, Zs);
     }
   }
-  __syncthreads();                                             // H / u0 of this factor are visible to the block
-  // ---- phase 2 (every wave): its chunk of the orbit table ----
-  const int NP = npairs(d);
-  const int ldsw = orbit_lds_doubles(d, M, S.oa.copies);
-  size_t walk = (size_t)4 * ldsw;
-  {
-    const size_t dp = d + (d & 1);
-    const size_t prep = 4 * (size_t)dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1 + dd + d + 2, epi = epilogue_lds_doubles(d) + 256;
-    if (prep > walk) walk = prep;
-    if (epi > walk) walk = epi;
-    walk = (walk + 1) & ~(size_t)1;
+  FUSED_STAMP(1);
+  __syncthreads();                                             // H / u0 of the items are visible to the block
+  FUSED_STAMP(2);
+  // ---- phase 2: every wave walks its chunk of the orbit table, item after item ----
+  for (int it = 0; it < nitems; ++it) {
+    const int si = it < c0 ? 0 : 1;
+    const int k = b + (it < c0 ? it : it - c0) * A.nblk;
+    const FusedSet& S = A.s[si];
+    orbit_wave<M, SMAX, true, false, true>(S.oa, k, wave, sm + (size_t)wave * region, Pbase + (size_t)it * ps + (size_t)wave * npairs(S.f.d));
   }
-  double* Pl = sm + walk;                                      // [4][NP] chunk partials
-  orbit_wave<M, SMAX, true, false, true>(S.oa, k, wave, sm + (size_t)wave * ldsw, Pl + (size_t)wave * NP);
+  FUSED_STAMP(3);
   __syncthreads();
-  if (wave != 0) return;
-  // ---- phase 3 (wave 0): ordered chunk sum, cost (+ tail), back-transform ----
-  EpiArgs e;
-  e.f = f; e.partial = nullptr; e.nchunk = 4; e.full = 1;
-  e.Ephi = S.Ephi; e.cost = S.cost; e.Vdmu = S.Vdmu; e.Vddmu = S.Vddmu; e.E_xmuphi = nullptr; e.E_xxphi = nullptr;
-  if (!A.tail.on) { epilogue_body_p(e, k, sm, 0, Pl); return; }
-  const double costk = epilogue_body_p(e, k, sm, 1, Pl);
-  __shared__ int last;
-  epi_tail_arrive(A.cl, A.tail, S.cost + k, costk, (int)threadIdx.x, blockIdx.x, (unsigned)nfac, sm + epilogue_lds_doubles(d), &last);
-  epilogue_body_p(e, k, sm, 2, Pl);
+  FUSED_STAMP(4);
+  if (wave >= nitems) return;
+  // ---- phase 3: wave i: ordered chunk sum, cost (+ tail), back-transform of item i ----
+  {
+    const int si = wave < c0 ? 0 : 1;
+    const int k = b + (wave < c0 ? wave : wave - c0) * A.nblk;
+    const FusedSet& S = A.s[si];
+    const int d = S.f.d;
+    double* area = sm + (size_t)wave * region;
+    double* Zs = Zbase + (size_t)wave * zs;
+    const double* Pl = Pbase + (size_t)wave * ps;
+    EpiArgs e;
+    e.f = S.f; e.partial = nullptr; e.nchunk = 4; e.full = 1;
+    e.Ephi = S.Ephi; e.cost = S.cost; e.Vdmu = S.Vdmu; e.Vddmu = S.Vddmu; e.E_xmuphi = nullptr; e.E_xxphi = nullptr;
+    auto epi = [&](int phase) { return si == 0 ? epilogue_body_t<D0>(e, k, area, phase, Pl, Zs) : epilogue_body_t<D1>(e, k, area, phase, Pl, Zs); };
+    if (!A.tail.on) { epi(0); return; }
+    const double costk = epi(1);
+    FUSED_STAMP(5);
+    int* last = (int*)(area + epilogue_lds_doubles(d));
+    epi_tail_arrive(A.cl, A.tail, S.cost + k, costk, (int)(threadIdx.x & 63), (unsigned)(A.koff[si] + k), (unsigned)A.koff[A.nsets], last);
+    FUSED_STAMP(6);
+    epi(2);
+    FUSED_STAMP(7);
+  }
 }
 
 }  // namespace gvi

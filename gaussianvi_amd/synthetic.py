@@ -138,7 +138,18 @@ def make_literal_chain(name: str):
 def make_chain(name: str):
     """Returns dict(T, n, specs, mu0, D0, U0).  specs[0]: the T-1 binary prior factors (d = 2n,
     QUAD_PRIOR); specs[1]: T unary measurement factors (d = n, FIXED_PRIOR), the first and the last
-    being the strong end anchors."""
+    being the strong end anchors.  "planar1k" / "planar": the planning graph with hinge-on-SDF obstacle factors
+    (make_planar_chain); "arm7x": the 7-DOF arm graph (make_obstacle_chain) at T = 129."""
+    if name == "planar1k":          # bench.py --config planar1k: 1025 states, 1025 obstacle factors d = 4 at p = 7 (2145 points)
+        ch = make_planar_chain(T=1025, p=3, p_obstacle=7)
+        ch["name"] = name
+        return ch
+    if name == "planar":
+        return make_planar_chain()
+    if name == "arm7x":
+        ch = make_obstacle_chain("arm7", T=129)
+        ch["name"] = name
+        return ch
     if name not in CONFIGS and name.startswith("c3x") and name[3:].isdigit():
         CONFIGS[name] = (3, 1024 * int(name[3:]) + 1, 6, 5, "ltv")      # weak-scaling family: 1024 factors per GPU
     if CONFIGS[name][4] == "ltvlit":
@@ -196,13 +207,14 @@ def circle_sdf(origin, cell, rows, cols, centers, radii):
     return f
 
 
-def make_planar_chain(T=17, p=3, seed=0x5EED + 40, jitter=0.02):
+def make_planar_chain(T=17, p=3, seed=0x5EED + 40, jitter=0.02, p_obstacle=None, horizon=None):
     """Planar point-robot planning graph of the reference's own GPU workload: states
     [x, y, vx, vy] (n = 4), T-1 minimum-acceleration priors (d = 8), T hinge-on-SDF obstacle factors on
-    every state (d = 4, helpers/CudaOperation.h:491-523) and two fixed-prior end anchors."""
+    every state (d = 4, helpers/CudaOperation.h:491-523) and two fixed-prior end anchors.  p_obstacle: GH degree of the
+    obstacle factors (default p + 1); horizon: total time (default (T - 1) / 4, i.e. dt = 0.25)."""
     rng = np.random.default_rng(seed)
     n, nd, K = 4, 2, T - 1
-    dt = 0.25
+    dt = 0.25 if horizon is None else horizon / (T - 1)
     Phi1, Qinv1 = _minacc(nd, QC, dt)
     Phi, Qinv = np.stack([Phi1] * K), np.stack([Qinv1] * K)
     start_xy, goal_xy = np.array([-3.0, -0.4]), np.array([3.0, 0.4])
@@ -225,7 +237,7 @@ def make_planar_chain(T=17, p=3, seed=0x5EED + 40, jitter=0.02):
     specs = [
         dict(kind=PSI_QUAD_PRIOR, d=2 * n, p=p, start=np.arange(K, dtype=np.int32),
              params=np.concatenate([Phi.reshape(K, -1), Qinv.reshape(K, -1)], axis=1), temperature=np.ones(K), Phi=Phi, Qinv=Qinv),
-        dict(kind=PSI_HINGE_SDF_2D, d=n, p=p + 1, start=np.arange(T, dtype=np.int32),
+        dict(kind=PSI_HINGE_SDF_2D, d=n, p=p + 1 if p_obstacle is None else p_obstacle, start=np.arange(T, dtype=np.int32),
              params=np.tile(np.array([[15.5, 0.5, 0.3]]), (T, 1)), temperature=np.ones(T),
              sdf_origin=origin, sdf_cell=cell, sdf_field=field),
         dict(kind=PSI_FIXED_PRIOR, d=n, p=p, start=np.array([0, T - 1], dtype=np.int32),

@@ -301,6 +301,11 @@ gvi_status gvi_ngd_get_gradients(gvi_ctx* ctx, double* dmu, double* dD, double* 
  *      dominant launch is bracketed (sampling keeps the measurement out of the measured iteration time). ---- */
 gvi_status gvi_profile_enable(gvi_ctx* ctx, int on);
 gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kernel, 1 cost kernel*/, float* ms);
+/* Stage timing of the resident iteration: while on, the launches of the three stages -- 0 the chain operations (trial
+ * factorisation || gradient solve), 1 the factor pass (products, psi, epilogue), 2 the assemble -- are bracketed by event
+ * pairs.  mean_us / counts (each [3], optional): mean device time per bracket and the number of brackets since the last
+ * call; the records are then cleared and the mode set to `on`.  A pair costs ~14 us of queue gaps: keep it out of timed runs. */
+gvi_status gvi_profile_stages(gvi_ctx* ctx, int on, float* mean_us, int* counts);
 /* Launch geometry of the set's last moments/cost launch: variant (0 closed form, 1 generic, 2 register, 3 split = four waves per factor, d = 16/20/24,
  * 5 register kernel fused with the chain's other set in one launch, 6 sign-orbit kernel), chunks. */
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk);

@@ -10,6 +10,7 @@
  *                                                                             ngd/NGDFactorizedBaseGH.h:46-48
  *   calculate_partial_V: Vdmu = Lam E1 / T, Vddmu = sym_upper(Lam E2 Lam - Lam E0) / T   ngd/NGDFactorizedBaseGH.h:53-74
  *   OpenMP over factors                                                       ngd/NGD-GH-impl.h:31-44
+ * psi kinds: the 1-D range factor, the two quadratic priors and the planar hinge-on-SDF obstacle cost.
  * `fused = 1` is the best-effort CPU variant (one pass, psi once per point, upper triangle only).
  * Pinned against oracle/gvi_oracle.py (itself pinned by K1-K9) in tests/test_oracle_c.py.
  */
@@ -20,12 +21,39 @@
 #include <omp.h>
 #endif
 
-enum { PSI_RANGE_1D = 0, PSI_QUAD_PRIOR = 1, PSI_FIXED_PRIOR = 2 };
+enum { PSI_RANGE_1D = 0, PSI_QUAD_PRIOR = 1, PSI_FIXED_PRIOR = 2, PSI_HINGE_SDF_2D = 4 };
 
 typedef struct { int kind, d, n; const double* p; } psi_closure;
 
+/* signed-distance grid of the hinge kinds (set once by gvi_oracle_set_sdf2d; read-only afterwards): field[r + c rows] */
+static struct { const double* field; int rows, cols; double ox, oy, cell; } g_sdf;
+
+/* PlanarSDF::convertPoint2toCell + signed_distance (helpers/CudaOperation.h:61-103): clamp the query to the grid, bilinear
+ * interpolation of the column-major field (data_array_[r + c rows], :130); the upper index is clamped where its weight is 0 */
+static double sdf2d_lookup(double px, double py) {
+  const double xmax = g_sdf.ox + (g_sdf.cols - 1.0) * g_sdf.cell, ymax = g_sdf.oy + (g_sdf.rows - 1.0) * g_sdf.cell;
+  const double xin = px < g_sdf.ox ? g_sdf.ox : (px > xmax ? xmax : px);
+  const double yin = py < g_sdf.oy ? g_sdf.oy : (py > ymax ? ymax : py);
+  const double col = (xin - g_sdf.ox) / g_sdf.cell, row = (yin - g_sdf.oy) / g_sdf.cell;
+  const double lr = floor(row), lc = floor(col), hr = lr + 1.0, hc = lc + 1.0;
+  const int lri = (int)lr, lci = (int)lc, R = g_sdf.rows;
+  const int hri = lri + 1 < g_sdf.rows ? lri + 1 : g_sdf.rows - 1;
+  const int hci = lci + 1 < g_sdf.cols ? lci + 1 : g_sdf.cols - 1;
+  const double* f = g_sdf.field;
+  return (hr - row) * (hc - col) * f[lri + lci * R] + (row - lr) * (hc - col) * f[hri + lci * R] +
+         (hr - row) * (col - lc) * f[lri + hci * R] + (row - lr) * (col - lc) * f[hri + hci * R];
+}
+
 /* src/1d_example.cpp:25-35; gp/minimum_acc_prior.h:103-106 / gp/LTV_prior.h:223-226; gp/fixed_prior.h:28-30 */
 static double psi_eval(const double* x, const psi_closure* c) {
+  if (c->kind == PSI_HINGE_SDF_2D) {
+    /* cost_obstacle_planar of the planar point robot (helpers/CudaOperation.h:491-508): one ball, slope 1;
+       p = (sigma, eps, r): sigma * max(0, eps + r - sdf(x0, x1))^2 */
+    const double* p = c->p;
+    const double sd = sdf2d_lookup(x[0], x[1]), thr = p[1] + p[2];
+    const double err = sd > thr ? 0.0 : thr - sd;
+    return err * err * p[0];
+  }
   if (c->kind == PSI_RANGE_1D) {
     const double* p = c->p; /* y, mu_p, fb, sig_r_sq, sig_p_sq */
     double e = x[0] - p[1], r = p[0] - p[2] / x[0];
@@ -199,6 +227,12 @@ int gvi_oracle_moments(int K, int d, int n, long N, const double* Z, const doubl
     }
     free(X); free(buf);
   }
+  return 0;
+}
+
+/* field: [rows x cols] column-major (r + c rows), kept by reference */
+int gvi_oracle_set_sdf2d(const double* field, int rows, int cols, double ox, double oy, double cell) {
+  g_sdf.field = field; g_sdf.rows = rows; g_sdf.cols = cols; g_sdf.ox = ox; g_sdf.oy = oy; g_sdf.cell = cell;
   return 0;
 }
 

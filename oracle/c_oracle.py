@@ -17,7 +17,21 @@ def lib():
         _lib.gvi_oracle_moments.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long] + [C.c_void_p] * 4 + \
             [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
         _lib.gvi_oracle_max_threads.restype = C.c_int
+        _lib.gvi_oracle_set_sdf2d.restype = C.c_int
+        _lib.gvi_oracle_set_sdf2d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     return _lib
+
+
+_sdf_keep = None
+
+
+def set_sdf2d(origin, cell, field):
+    """Grid of the HINGE_SDF_2D kind (kind 4): field[r, c] at origin + (c, r) cell, handed over column-major as the
+    reference stores it (helpers/CudaOperation.h:130)."""
+    global _sdf_keep
+    f = np.asfortranarray(np.asarray(field, dtype=np.float64))
+    _sdf_keep = f                                       # the library keeps the pointer
+    lib().gvi_oracle_set_sdf2d(f.ctypes.data_as(C.c_void_p), f.shape[0], f.shape[1], float(origin[0]), float(origin[1]), float(cell))
 
 
 def max_threads():

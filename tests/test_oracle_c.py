@@ -44,3 +44,25 @@ def test_c_oracle_fixed_and_range():
     E, Vd, Vdd = c_oracle.moments(Z, w, np.array([[20.0]]), np.array([[[9.0]]]), syn.PSI_RANGE_1D,
                                   np.array([[1.2, 20.0, 40.0, 0.09, 9.0]]), 1)
     assert np.isclose(E[0], r["E_phi"][0], rtol=1e-13) and np.isclose(Vdd[0, 0, 0], r["Vddmu"][0, 0, 0], rtol=1e-11)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_c_oracle_hinge_sdf2d(fused):
+    """The planar hinge-on-SDF port (bench.py's cpu_baseline for --config planar1k) against the numpy oracle: marginals
+    near and inside the obstacles, so the hinge is active on part of the sigma points."""
+    ch = syn.make_planar_chain(T=9, p=3)
+    spec = ch["specs"][1]
+    K, d = len(spec["start"]), spec["d"]
+    rng = np.random.default_rng(7)
+    mu = ch["mu0"][spec["start"]] + 0.3 * rng.normal(size=(K, d))
+    mu[:3, :2] = [[0.0, 0.9], [-1.0, -1.6], [0.4, 1.2]]              # at the discs' rims
+    _, Sigma = syn.random_marginals(rng, K, d, 0.2)
+    Z, w = o.nwspgr(d, spec["p"])
+    r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_hinge_sdf2d(spec["params"], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"]),
+                          np.ones(K))
+    c_oracle.set_sdf2d(spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
+    E, Vd, Vdd = c_oracle.moments(Z, w, mu, Sigma, syn.PSI_HINGE_SDF_2D, spec["params"], ch["n"], fused=fused, nthreads=2)
+    assert np.abs(r["E_phi"]).max() > 1e-3                            # the hinge is active
+    assert np.allclose(E, r["E_phi"], rtol=1e-11, atol=1e-13)
+    assert np.allclose(Vd, r["Vdmu"], rtol=1e-9, atol=1e-11 * np.abs(r["Vdmu"]).max())
+    assert np.allclose(Vdd, r["Vddmu"], rtol=1e-8, atol=1e-10 * np.abs(r["Vddmu"]).max())
