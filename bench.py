@@ -201,14 +201,19 @@ def main():
                     help="strong (default, BASELINE configs[3]): the same chain over N GPUs (128 factors per GPU at N = 8: bounded "
                          "by the replicated chain recursions and the exchange); weak: 1024 factors PER GPU, i.e. a (1024 N)-factor "
                          "chain (config c3xN) -- the metric string then names c3xN")
+    ap.add_argument("--no-c5-strong", action="store_true",
+                    help="N > 1: skip the additional sharded run of BASELINE configs[4] (block `c5_strong` of the JSON line; ~80 s of set-up)")
     ap.add_argument("--fuse-trial", type=int, default=2, choices=[0, 1, 2],
                     help="gvi_ngd_set_mode: 0 the reference's pass order (gradient pass + one cost pass per trial), 1 fused, "
                          "2 adaptive (library default)")
-    ap.add_argument("--restart-every", type=int, default=30,
+    ap.add_argument("--restart-every", type=int, default=None,
                     help="re-initialise (mu0, precision0) inside the timed region every R steps so that every step is a "
-                         "descending iteration with one accepted trial (the chain converges after ~35 steps)")
+                         "descending iteration with one accepted trial (the chain converges after ~35 steps; default 30, 6 for the "
+                         "obstacle graphs planar1k / arm7x)")
     args = ap.parse_args()
     big = args.config.startswith("c5") and args.config != "c5mini"
+    if args.restart_every is None:                     # the obstacle graphs converge within ~8 iterations, the quadratic chains in ~35
+        args.restart_every = 6 if args.config in ("planar1k", "planar", "arm7x") else 30
     if args.steps is None:
         args.steps = 3 if big else 200
     if args.warmup is None:
@@ -260,36 +265,40 @@ def main():
     # N > 1 (or a forced size-1 group): both exchange steps of a pass run INSIDE the library on its own stream
     # (include/gvi_hip.h, gvi_dist_init_*): RCCL all-gathers; the rehearsal on one GPU goes through a gloo callback
     sharded = use_pg and (world > 1 or os.environ.get("GVI_FORCE_ALLREDUCE") == "1")
-    transport = "none"
-    if sharded:
+
+    def init_transport(cx):
+        """Exchange transport of a sharded context.  The library's own RCCL communicator (dlopen of librccl); should loading
+        it or creating the unique id fail on ANY rank, every rank falls back to the callback transport over
+        torch.distributed's RCCL group -- the same all-gathers on the library's stream, one Python call each.  (The fallback
+        covers load / unique-id failures; ncclCommInitRank itself is collective: a rank stuck inside it is a hung job, which
+        the launcher's timeout ends -- no in-process retry.)"""
         if rehearsal:
-            ctx.dist_init_callback(rank, world, torch_allgather(local_rank))
-        else:
-            # the library's own RCCL communicator (dlopen of librccl); should that fail on ANY rank (library not found,
-            # communicator refused), every rank falls back to the callback transport over torch.distributed's RCCL group --
-            # the same all-gathers on the library's stream, one Python call each
-            ok = torch.ones(1, dtype=torch.float64, device="cuda")
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            cx.dist_init_callback(rank, world, torch_allgather(local_rank))
+            return "gloo callback (rehearsal)"
+        ok = torch.ones(1, dtype=torch.float64, device="cuda")
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        try:
+            my_id = api.dist_unique_id()           # every rank: also the probe that librccl loads here
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+        except Exception as e:
+            ok.zero_()
+            print(f"[bench rank {rank}] gvi_dist_unique_id failed: {e}", file=sys.stderr, flush=True)
+        dist.broadcast(uid, 0)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0.5:
             try:
-                my_id = api.dist_unique_id()           # every rank: also the probe that librccl loads here
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+                cx.dist_init_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
             except Exception as e:
                 ok.zero_()
-                print(f"[bench rank {rank}] gvi_dist_unique_id failed: {e}", file=sys.stderr, flush=True)
-            dist.broadcast(uid, 0)
+                print(f"[bench rank {rank}] gvi_dist_init_rccl failed: {e}", file=sys.stderr, flush=True)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok.item()) > 0.5:
-                try:
-                    ctx.dist_init_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
-                except Exception as e:
-                    ok.zero_()
-                    print(f"[bench rank {rank}] gvi_dist_init_rccl failed: {e}", file=sys.stderr, flush=True)
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            transport = "RCCL (library communicator)"
-            if float(ok.item()) < 0.5:
-                ctx.dist_init_callback(rank, world, torch_allgather(local_rank))
-                transport = "RCCL (torch.distributed group through the callback transport)"
+        if float(ok.item()) < 0.5:
+            cx.dist_init_callback(rank, world, torch_allgather(local_rank))
+            return "RCCL (torch.distributed group through the callback transport)"
+        return "RCCL (library communicator)"
+
+    transport = init_transport(ctx) if sharded else "none"
     ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
     # HIP events around every 8th dominant launch (a pair costs ~14 us of queue gaps); every launch for the seconds-long c5 passes
     ctx.profile_enable(1 if big else 3)
@@ -400,24 +409,69 @@ def main():
     chain_pattern = len(ctx.sets) <= 2 and all(spec["kind"] in (1, 2) for spec in local["specs"])
     stages = None
     if single and not big:
-        ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
-        for _ in range(4):
-            ctx.ngd_step(0.55, 10)
+        def descending_steps(nsteps):                   # same restart rule as the timed region: every step an accepted one
+            done = 0
+            while done < nsteps:
+                ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
+                for _ in range(min(nsteps - done, args.restart_every)):
+                    ctx.ngd_step(0.55, 10); done += 1
+        descending_steps(4)
         ctx.profile_stages(True, read=False)
-        for _ in range(16):
-            ctx.ngd_step(0.55, 10)
+        descending_steps(16)
         st = ctx.profile_stages(False)
         stages = {k: {"mean_us": round(float(v[0]), 2), "brackets": int(v[1])} for k, v in st.items()}
         if not chain_pattern:
             ctx.profile_enable(2)
             kern_ms = []
-            for _ in range(12):
-                ctx.ngd_step(0.55, 10)
-                try:
-                    kern_ms.append(ctx.profile_last(ids[dom], 0))
-                except api.GviError:
-                    pass
+            for _ in range(3):
+                ctx.ngd_init(chain["mu0"], chain["D0"], chain["U0"])
+                for _ in range(min(4, args.restart_every)):
+                    ctx.ngd_step(0.55, 10)
+                    try:
+                        kern_ms.append(ctx.profile_last(ids[dom], 0))
+                    except api.GviError:
+                        pass
             ctx.profile_enable(0)
+
+    # ---- N > 1: BASELINE configs[4] (4096 factors, d = 24, p = 7; fp64) sharded over the same ranks, two iterations:
+    # the workload whose factor pass (0.13 s on one GPU) dwarfs the replicated chain operations, i.e. where sharding has
+    # work to split (strong scaling).  GVI_BENCH_C5_CONFIG selects a smaller d = 24 chain for rehearsals.
+    c5_block = None
+    if world > 1 and not args.no_c5_strong:
+        cfg5 = os.environ.get("GVI_BENCH_C5_CONFIG", "c5")
+        t_build = time.perf_counter()
+        chain5 = synthetic.make_chain(cfg5)
+        local5 = shard_chain(chain5, rank, world)
+        ctx5, ids5 = api.context_for_chain(local5, device=local_rank)
+        ctx5.ngd_set_mode(True, 2)
+        tr5 = init_transport(ctx5)
+        ctx5.ngd_init(chain5["mu0"], chain5["D0"], chain5["U0"])
+        ctx5.ngd_step(0.55, 10)                              # warm-up (table upload, buffers)
+        ctx5.ngd_init(chain5["mu0"], chain5["D0"], chain5["U0"])
+        t_build = time.perf_counter() - t_build
+        barrier()
+        ctx5.ngd_counters(reset=True)
+        t5 = time.perf_counter()
+        log5 = [ctx5.ngd_step(0.55, 10) for _ in range(2)]
+        barrier()
+        t5 = time.perf_counter() - t5
+        f5, c5c = ctx5.ngd_counters()
+        ev5 = sum(K * N for (K, d, p, N) in ctx5.sets)
+        st5 = torch.tensor([t5, float((f5 + c5c) * ev5)], dtype=torch.float64, device="cuda")
+        mx5 = st5.clone()
+        dist.all_reduce(mx5, op=dist.ReduceOp.MAX)
+        dist.all_reduce(st5, op=dist.ReduceOp.SUM)
+        nfac = torch.zeros(world, dtype=torch.float64, device="cuda")
+        nfac[rank] = float(ctx5.sets[0][0])
+        dist.all_reduce(nfac, op=dist.ReduceOp.SUM)
+        c5_block = {"config": cfg5, "workload": f"T={chain5['T']} n={chain5['n']}: {chain5['T'] - 1} prior factors d={ctx5.sets[0][1]} p={ctx5.sets[0][2]} "
+                                                  f"(N={ctx5.sets[0][3]}) + {chain5['T']} unary d={ctx5.sets[1][1]} factors, fp64, factor list sharded over {world} ranks",
+                    "steps": 2, "ms_per_step": 1e3 * float(mx5[0]) / 2, "value": float(st5[1]) / float(mx5[0]), "unit": "psi-evals/s",
+                    "accepted_steps": int(sum(r["accepted"] for r in log5)), "final_cost": log5[-1]["new_cost"],
+                    "factors_per_rank": [int(v) for v in nfac.tolist()], "transport": tr5, "scaling": "strong",
+                    "setup_s_rank0": round(t_build, 1),
+                    "note": "BASELINE configs[4] in fp64 (fp32 refused: DESIGN section 4.4); one-GPU reference: bench.py --config c5"}
+        ctx5.close()
 
     if rank == 0:
         Kd, dd_, pd_, Nd = ctx.sets[dom]
@@ -558,6 +612,9 @@ def main():
                                                      "exceeds 1 where the table is served from L2"}},
         }
         if world > 1:
+            out["transport"] = transport
+            out.setdefault("rccl_ranks", None)                # (no RCCL group in a rehearsal)
+            out["c5_strong"] = c5_block
             # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU stage times of round 3
             # (profiles/r03_*): the factor pass W shards, the chain operations + assemble R are replicated, the exchange X is added.
             W, R, X = 0.046, 0.062, 0.030                     # ms; round-3 constants (profiles/r03_a_kernel_stats.csv), not measured in this run

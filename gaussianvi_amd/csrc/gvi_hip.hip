@@ -2855,7 +2855,10 @@ struct RcclApi {
   int (*CommDestroy)(void*) = nullptr;
 };
 bool load_rccl(RcclApi& r, std::string& err) {
-  const char* names[] = {getenv("GVI_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // GVI_RCCL_PATH, when set, names the ONLY candidate (an explicit choice is not second-guessed); else the usual names
+  const char* forced = getenv("GVI_RCCL_PATH");
+  const bool only = forced && *forced;
+  const char* names[] = {forced, only ? nullptr : "librccl.so.1", only ? nullptr : "librccl.so", only ? nullptr : "/opt/rocm/lib/librccl.so.1"};
   std::string why;                                   // dlerror() clears the message it returns: read it ONCE per failed dlopen
   for (const char* nm : names) {
     if (!nm || !*nm) continue;

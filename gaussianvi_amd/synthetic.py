@@ -143,12 +143,16 @@ def make_chain(name: str):
     if name == "planar1k":          # bench.py --config planar1k: 1025 states, 1025 obstacle factors d = 4 at p = 7 (2145 points)
         ch = make_planar_chain(T=1025, p=3, p_obstacle=7)
         ch["name"] = name
+        # obstacle factors at the reference's HIGH temperature (gvibase/GVI-GH-impl.h:104-117 switches to it when the line search
+        # is exhausted; its planar experiments start there): at T_k = 1 the hinge rejects every step after two iterations
+        ch["specs"][1]["temperature"] = np.full(len(ch["specs"][1]["start"]), 30.0)
         return ch
     if name == "planar":
         return make_planar_chain()
     if name == "arm7x":
         ch = make_obstacle_chain("arm7", T=129)
         ch["name"] = name
+        ch["specs"][1]["temperature"] = np.full(len(ch["specs"][1]["start"]), 30.0)
         return ch
     if name not in CONFIGS and name.startswith("c3x") and name[3:].isdigit():
         CONFIGS[name] = (3, 1024 * int(name[3:]) + 1, 6, 5, "ltv")      # weak-scaling family: 1024 factors per GPU

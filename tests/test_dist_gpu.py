@@ -97,7 +97,7 @@ def _worker_inlib(rank, world, port, name, iters, fuse, q):
 
 
 @pytest.mark.parametrize("fuse", [0, 2])
-@pytest.mark.parametrize("name,iters,world", [("c2", 4, 2), ("c3small", 3, 3), ("planar", 3, 4)])
+@pytest.mark.parametrize("name,iters,world", [("c2", 4, 2), ("c3small", 3, 3), ("planar", 3, 4), ("c5small", 2, 2)])
 def test_in_library_exchange_matches_single_process(name, iters, world, fuse):
     """exchange 0 as an all-gather of each rank's state records (+ the one state neighbours share),
     exchange 1 as an all-gather of the partial cost sums, both issued by the library itself.  2, 3 and 4 ranks (4 ranks on
@@ -171,7 +171,7 @@ def test_bench_two_rank_rehearsal_reproduces_the_single_gpu_cost():
     r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr[-2000:]
     one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
-    env = dict(os.environ, GVI_BENCH_REHEARSAL="1")
+    env = dict(os.environ, GVI_BENCH_REHEARSAL="1", GVI_BENCH_C5_CONFIG="c5small")
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                          "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
                         capture_output=True, text=True, timeout=900, env=env)
@@ -179,5 +179,11 @@ def test_bench_two_rank_rehearsal_reproduces_the_single_gpu_cost():
     two = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][-1])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["metric"] == one["metric"]
     assert "rehearsal" in two and "all-gather" in two["config"]["sharding"]
+    # what the first real N > 1 run will be read by: who took part, over which transport, the expected ceiling, and the
+    # sharded showcase block (rehearsed on the small d = 24 chain)
+    assert "rccl_ranks" in two and "transport" in two and "gloo" in two["transport"]
+    assert two["strong_scaling_model"]["expected_speedup_at_n"] > 0
+    assert two["c5_strong"]["config"] == "c5small" and two["c5_strong"]["accepted_steps"] == two["c5_strong"]["steps"] == 2
+    assert two["c5_strong"]["factors_per_rank"] == [16, 16]
     assert abs(two["final_cost"] - one["final_cost"]) < 1e-10 * abs(one["final_cost"])
     assert two["accepted_steps"] == one["accepted_steps"] == 12

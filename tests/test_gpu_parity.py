@@ -1369,3 +1369,49 @@ def test_c5_table_weights_rule_out_fp32():
     assert 1.0e7 < ratio < 3.0e7
     assert ratio * np.finfo(np.float32).eps > 0.5
     del Z, idx
+
+
+def test_c5_full_chain_two_iterations_closed_form_and_chain_round_trip():
+    """BASELINE configs[4] at FULL size on one GPU (fp64): two NGD iterations of the 4096-factor d = 24
+    p = 7 chain (T = 4097, n = 12; 20 557 057 sigma points per prior factor), then
+      * the cost strictly decreases and both first trials are accepted;
+      * 16 sampled prior factors of the (24,7) pass against the analytic closed form (<= 2e-7);
+      * the chain operations at T = 4097, n = 12 through size-independent identities: the solve's residual and
+        Lam Sigma = I on the block-tridiagonal pattern."""
+    ch = syn.make_chain("c5")
+    T, n = ch["T"], ch["n"]
+    ctx, ids = api.context_for_chain(ch)
+    ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+    r1 = ctx.ngd_step(0.55, 10)
+    r2 = ctx.ngd_step(0.55, 10)
+    assert r1["accepted"] and r2["accepted"] and r1["ntrials"] == 1 and r2["ntrials"] == 1
+    assert r1["new_cost"] < r1["cost_iter"] and r2["new_cost"] < r2["cost_iter"] and r2["cost_iter"] == r1["new_cost"]
+    st = ctx.ngd_get_state()
+    D, U, SD, SU, mu = st["D"], st["U"], st["SigD"], st["SigU"], st["mu"]
+    # ---- chain round trip: Lam Sig = I on the tridiagonal pattern (rows t: D_t S_tt + U_{t-1}^T S_{t-1,t} + U_t S_{t,t+1}^T) ----
+    I = np.eye(n)
+    worst = 0.0
+    for t in range(0, T, 97):
+        acc = D[t] @ SD[t]
+        if t > 0:
+            acc = acc + U[t - 1].T @ SU[t - 1]
+        if t < T - 1:
+            acc = acc + U[t] @ SU[t].T
+        worst = max(worst, np.abs(acc - I).max())
+    assert worst < 1e-9, worst
+    rng = np.random.default_rng(5)
+    rhs = rng.normal(size=(T, n))
+    x = ctx.bt_solve(D, U, rhs).reshape(T, n)
+    res = np.einsum("tij,tj->ti", D, x) - rhs
+    res[:-1] += np.einsum("tij,tj->ti", U, x[1:])
+    res[1:] += np.einsum("tji,tj->ti", U, x[:-1])
+    assert np.abs(res).max() < 1e-9 * max(1.0, np.abs(rhs).max() * np.abs(D).max()), np.abs(res).max()
+    # ---- the (24,7) pass of all 4096 factors at the current state; 16 of them against the closed form ----
+    spec = ch["specs"][0]
+    mk, Sk = ctx.gather_marginals(ids[0], mu, SD, SU)
+    Ephi, Vdmu, Vddmu = ctx.moments(ids[0], mk, Sk)
+    assert ctx.profile_geometry(ids[0])["variant"] == 6
+    pick = np.arange(0, len(spec["start"]), 256)
+    w = _closed_form_worst(spec["Phi"][pick], spec["Qinv"][pick], mk[pick], Sk[pick], Ephi[pick], Vdmu[pick], Vddmu[pick])
+    assert max(w.values()) < 2e-7, w
+    ctx.close()
