@@ -68,10 +68,11 @@ def build_examples(force: bool = False) -> str:
     out_dir = os.path.join(ROOT, "examples", "bin")
     os.makedirs(out_dir, exist_ok=True)
     first = None
-    for name in ("1d_example", "1d_example_prox", "planar_example", "factorwise_example"):
+    for name in ("1d_example", "1d_example_prox", "planar_example", "factorwise_example", "ltv_chain_example"):
         src = os.path.join(ROOT, "examples", name + ".cpp")
         exe = os.path.join(out_dir, name)
-        deps = [src, os.path.join(ROOT, "include", "gvi", "gvi_host.hpp"), os.path.join(ROOT, "include", "gvi_hip.h")]
+        deps = [src, os.path.join(ROOT, "include", "gvi", "gvi_host.hpp"), os.path.join(ROOT, "include", "gvi", "factorized_opts_LTV.hpp"),
+                os.path.join(ROOT, "include", "gvi_hip.h")]
         if force or _stale(exe, deps):
             cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src,
                    "-L", HERE, "-lgvi_hip", "-Wl,-rpath," + HERE, "-o", exe]

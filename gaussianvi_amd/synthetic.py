@@ -54,18 +54,27 @@ def _minacc(nd, qc, dt):
     return Phi, Qinv
 
 
-def _ltv(rng, nd, dt):
-    """Exact discretisation over 4 piece-wise-constant sub-intervals of a seeded stable second-order
-    system x'' = -Kp x - Kd x' + B2 u (state [x, x']): the maths of gp/LTV_prior.h:123-197."""
-    from scipy.linalg import expm
-    n = 2 * nd
-    Phi, Q = np.eye(n), np.zeros((n, n))
-    h = dt / 4
+def _ltv_system(rng, nd):
+    """Four (A, B) pairs -- one per piece-wise-constant sub-interval -- of a seeded stable second-order system
+    x'' = -Kp x - Kd x' + B2 u (state [x, x']): the hA / hB entries LTV_GP reads (gp/LTV_prior.h:57-61)."""
+    out = []
     for _ in range(4):
         Kp = np.diag(rng.uniform(0.5, 2.0, nd)) + 0.1 * rng.normal(size=(nd, nd))
         Kd = np.diag(rng.uniform(0.5, 1.5, nd)) + 0.1 * rng.normal(size=(nd, nd))
         A = np.block([[np.zeros((nd, nd)), np.eye(nd)], [-Kp, -Kd]])
         B = np.vstack([np.zeros((nd, nd)), B_SCALE * (np.eye(nd) + 0.1 * rng.normal(size=(nd, nd)))])
+        out.append((A, B))
+    return out
+
+
+def _ltv_from_system(system, dt):
+    """Exact discretisation over the 4 sub-intervals (product of matrix exponentials, Van Loan block form for the Gramian):
+    the maths of gp/LTV_prior.h:123-197."""
+    from scipy.linalg import expm
+    n = system[0][0].shape[0]
+    Phi, Q = np.eye(n), np.zeros((n, n))
+    h = dt / 4
+    for A, B in system:
         M = np.zeros((2 * n, 2 * n))
         M[:n, :n], M[:n, n:], M[n:, n:] = -A, B @ B.T, A.T
         E = expm(M * h)
@@ -74,6 +83,25 @@ def _ltv(rng, nd, dt):
         Phi = Ad @ Phi
         Q = Ad @ Q @ Ad.T + (Qd + Qd.T) / 2
     return Phi, np.linalg.inv(Q)
+
+
+def _ltv(rng, nd, dt):
+    """(Phi, Q^-1) of one seeded LTV prior factor."""
+    return _ltv_from_system(_ltv_system(rng, nd), dt)
+
+
+def ltv_chain_system(name: str):
+    """The (hA, hB) lists behind make_chain(name)'s LTV priors, in LTV_GP's layout: 4 (T - 1) + 1 matrices each, factor k
+    reading entries 4k .. 4k + 4 (the 5th is only touched at t = delta_t exactly; here the next factor's first)."""
+    cfg, T, n, p, kind = CONFIGS[name][:5]
+    assert kind == "ltv"
+    rng = np.random.default_rng(0x5EED + cfg)
+    hA, hB = [], []
+    for k in range(T - 1):
+        for A, B in _ltv_system(rng, n // 2):
+            hA.append(A); hB.append(B)
+    hA.append(hA[-1].copy()); hB.append(hB[-1].copy())
+    return np.stack(hA), np.stack(hB)
 
 
 def _ltv_literal(rng, n, dt):

@@ -465,6 +465,105 @@ class MinimumAccGP : public LinearFactor {
   VectorXd _m0, _target_mu;
 };
 
+// Linear time-varying GP prior between two consecutive states (gp/LTV_prior.h:42-95, 123-197, 223-249): over [0, delta_t] the
+// system x' = A(t) x + B(t) w with A, B piece-wise constant on FOUR sub-intervals (hA / hB hold 4 (n_states - 1) + 1 matrices,
+// factor `start_index` reads hA[4 start_index .. 4 start_index + 4]); Phi' = A Phi, Phi(0) = I and the Gramian
+// Q' = A Q + Q A^T + B B^T, Q(0) = 0 are integrated to tolerance 1e-12 -- the reference drives GSL's rkf45 (absent here); this
+// is an embedded Runge-Kutta-Fehlberg 4(5) with step-size control, restarted at the three interior breakpoints so that no
+// step straddles a jump of A / B.  Lambda = [-Phi, I], Psi = [Phi, -I], constant 1/2; cost() ignores the target mean exactly
+// as the reference's does (:223-226).
+class LTV_GP : public LinearFactor {
+ public:
+  LTV_GP() {}
+  LTV_GP(const MatrixXd& Qc, int start_index, const double& delta_t, const VectorXd& mu_0, int n_states,
+         const std::vector<MatrixXd>& hA, const std::vector<MatrixXd>& hB, const std::vector<VectorXd>& target_mean)
+      : _dim(Qc.cols()), _start_index(start_index), _dim_state(2 * Qc.cols()), _delta_t(delta_t), _Qc(Qc), _invQc(Qc.inverse()),
+        _m0(mu_0), _target_mu(VectorXd::Zero(4 * Qc.cols())) {
+    (void)n_states;
+    const int n = _dim_state;
+    if ((int)hA.size() < 4 * start_index + 5 || (int)hB.size() < 4 * start_index + 5)
+      throw GviError(GVI_ERR_ARG, "LTV_GP: hA / hB need 4 (n_states - 1) + 1 entries");
+    _A_vec.assign(hA.begin() + 4 * start_index, hA.begin() + 4 * start_index + 5);
+    _B_vec.assign(hB.begin() + 4 * start_index, hB.begin() + 4 * start_index + 5);
+    _Phi = integrate(false);
+    for (int i = 0; i < n; ++i) { _target_mu(i) = target_mean[start_index](i); _target_mu(n + i) = target_mean[start_index + 1](i); }
+    _Q = integrate(true);
+    compute_invQ();
+    _Lambda = MatrixXd::Zero(n, 2 * n);                 // [-Phi, I]
+    _Lambda.set_block(0, 0, -_Phi);
+    _Lambda.set_block(0, n, MatrixXd::Identity(n, n));
+    _Psi = MatrixXd::Zero(n, 2 * n);                    // [Phi, -I]
+    _Psi.set_block(0, 0, _Phi);
+    _Psi.set_block(0, n, -MatrixXd::Identity(n, n));
+  }
+  MatrixXd A_function(double t) const { return _A_vec[interval(t)]; }                             // :182-186
+  std::pair<MatrixXd, MatrixXd> system_param(double t) const { const int i = interval(t); return {_A_vec[i], _B_vec[i]}; }   // :188-192
+  inline MatrixXd Q() const { return _Q; }
+  inline MatrixXd Qc() const { return _Qc; }
+  inline MatrixXd Phi() const { return _Phi; }
+  inline double cost(const VectorXd& theta1, const VectorXd& theta2) const {   // :223-226
+    const VectorXd r = _Phi * theta1 - theta2;
+    const VectorXd q = _invQ * r;
+    double c = 0.0;
+    for (int i = 0; i < r.size(); ++i) c += r(i) * q(i);
+    return c / 2;
+  }
+  inline int dim_posvel() const { return 2 * _dim; }
+  inline void compute_invQ() { _invQ = _Q.inverse(); }                          // :230-233
+  VectorXd get_mu() const override { return _target_mu; }
+  MatrixXd get_precision() const override { return _invQ; }
+  MatrixXd get_covariance() const override { return _Q; }
+  MatrixXd get_Lambda() const override { return _Lambda; }
+  MatrixXd get_Psi() const override { return _Psi; }
+  double get_Constant() const override { return 0.5; }
+  DevicePsi device_psi() const override { return DevicePsi::QuadPrior(_Phi, _invQ); }
+
+ private:
+  int interval(double t) const { const int i = (int)std::floor(4 * t / _delta_t); return i < 0 ? 0 : (i > 4 ? 4 : i); }
+  // right-hand side on sub-interval i: gramian ? A Y + Y A^T + B B^T : A Y
+  MatrixXd rhs(int i, const MatrixXd& Y, bool gramian, const MatrixXd& BBt) const {
+    MatrixXd d = _A_vec[i] * Y;
+    if (gramian) d = d + Y * _A_vec[i].transpose() + BBt;
+    return d;
+  }
+  static double norm_inf(const MatrixXd& M) {
+    double m = 0.0;
+    for (int i = 0; i < M.rows(); ++i) for (int j = 0; j < M.cols(); ++j) m = std::max(m, std::fabs(M(i, j)));
+    return m;
+  }
+  // Runge-Kutta-Fehlberg 4(5) (the tableau of gsl_odeiv2_step_rkf45), error per step <= 1e-12 (1 + |Y|), 5th-order solution kept
+  MatrixXd integrate(bool gramian) const {
+    const int n = _dim_state;
+    MatrixXd Y = gramian ? MatrixXd::Zero(n, n) : MatrixXd::Identity(n, n);
+    const double tol = 1e-12, h4 = _delta_t / 4;
+    for (int i = 0; i < 4; ++i) {
+      const MatrixXd BBt = gramian ? _B_vec[i] * _B_vec[i].transpose() : MatrixXd::Zero(n, n);
+      double t = 0.0, h = h4 / 4;
+      while (t < h4) {
+        if (t + h > h4) h = h4 - t;
+        const MatrixXd k1 = rhs(i, Y, gramian, BBt);
+        const MatrixXd k2 = rhs(i, Y + k1 * (h / 4), gramian, BBt);
+        const MatrixXd k3 = rhs(i, Y + k1 * (3 * h / 32) + k2 * (9 * h / 32), gramian, BBt);
+        const MatrixXd k4 = rhs(i, Y + k1 * (1932 * h / 2197) - k2 * (7200 * h / 2197) + k3 * (7296 * h / 2197), gramian, BBt);
+        const MatrixXd k5 = rhs(i, Y + k1 * (439 * h / 216) - k2 * (8 * h) + k3 * (3680 * h / 513) - k4 * (845 * h / 4104), gramian, BBt);
+        const MatrixXd k6 = rhs(i, Y - k1 * (8 * h / 27) + k2 * (2 * h) - k3 * (3544 * h / 2565) + k4 * (1859 * h / 4104) - k5 * (11 * h / 40), gramian, BBt);
+        const MatrixXd y5 = Y + (k1 * (16.0 / 135) + k3 * (6656.0 / 12825) + k4 * (28561.0 / 56430) - k5 * (9.0 / 50) + k6 * (2.0 / 55)) * h;
+        const MatrixXd err = (k1 * (1.0 / 360) - k3 * (128.0 / 4275) - k4 * (2197.0 / 75240) + k5 * (1.0 / 50) + k6 * (2.0 / 55)) * h;
+        const double e = norm_inf(err), bound = tol * (1.0 + norm_inf(Y));
+        if (e <= bound || h <= 1e-14 * h4) { Y = y5; t += h; }
+        const double fac = e > 0.0 ? 0.9 * std::pow(bound / e, 0.2) : 4.0;
+        h *= std::min(4.0, std::max(0.2, fac));
+      }
+    }
+    return Y;
+  }
+  int _dim = 0, _start_index = 0, _dim_state = 0;
+  double _delta_t = 0;
+  MatrixXd _Qc, _invQc, _Q, _invQ, _Phi, _Lambda, _Psi;
+  std::vector<MatrixXd> _A_vec, _B_vec;
+  VectorXd _m0, _target_mu;
+};
+
 // Fixed Gaussian prior (gp/fixed_prior.h:18-50): psi(x) = (x - mu)^T K^-1 (x - mu), constant 1.
 class FixedPriorGP : public LinearFactor {
  public:
@@ -491,10 +590,20 @@ class FixedPriorGP : public LinearFactor {
 };
 
 inline double cost_fixed_gp(const VectorXd& x, const FixedPriorGP& fixed_gp) { return fixed_gp.fixed_factor_cost(x); }   // gp/cost_functions.h:25-27
-inline double cost_linear_gp(const VectorXd& pose_cmb, const MinimumAccGP& gp_minacc) {                                     // :36-39
+// cost_linear_gp: ONE overload per program, as in the reference (gp/cost_functions.h:36-39 for MinimumAccGP,
+// gp/cost_functions_LTV.h:34-37 for LTV_GP; a program includes one of the two headers) -- the name is passed around as a
+// plain function, which two visible overloads would make ambiguous
+#ifdef GVI_FACTORIZED_OPTS_LTV
+inline double cost_linear_gp(const VectorXd& pose_cmb, const LTV_GP& gp_ltv) {
+  const int dim = gp_ltv.dim_posvel();
+  return gp_ltv.cost(pose_cmb.segment(0, dim), pose_cmb.segment(dim, dim));
+}
+#else
+inline double cost_linear_gp(const VectorXd& pose_cmb, const MinimumAccGP& gp_minacc) {
   const int dim = gp_minacc.dim_posvel();
   return gp_minacc.cost(pose_cmb.segment(0, dim), pose_cmb.segment(dim, dim));
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Factor operator surface (gvibase/GVIFactorizedBase.h:36-248; gvibase/GVIFactorizedBaseGH.h:20-78)
@@ -880,11 +989,18 @@ class NGDFactorizedLinear : public NGDFactorDeviceOps {
   double _constant;
 };
 
-// gp/factorized_opts_linear.h:6-13
+// gp/factorized_opts_linear.h:6-13; with GVI_FACTORIZED_OPTS_LTV (include/gvi/factorized_opts_LTV.hpp) the linear prior is
+// LTV_GP instead of MinimumAccGP, as in gp/factorized_opts_LTV.h:7-13 -- the reference chooses between the two by which of
+// the two headers a program includes, the names are the same
 using FixedGpPrior = NGDFactorizedLinear<FixedPriorGP>;
-using LinearGpPrior = NGDFactorizedLinear<MinimumAccGP>;
 using FixedGpPriorGH = NGDFactorizedLinearGH<FixedPriorGP>;
+#ifdef GVI_FACTORIZED_OPTS_LTV
+using LinearGpPrior = NGDFactorizedLinear<LTV_GP>;
+using LinearGpPriorGH = NGDFactorizedLinearGH<LTV_GP>;
+#else
+using LinearGpPrior = NGDFactorizedLinear<MinimumAccGP>;
 using LinearGpPriorGH = NGDFactorizedLinearGH<MinimumAccGP>;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Result recorder (helpers/DataRecorder.h:25-225): nine CSV files, one COLUMN per iteration, Eigen's column-major
