@@ -67,7 +67,7 @@ inline hipError_t chain_allow_lds() {
 // on0: factorisation a0 (log-det; + selected inverse when a0.need_back); on1: pivoted solve a1.  Both: side by side in the
 // same launches.  Returns hipErrorInvalidValue when a pass does not fit LDS.
 template <int N>
-inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st) {
+inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st, const AsmList& AL) {
   hipError_t e = chain_allow_lds<N>();
   if (e != hipSuccess) return e;
   auto set = [](ChainArgs& a, const ChainPass& ps) {
@@ -86,8 +86,8 @@ inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1
     lds *= 8;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int nb0 = on0 ? ps.blocks : 0, nb = nb0 + (on1 ? ps.blocks : 0);
-    if (ps.top) hipLaunchKernelGGL((chain_forward_kernel<N, true>), dim3(nb), dim3(pl.threads), lds, st, a0, a1, nb0);
-    else hipLaunchKernelGGL((chain_forward_kernel<N, false>), dim3(nb), dim3(pl.threads), lds, st, a0, a1, nb0);
+    if (ps.top) hipLaunchKernelGGL((chain_forward_kernel<N, true>), dim3(nb), dim3(pl.threads), lds, st, a0, a1, nb0, AL);
+    else hipLaunchKernelGGL((chain_forward_kernel<N, false>), dim3(nb), dim3(pl.threads), lds, st, a0, a1, nb0, AL);
   }
   const bool back0 = on0 && a0.need_back;
   if (back0 || on1) {
@@ -106,18 +106,22 @@ inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1
   return hipGetLastError();
 }
 
-// n: the caller's block size (a0.n / a1.n are set here)
-inline hipError_t chain_launch(int n, const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st) {
+// n: the caller's block size (a0.n / a1.n are set here).  AL: the factor sets of an assemble-on-load (a0.asm_on / a1.asm_on), else null
+inline hipError_t chain_launch(int n, const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st,
+                               const AsmList* AL = nullptr) {
   a0.n = a1.n = n;
+  AsmList none{};
+  const AsmList& L = AL ? *AL : none;
+  if (!AL) a0.asm_on = a1.asm_on = 0;
   switch (chain_padded(n)) {
-    case 1: return chain_launch_t<1>(pl, a0, a1, on0, on1, st);
-    case 2: return chain_launch_t<2>(pl, a0, a1, on0, on1, st);
-    case 3: return chain_launch_t<3>(pl, a0, a1, on0, on1, st);
-    case 4: return chain_launch_t<4>(pl, a0, a1, on0, on1, st);
-    case 6: return chain_launch_t<6>(pl, a0, a1, on0, on1, st);
-    case 8: return chain_launch_t<8>(pl, a0, a1, on0, on1, st);
-    case 12: return chain_launch_t<12>(pl, a0, a1, on0, on1, st);
-    case 16: return chain_launch_t<16>(pl, a0, a1, on0, on1, st);
+    case 1: return chain_launch_t<1>(pl, a0, a1, on0, on1, st, L);
+    case 2: return chain_launch_t<2>(pl, a0, a1, on0, on1, st, L);
+    case 3: return chain_launch_t<3>(pl, a0, a1, on0, on1, st, L);
+    case 4: return chain_launch_t<4>(pl, a0, a1, on0, on1, st, L);
+    case 6: return chain_launch_t<6>(pl, a0, a1, on0, on1, st, L);
+    case 8: return chain_launch_t<8>(pl, a0, a1, on0, on1, st, L);
+    case 12: return chain_launch_t<12>(pl, a0, a1, on0, on1, st, L);
+    case 16: return chain_launch_t<16>(pl, a0, a1, on0, on1, st, L);
   }
   return hipErrorInvalidValue;
 }

@@ -89,6 +89,7 @@ struct FactorSet {
   bool use_orbit = false;
   bool fused_pair = false;            // last resident launch went out fused with the other set
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
+  bool chain_structured = false;      // start[k] == k (factor k on state k / states k, k + 1): assemble-on-load needs no CSR
   bool all_pos = false;               // every residual row has sgn = +1 (positive-definite weight)
   double jtol = 1e-34;                // ctx->jacobi_tol
   bool use_chol = true;               // ctx->chol_sqrt
@@ -213,6 +214,11 @@ struct gvi_ctx {
   // out fused with the next trial factorisation (same three launches, no fork / join events)
   bool dual_chain = true;
   bool solve_deferred[2] = {false, false};
+  // assemble-on-load (GVI_ASM_ON_LOAD=0 / option "assemble_on_load": the stand-alone assemble launch): on chain-structured
+  // graphs the ordered assemble of (g, V_D, V_U) is not launched behind the factor pass but done by the first pass of the
+  // chain operations that consume it (kernels_chain.hpp, AsmList); asm_pending[gb]: gradient buffer gb is NOT assembled yet
+  bool asm_on_load = true;
+  bool asm_pending[2] = {false, false};
   DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
   DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
   DevMem epi_counter;                 // two-level arrival counters of epilogue_all_kernel's tail
@@ -894,10 +900,10 @@ ChainArgs make_chain_args(gvi_ctx* c, const ChainWs& w, const double* D, const d
   return a;
 }
 
-gvi_status run_chain(gvi_ctx* c, const ChainArgs& a0, const ChainArgs& a1, bool on0, bool on1) {
+gvi_status run_chain(gvi_ctx* c, const ChainArgs& a0, const ChainArgs& a1, bool on0, bool on1, const AsmList* AL = nullptr) {
   hipStream_t st = c->chain_stream ? c->chain_stream : c->stream;
   StageScope scope(c, STAGE_CHAIN);
-  const hipError_t e = chain_launch(c->n, chain_plan(c->T, c->n), a0, a1, on0, on1, st);
+  const hipError_t e = chain_launch(c->n, chain_plan(c->T, c->n), a0, a1, on0, on1, st, AL);
   if (e == hipErrorInvalidValue) return fail(c, GVI_ERR_UNSUPPORTED, "chain kernels: block size / LDS budget");
   HIPCK(c, e);
   return GVI_OK;
@@ -974,6 +980,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
   if (const char* w = getenv("GVI_FUSED")) c->fused = atoi(w) != 0;
+  if (const char* w = getenv("GVI_ASM_ON_LOAD")) c->asm_on_load = atoi(w) != 0;
   if (const char* w = getenv("GVI_PIPELINE")) c->pipeline = atoi(w) != 0;
   if (const char* w = getenv("GVI_CHOL_SQRT")) c->chol_sqrt = atoi(w) != 0;
   if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
@@ -1202,6 +1209,8 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
     std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
     for (int k = 0; k < K; ++k) idx[fill[start[k]]++] = k;
   }
+  s->chain_structured = (d == ctx->n && K <= ctx->T) || (d == 2 * ctx->n && K <= ctx->T - 1);
+  for (int k = 0; k < K && s->chain_structured; ++k) s->chain_structured = s->start[k] == k;
   GVICK(up(s->dstart, s->start.data(), (size_t)K * 4));
   GVICK(up(s->dptr, ptr.data(), ptr.size() * 4));
   GVICK(up(s->didx, idx.data(), idx.size() * 4));
@@ -1962,6 +1971,7 @@ gvi_status gvi_ngd_init(gvi_ctx* ctx, const double* mu, const double* D, const d
   }
   g.gcur = 0; g.grad_valid = false; g.grad_slot = -1;
   ctx->solve_deferred[0] = ctx->solve_deferred[1] = false;
+  ctx->asm_pending[0] = ctx->asm_pending[1] = false;
   ctx->last_first_accepted = true;                 // adaptive fusing starts afresh: the pass order of a run must not depend on the previous problem
   HIPCK(ctx, g.exch1.ensure(8));
   HIPCK(ctx, g.dmu.ensure(T * n * 8));
@@ -2212,8 +2222,48 @@ static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot, int publish_slot = -1
   return ngd_epilogue_all(ctx, 1, publish_slot);
 }
 
-// ordered assemble of the per-factor results into gradient buffer `gb`
+// assemble-on-load applies: every set chain-structured, the solve of this buffer will go out through the dual launch (or
+// the flushing solve), nobody needs [g | V_D | V_U] in memory before that
+static bool asm_on_load_ok(const gvi_ctx* ctx) {
+  if (!ctx->asm_on_load || dist_on(ctx) || ctx->pipeline || ctx->update_rule != GVI_RULE_NGD || ctx->sets.empty()) return false;
+  if (!(ctx->dual_chain && ctx->side_solve && chain_supported(ctx->n) && ctx->T > 1)) return false;
+  for (auto& s : ctx->sets)
+    if (!s->chain_structured) return false;
+  return true;
+}
+
+static AsmList make_asm_list(gvi_ctx* ctx) {
+  AsmList L{};
+  L.nsets = (int)ctx->sets.size();
+  for (int i = 0; i < L.nsets; ++i) {
+    FactorSet& s = *ctx->sets[i];
+    L.s[i].K = s.K; L.s[i].d = s.d; L.s[i].Vdmu = s.Vdmu.d(); L.s[i].Vddmu = s.Vddmu.d();
+  }
+  return L;
+}
+
+static gvi_status ngd_scatter_now(gvi_ctx* ctx, int slot, int gb);
+
+// ordered assemble of the per-factor results into gradient buffer `gb` -- launched now, or left to the first pass of the
+// chain operations that consume the buffer (assemble-on-load)
 static gvi_status ngd_scatter(gvi_ctx* ctx, int slot, int gb) {
+  if ((int)ctx->sets.size() <= MAX_SETS && asm_on_load_ok(ctx)) {
+    ctx->asm_pending[gb] = true;
+    ctx->asm_pending[1 - gb] = false;               // its source (the sets' Vdmu / Vddmu) has just been overwritten
+    return GVI_OK;
+  }
+  ctx->asm_pending[gb] = false;
+  return ngd_scatter_now(ctx, slot, gb);
+}
+
+// stand-alone assemble of a buffer whose assemble was left pending (consumers other than the chain launches)
+static gvi_status ngd_flush_assemble(gvi_ctx* ctx, int gb) {
+  if (!ctx->asm_pending[gb]) return GVI_OK;
+  ctx->asm_pending[gb] = false;
+  return ngd_scatter_now(ctx, ctx->ngd.cur, gb);
+}
+
+static gvi_status ngd_scatter_now(gvi_ctx* ctx, int slot, int gb) {
   NgdState& g = ctx->ngd;
   const size_t T = ctx->T, n = ctx->n, nn = n * n;
   double* eg = g.exch0[gb].d();
@@ -2251,6 +2301,7 @@ static gvi_status ngd_grad_finish(gvi_ctx* ctx, int gb) {
     ctx->solve_deferred[gb] = true;                     // goes out with the next trial factorisation (ngd_trial_state)
     return GVI_OK;
   }
+  GVICK(ngd_flush_assemble(ctx, gb));
   if (ctx->side_solve && chain_supported(ctx->n)) {
     // the solve only feeds mu_trial; the trial precision and its factorisation need Vddmu alone, so the solve goes
     // to the side stream and ngd_join_solve() waits for it right before the first reader of dmu
@@ -2280,10 +2331,22 @@ static gvi_status ngd_join_solve(gvi_ctx* ctx, int gb) {
     const size_t T = ctx->T, n = ctx->n, nn = n * n;
     double* eg = g.exch0[gb].d();
     ctx->chain_ws = 1;
-    const gvi_status st = run_bt_solve(ctx, eg + T * n, eg + T * n + T * nn, eg, -1.0, g.dmu2[gb].d());
+    gvi_status st;
+    if (ctx->asm_pending[gb]) {
+      ctx->asm_pending[gb] = false;
+      ChainWs w;
+      st = ensure_chain_ws(ctx, w);
+      if (st == GVI_OK) {
+        ChainArgs a1 = make_chain_args(ctx, w, eg + T * n, eg + T * n + T * nn, eg, -1.0, false, nullptr, nullptr, g.dmu2[gb].d(), nullptr, false);
+        a1.asm_on = 1; a1.asmG = eg; a1.asmD = eg + T * n; a1.asmU = eg + T * n + T * nn;
+        const AsmList AL = make_asm_list(ctx);
+        st = run_chain(ctx, a1, a1, false, true, &AL);
+      }
+    } else st = run_bt_solve(ctx, eg + T * n, eg + T * n + T * nn, eg, -1.0, g.dmu2[gb].d());
     ctx->chain_ws = 0;
     return st;
   }
+  GVICK(ngd_flush_assemble(ctx, gb));
   if (ctx->solve_pending[gb]) {
     HIPCK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_solve[gb], 0));
     ctx->solve_pending[gb] = false;
@@ -2335,9 +2398,17 @@ static gvi_status ngd_trial_state(gvi_ctx* ctx, double step) {
     ctx->chain_ws = 0;
     if (fs == GVI_OK) {
       double* sD = g.Sig[t].d();
-      const ChainArgs a0 = make_chain_args(ctx, w0, g.Lam[c].d(), g.Lam[c].d() + Tnn, nullptr, 1.0, true, sD, sD + Tnn, nullptr, g.hld[t].d(), true);
-      const ChainArgs a1 = make_chain_args(ctx, w1, V, V + Tnn, eg, -1.0, false, nullptr, nullptr, g.dmu2[g.gcur].d(), nullptr, false);
-      fs = run_chain(ctx, a0, a1, true, true);
+      ChainArgs a0 = make_chain_args(ctx, w0, g.Lam[c].d(), g.Lam[c].d() + Tnn, nullptr, 1.0, true, sD, sD + Tnn, nullptr, g.hld[t].d(), true);
+      ChainArgs a1 = make_chain_args(ctx, w1, V, V + Tnn, eg, -1.0, false, nullptr, nullptr, g.dmu2[g.gcur].d(), nullptr, false);
+      if (ctx->asm_pending[g.gcur]) {
+        // the assemble of this gradient buffer was left to these launches: both operations form V from the per-factor
+        // results while they load, the solve leaves [g | V_D | V_U] in the buffer (later trials of this iteration read it)
+        ctx->asm_pending[g.gcur] = false;
+        a0.asm_on = a1.asm_on = 1;
+        a1.asmG = eg; a1.asmD = eg + Tn; a1.asmU = eg + Tn + Tnn;
+        const AsmList AL = make_asm_list(ctx);
+        fs = run_chain(ctx, a0, a1, true, true, &AL);
+      } else fs = run_chain(ctx, a0, a1, true, true);
     }
     ctx->mix = gvi_ctx::Mix();
     GVICK(fs);
@@ -2939,6 +3010,8 @@ gvi_status gvi_ngd_counters(gvi_ctx* ctx, int64_t* full_passes, int64_t* cost_pa
 gvi_status gvi_ngd_exchange(gvi_ctx* ctx, int which, void** dev_ptr, int64_t* count) {
   GVICK(ngd_check(ctx));
   if (!dev_ptr || !count) return fail(ctx, GVI_ERR_ARG, "NULL argument");
+  GVICK(ngd_flush_assemble(ctx, 0));                    // the caller is going to read / reduce the buffers themselves
+  GVICK(ngd_flush_assemble(ctx, 1));
   if (which == 0) { *dev_ptr = ctx->ngd.exch0[ctx->ngd.gcur].p; *count = (int64_t)((size_t)ctx->T * ctx->n + bt_count(ctx)); }
   else if (which == 1) { *dev_ptr = ctx->ngd.exch1.p; *count = 1; }
   else if (which == 2) { *dev_ptr = ctx->ngd.exch0[1 - ctx->ngd.gcur].p; *count = (int64_t)((size_t)ctx->T * ctx->n + bt_count(ctx)); }
@@ -3039,6 +3112,7 @@ gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nch
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return GVI_ERR_ARG;
   const std::string n(name);
+  if (ctx->ngd.ready) { GVICK(ngd_flush_assemble(ctx, 0)); GVICK(ngd_flush_assemble(ctx, 1)); }
   if (n == "split_flush") ctx->split_flush = std::max(0, value);
   else if (n == "sreg_pipe") ctx->sreg_pipe = value != 0;
   else if (n == "mirror") ctx->mirror = value != 0;
@@ -3051,6 +3125,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "target_waves") ctx->target_waves = std::max(1, value);
   else if (n == "orbit") ctx->orbit = value != 0;
   else if (n == "fused") ctx->fused = value != 0;
+  else if (n == "assemble_on_load") ctx->asm_on_load = value != 0;
   else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") {

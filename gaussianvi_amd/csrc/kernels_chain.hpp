@@ -47,6 +47,7 @@
 #include <stdint.h>
 
 #include "device_common.hpp"
+#include "kernels_bt.hpp"
 
 namespace gvi {
 
@@ -84,9 +85,43 @@ struct ChainArgs {
   const double* mixV;
   double* mixOut;
   double mix_step;
+  // optional assemble-on-load (first pass; chain-structured factor sets, AsmList below): the matrix V = [V_D | V_U] and the
+  // vector g are not read but ASSEMBLED from the per-factor results (the sums of bt_scatter_all_kernel, same order):
+  //   solve (rhs != null):  (D, U, rhs) <- assembled (V_D, V_U, g), written out to asmD / asmU / asmG on the way;
+  //   factorisation:        the mixed-in matrix mixV <- assembled (the chain operated on is D + mix_step (V - D)).
+  int asm_on;
+  double* asmD;
+  double* asmU;
+  double* asmG;
   const double* pred;    // predicated launch (device_common.hpp, pred_skip) or null
   double pred_val;
 };
+
+// Chain-structured factor sets for the assemble-on-load: factor k of a binary set (d = 2n) couples states k, k + 1, factor
+// k of a unary set (d = n) sits on state k -- start[k] = k, so no CSR indirection (three INDEPENDENT loads per element
+// instead of ptr -> idx -> value).  Other graphs keep the stand-alone assemble launch.
+struct AsmSet { int K, d; const double* Vdmu; const double* Vddmu; };
+struct AsmList { int nsets; AsmSet s[MAX_SETS]; };
+
+// element (r, c) of V_D[t] (which = 0) / V_U[t] (which = 1), or entry r of g[t] (which = 2): bt_scatter_all_kernel's sums
+__device__ __forceinline__ double asm_element(const AsmList& L, const int n, const int t, const int which, const int r, const int c) {
+  double acc = 0.0;
+  for (int si = 0; si < L.nsets; ++si) {
+    const AsmSet& a = L.s[si];
+    const int d = a.d;
+    const bool two = d == 2 * n;
+    double s = 0.0;
+    if (which == 2) {
+      if (t < a.K) s += a.Vdmu[(size_t)t * d + r];
+      if (two && t > 0 && t - 1 < a.K) s += a.Vdmu[(size_t)(t - 1) * d + n + r];
+    } else if (which == 0) {
+      if (t < a.K) s += a.Vddmu[(size_t)t * d * d + r * d + c];
+      if (two && t > 0 && t - 1 < a.K) s += a.Vddmu[(size_t)(t - 1) * d * d + (n + r) * d + n + c];
+    } else if (two && t < a.K) s += a.Vddmu[(size_t)t * d * d + r * d + n + c];
+    acc += s;                 // same association as bt_scatter_all_kernel
+  }
+  return acc;
+}
 
 #ifndef GVI_CHAIN_THREADS_SMALL
 #define GVI_CHAIN_THREADS_SMALL 1024
@@ -439,7 +474,7 @@ __host__ __device__ constexpr size_t bwd_lds_doubles(int S) {
 
 // ---- passes A / B: one workgroup per segment ----
 template <bool PIVOT, bool HAS_E, bool HAS_Y, bool TOP, int N>
-__device__ __forceinline__ void forward_body(const ChainArgs& a, const int bid, double* sm) {
+__device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& AL, const int bid, double* sm) {
   constexpr int nn = N * N;
   const int T = a.T, S = a.S, st = 1 << a.level0;
   // the wave index as a SCALAR: everything derived from it (node, offsets, has_b) is then wave-uniform for the compiler too
@@ -465,7 +500,7 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const int bid, 
   const int xn = x0 + S * st;
   const bool ext_right = !TOP && xn < T;            // the next segment's first node exists
   const bool first = a.first != 0;
-  const bool mix = first && a.mixV != nullptr;
+  const bool mix = first && (a.mixV != nullptr || (a.asm_on && !HAS_Y));
   [[maybe_unused]] double lpm = 1.0;
   [[maybe_unused]] int lpe = 0, lpb = 0;
   if constexpr (TOP) {
@@ -497,11 +532,24 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const int bid, 
         if (first) {
           const int xe = ext_el<N>(a.n, el);
           const size_t ge = (size_t)x * (a.n * a.n) + xe, gu = (size_t)(T + x) * (a.n * a.n) + xe;
-          dv[u] = xe >= 0 ? a.D[ge] : ((el / N == el % N) ? 1.0 : 0.0);                            // identity padding
-          if (mix && xe >= 0) { const double mv = a.mixV[ge]; dv[u] = dv[u] + a.mix_step * (mv - dv[u]); }      // same arithmetic as trial_kernel
-          if (hasc[u] && xe >= 0) {
-            cu[u] = a.U[ge];
-            if (mix) { const double mv = a.mixV[gu]; cu[u] = cu[u] + a.mix_step * (mv - cu[u]); }
+          const bool asmv = a.asm_on != 0 && xe >= 0;
+          const int er = xe >= 0 ? xe / a.n : 0, ec = xe >= 0 ? xe % a.n : 0;
+          double vD = 0.0, vU = 0.0;
+          if (asmv) {                                     // assembled V_D / V_U element (independent loads, issued with the rest)
+            vD = asm_element(AL, a.n, x, 0, er, ec);
+            if (hasc[u]) vU = asm_element(AL, a.n, x, 1, er, ec);
+          }
+          if (HAS_Y && asmv) {                            // the solve operates ON the assembled matrix and leaves it in memory
+            dv[u] = vD;
+            a.asmD[ge] = vD;
+            if (hasc[u]) { cu[u] = vU; a.asmU[ge] = vU; }
+          } else {
+            dv[u] = xe >= 0 ? a.D[ge] : ((el / N == el % N) ? 1.0 : 0.0);                            // identity padding
+            if (mix && xe >= 0) { const double mv = asmv ? vD : a.mixV[ge]; dv[u] = dv[u] + a.mix_step * (mv - dv[u]); }   // trial_kernel's arithmetic
+            if (hasc[u] && xe >= 0) {
+              cu[u] = a.U[ge];
+              if (mix) { const double mv = asmv ? vU : a.mixV[gu]; cu[u] = cu[u] + a.mix_step * (mv - cu[u]); }
+            }
           }
         } else {
           const double b0 = ws_mat<N>(a, W_DEFF)[g];
@@ -538,7 +586,13 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const int bid, 
       const int j = e / N, r = e % N, x = x0 + j * st;
       double v = 0.0;
       if (j < cnt) {
-        if (first) v = r < a.n ? a.rhs_scale * a.rhs[(size_t)x * a.n + r] : 0.0;
+        if (first) {
+          if (a.asm_on && r < a.n) {
+            const double gv = asm_element(AL, a.n, x, 2, r, 0);
+            a.asmG[(size_t)x * a.n + r] = gv;
+            v = a.rhs_scale * gv;
+          } else v = r < a.n ? a.rhs_scale * a.rhs[(size_t)x * a.n + r] : 0.0;
+        }
         else {
           const size_t g = (size_t)x * N + r;
           v = (ws_vec<N>(a, V_YEFF)[g] + (x > 0 ? ws_vec<N>(a, V_YLS + (a.par ^ 1))[g] : 0.0)) + ws_vec<N>(a, V_YRS)[g];
@@ -845,14 +899,14 @@ __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid,
 // Blocks [0, nb0): factorisation a0 (unpivoted; log-det, selected inverse); the rest: pivoted solve a1.
 
 template <int N, bool TOP>
-__global__ __launch_bounds__(chain_threads(N)) void chain_forward_kernel(ChainArgs a0, ChainArgs a1, int nb0) {
+__global__ __launch_bounds__(chain_threads(N)) void chain_forward_kernel(ChainArgs a0, ChainArgs a1, int nb0, AsmList AL) {
   extern __shared__ double sm[];
   if ((int)blockIdx.x < nb0) {
     if (pred_skip(a0.pred, a0.pred_val)) return;
-    chain::forward_body<false, true, false, TOP, N>(a0, (int)blockIdx.x, sm);
+    chain::forward_body<false, true, false, TOP, N>(a0, AL, (int)blockIdx.x, sm);
   } else {
     if (pred_skip(a1.pred, a1.pred_val)) return;
-    chain::forward_body<true, false, true, TOP, N>(a1, (int)blockIdx.x - nb0, sm);
+    chain::forward_body<true, false, true, TOP, N>(a1, AL, (int)blockIdx.x - nb0, sm);
   }
 }
 

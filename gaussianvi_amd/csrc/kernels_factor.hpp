@@ -332,6 +332,24 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
   double* Xl = Ll + dd;       // [d][d] X = L^-1
   const double* Sg = Sigma + (size_t)kin * dd;
   const int li = lane < d ? lane : d - 1;                     // lanes >= d shadow the last row (results unused)
+  // The rows of A (and b) the psi operands H = A L, u0 = b + A mu need do not depend on the factorisation: request them
+  // NOW, so that their global-memory latency runs under the Cholesky instead of behind it (the prep is a chain of dependent
+  // latencies: ~10 us per factor before this, profiles/r03 fused-pass stamps).  Element e = lane (+ 64) of H reads row e / d.
+  constexpr int HPL = 2;                                       // H elements per lane: m d <= 128 for the Cholesky shapes (m <= d / 2 ... d)
+  const int mm = f.m;
+  const bool pre = mm > 0 && mm * d <= 64 * HPL;
+  double arow[HPL][DT], brow = 0.0;
+  if (pre) {
+    const double* Ak = f.A + (size_t)k * mm * d;
+#pragma unroll
+    for (int q = 0; q < HPL; ++q) {
+      const int e = lane + 64 * q;
+      const int r = e < mm * d ? e / d : 0;
+#pragma unroll
+      for (int c = 0; c < d; ++c) arow[q][c] = Ak[r * d + c];
+    }
+    if (lane < mm) brow = f.b[(size_t)k * mm + lane];
+  }
   double row[DT];
 #pragma unroll
   for (int c = 0; c < d; ++c) row[c] = c <= li ? Sg[li * d + c] : 0.0;      // lower triangle, like SelfAdjointEigenSolver
@@ -377,19 +395,37 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
   if (f.m > 0) {
     const int m = f.m;
     const double* Ak = f.A + (size_t)k * m * d;
-    for (int e = lane; e < m * d; e += 64) {
-      const int r = e / d, a = e % d;
-      double h = 0.0;
+    if (pre) {                                           // operands already in registers (same products, same order)
 #pragma unroll
-      for (int c = 0; c < d; ++c) h += Ak[r * d + c] * Ll[c * d + a];
-      f.H[(size_t)k * m * d + a * m + r] = h;            // column-major [d][m]: a column's m entries contiguous
-      if (f.Hq) {
-        const int R = (m + 3) / 4;
-        f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+      for (int q = 0; q < HPL; ++q) {
+        const int e = lane + 64 * q;
+        if (e < m * d) {
+          const int r = e / d, a = e % d;
+          double h = 0.0;
+#pragma unroll
+          for (int c = 0; c < d; ++c) h += arow[q][c] * Ll[c * d + a];
+          f.H[(size_t)k * m * d + a * m + r] = h;        // column-major [d][m]: a column's m entries contiguous
+          if (f.Hq) {
+            const int R = (m + 3) / 4;
+            f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+          }
+        }
+      }
+    } else {
+      for (int e = lane; e < m * d; e += 64) {
+        const int r = e / d, a = e % d;
+        double h = 0.0;
+#pragma unroll
+        for (int c = 0; c < d; ++c) h += Ak[r * d + c] * Ll[c * d + a];
+        f.H[(size_t)k * m * d + a * m + r] = h;
+        if (f.Hq) {
+          const int R = (m + 3) / 4;
+          f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+        }
       }
     }
     if (lane < m) {
-      double u = f.b[(size_t)k * m + lane];
+      double u = pre ? brow : f.b[(size_t)k * m + lane];
 #pragma unroll
       for (int c = 0; c < d; ++c) u += Ak[lane * d + c] * mu[(size_t)kin * d + c];
       f.u0[(size_t)k * m + lane] = u;

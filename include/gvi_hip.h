@@ -319,12 +319,14 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * equivalent) route agree to rounding: "split_flush" (d = 16 / 20 / 24 kernel; 0 = plain recursive sums), "mirror",
  * "orbit" / "orbit_waves" / "orbit_copies" (sign-orbit kernel, its chunking and its private accumulator copies),
  * "chol_sqrt" (1: sum-of-squares sets take S = chol(Sigma) instead of the symmetric root -- the quadrature is exact there),
+ * "assemble_on_load" (1: on chain-structured graphs the ordered assemble of (g, V) is done by the first pass of the chain
+ * operations that consume it instead of a launch of its own; same sums in the same order),
  * "fused" (1: the full moments pass of the resident iteration is ONE launch per pass -- gather, per-pass products, psi walk, chunk
  * sum, cost and back-transform of a factor in one workgroup; 0: the three launches prep -> psi -> epilogue),
  * "jacobi_tol_exp" (stopping threshold 10^value of the symmetric-root solve, on SQUARED off-diagonal / diagonal mass; values
  * above -20 return GVI_ERR_ARG -- the environment form GVI_JACOBI_TOL_EXP clamps to -20 instead).
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,
- * orbit, fused, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline. */
+ * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline. */
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus

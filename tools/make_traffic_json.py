@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json (what bench.py reports as roofline.traffic) from a PMC summary (tools/summarize_pmc.py):
+"""profiles/rNN_traffic.json (what bench.py reports as roofline.traffic) from a PMC summary (tools/summarize_pmc.py):
    make_traffic_json.py <summary.json> <kernel-name substring> <algorithmic bytes per launch> <kernel us (rocprof)> <out.json>"""
 import json
 import sys
@@ -28,7 +28,7 @@ res = {
         "valu_instructions_per_wave": c["SQ_INSTS_VALU"] / c["SQ_WAVES"],
         "lds_instructions_per_wave": c["SQ_INSTS_LDS"] / c["SQ_WAVES"],
     },
-    "note": "rocprofv3 --pmc passes of `bench.py --steps 6 --warmup 2 --no-cpu-baseline` (tools/gpu_pmc_r02.sh: FETCH_SIZE, WRITE_SIZE, "
+    "note": "rocprofv3 --pmc passes of `bench.py --steps 6 --warmup 2 --no-cpu-baseline` (tools/gpu_pmc.sh: FETCH_SIZE, WRITE_SIZE, "
             "SQ_*, TCC_* in separate runs with --kernel-trace only), means over the launches of the run.  FETCH / WRITE in KB as "
             "rocprofv3 reports them; loads are 8 B per lane, so the guide's x2 FETCH_SIZE correction (calibrated on 16 B/lane streams) "
             "is given as a second figure.  SQ_BUSY_CYCLES / 32 shader engines = kernel duration in cycles; VALU pipe busy = "
