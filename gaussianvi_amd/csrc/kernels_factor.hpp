@@ -381,6 +381,18 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
 #pragma unroll
     for (int c = 0; c < d; ++c) { Ll[lane * d + c] = row[c]; Xl[c * d + lane] = xcol[c]; }
   }
+  // the prefetched rows of A also go to LDS (one copy per row: lanes e = r d hold row r), for u0 = b + A mu below
+  double* Al = Xl + dd;        // [m][d]
+  if (pre) {
+#pragma unroll
+    for (int q = 0; q < HPL; ++q) {
+      const int e = lane + 64 * q;
+      if (e < mm * d && e % d == 0) {
+#pragma unroll
+        for (int c = 0; c < d; ++c) Al[e + c] = arow[q][c];
+      }
+    }
+  }
   wave_lds_sync();
   for (int e = lane; e < dd; e += 64) {
     const int i = e / d, j = e % d;
@@ -427,7 +439,7 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     if (lane < m) {
       double u = pre ? brow : f.b[(size_t)k * m + lane];
 #pragma unroll
-      for (int c = 0; c < d; ++c) u += Ak[lane * d + c] * mu[(size_t)kin * d + c];
+      for (int c = 0; c < d; ++c) u += (pre ? Al[lane * d + c] : Ak[lane * d + c]) * mu[(size_t)kin * d + c];
       f.u0[(size_t)k * m + lane] = u;
     }
   }
