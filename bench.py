@@ -318,8 +318,12 @@ def main():
 
     # one-time costs (buffer growth on the first cost pass, side stream / event creation, kernel attribute calls, the
     # cold Jacobi start) are primed outside the contract's W warm-up steps as well, so a small W does not time them
-    for i in range(0 if big else max(0, 8 - args.warmup)):
-        step_fn()
+    # (and a fixed ~25 ms of untimed iterations first: a fresh process on a fresh box starts at low clocks)
+    if not big:
+        for j in range(200):
+            if j % args.restart_every == 0:
+                restart()
+            step_fn()
     # the W warm-up steps start from the initial state; the timed steps continue from there, so the timed region
     # begins with the iteration pipeline warm (a restart costs one cold step: synchronous upload + chain refresh)
     restart()
@@ -331,7 +335,7 @@ def main():
     barrier()
     ctx.ngd_counters(reset=True)
     t0 = time.perf_counter()
-    kern_ms, log = [], []
+    kern_ms, log, block_ms = [], [], []
     if single and not args.per_step_calls:
         # the iteration loop of GVIGH::optimize as ONE C call per block of steps (gvi_ngd_run): no interpreter between the
         # decision of an iteration and the launches of the next
@@ -339,7 +343,9 @@ def main():
         while done < args.steps:
             if pos == args.restart_every:
                 restart(); pos = 0                      # timed: host upload + one refresh of the chain products
+            tb = time.perf_counter()
             blk = ctx.ngd_run(min(args.steps - done, args.restart_every - pos, 64), 0.55, 10)
+            block_ms.append(1e3 * (time.perf_counter() - tb) / max(1, len(blk)))
             log.extend(blk); done += len(blk); pos += len(blk)
             try:
                 kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch of the block
@@ -572,6 +578,10 @@ def main():
                        "mirror_pairs": bool(geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"),
                        "fuse_trial": args.fuse_trial},
             "ngd_iters_per_s": args.steps / elapsed,
+            # diagnosis only (`value` / `ms_per_step` are the whole timed region): per-step time of the gvi_ngd_run blocks without
+            # the restarts between them; a max far above the median is a host / box stall (tens of ms have been seen), not the path
+            "block_ms_per_step": ({"median": float(np.median(block_ms)), "max": float(np.max(block_ms)), "blocks": len(block_ms)}
+                                  if block_ms else None),
             # `value` split by pass kind (SURVEY 8(d) defines an evaluation "in one moments pass")
             "passes": {"full": n_full, "cost_only": n_cost, "evals_per_pass": evals_pass * world if world > 1 else evals_pass,
                        "moments_pass_evals_per_s": evals_full / elapsed, "cost_pass_evals_per_s": evals_cost / elapsed,

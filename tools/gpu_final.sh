@@ -1,46 +1,47 @@
 #!/bin/bash
-# round-end validation: full GPU suite, smoke(), default bench (+ cpu baseline), C2 / C5 benches, kernel trace, 2-rank rehearsal
+# Round-end validation: full GPU suite, smoke(), default bench (+ cpu baseline), C2 / planar1k / C5 benches, kernel traces,
+# 2-rank rehearsal.  Output under gpurun_out/$R/final (R defaults to r03).
 set -o pipefail
-mkdir -p gpurun_out/r02/final
-O=gpurun_out/r02/final
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=$?
-tail -4 $O/pytest_gpu.log
-[ $rc -ne 0 ] && exit $rc
-timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
-tail -1 $O/smoke.log
-timeout -k 10 300 python bench.py > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+ROOT="${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}"
+R="${R:-r03}"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+O="gpurun_out/$R/final"
+mkdir -p "$O"
+if [ "${GVI_SKIP_TESTS:-0}" != "1" ]; then
+  timeout -k 10 1000 python -m pytest tests -m gpu -x -q > "$O/pytest_gpu.log" 2>&1; rc=$?
+  tail -4 "$O/pytest_gpu.log"
+  [ $rc -ne 0 ] && exit $rc
+fi
+timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1 || { tail -20 "$O/smoke.log"; exit 1; }
+tail -1 "$O/smoke.log"
+timeout -k 10 300 python bench.py > "$O/bench.json" 2> "$O/bench.err" || { tail -20 "$O/bench.err"; exit 1; }
+for c in c2 planar1k; do
+  timeout -k 10 300 python bench.py --config $c --steps 500 --warmup 50 > "$O/bench_$c.json" 2> "$O/bench_$c.err" || { tail -20 "$O/bench_$c.err"; exit 1; }
+done
+timeout -k 10 500 python bench.py --config c5 --no-cpu-baseline > "$O/bench_c5.json" 2> "$O/bench_c5.err" || { tail -20 "$O/bench_c5.err"; exit 1; }
 python - <<PY
 import json
-d=json.load(open("$O/bench.json"))
-print("c3 ms/step", d["ms_per_step"], "value", d["value"], "kernel ms", d["moments_kernel"]["ms"], "frac", d["roofline"]["frac"], "cpu", d["cpu_baseline"]["value"], "ref order", d["reference_pass_order"]["ms_per_step"])
+for c in ("", "_c2", "_planar1k", "_c5"):
+    d=json.load(open("$O/bench%s.json" % c))
+    print(c or "c3", "ms/step", round(d["ms_per_step"], 5), "value %.4g" % d["value"], "final", d["final_cost"], "kernel ms", round(d["roofline"]["kernel_ms"], 4),
+          "frac", round(d["roofline"]["frac"], 3) if d["roofline"]["frac"] == d["roofline"]["frac"] else None, "stages", d.get("iteration_breakdown_us"),
+          "cpu", (d.get("cpu_baseline") or {}).get("value"))
 PY
-timeout -k 10 200 python bench.py --config c2 --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err || { tail -20 $O/bench_c2.err; exit 1; }
-timeout -k 10 400 python bench.py --config c5 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err || { tail -20 $O/bench_c5.err; exit 1; }
-python - <<PY
-import json
-for c in ("c2", "c5"):
-    d=json.load(open("$O/bench_%s.json" % c))
-    print(c, "ms/step", d["ms_per_step"], "value", d["value"], "final", d["final_cost"], "variant", d["config"]["kernel_variant"])
-PY
-rm -rf $O/trace
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/trace.log 2>&1 || { tail -20 $O/trace.log; exit 1; }
-find $O/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
-head -12 $O/kernel_stats.csv | cut -c1-130
-GVI_BENCH_REHEARSAL=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 60 --warmup 10 > $O/bench_rehearsal2.log 2>&1 || { tail -20 $O/bench_rehearsal2.log; exit 1; }
-grep '^{' $O/bench_rehearsal2.log | tail -1 > $O/bench_rehearsal2.json
+for c in c3 c2 planar1k; do
+  rm -rf "$O/trace_$c"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_$c" -- python3 bench.py --config $c --steps 200 --warmup 20 --no-cpu-baseline > "$O/trace_$c.log" 2>&1 || { tail -20 "$O/trace_$c.log"; exit 1; }
+  find "$O/trace_$c" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/kernel_stats_$c.csv"
+  rm -rf "$O/trace_$c"
+done
+rm -rf "$O/trace_c5"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_c5" -- python3 bench.py --config c5 --steps 2 --warmup 1 --no-cpu-baseline > "$O/trace_c5.log" 2>&1 || tail -5 "$O/trace_c5.log"
+find "$O/trace_c5" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$O/kernel_stats_c5.csv"
+rm -rf "$O/trace_c5"
+head -8 "$O/kernel_stats_c3.csv" | cut -c1-150
+GVI_BENCH_REHEARSAL=1 GVI_BENCH_C5_CONFIG=c5small timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 60 --warmup 10 > "$O/bench_rehearsal2.log" 2>&1 || { tail -20 "$O/bench_rehearsal2.log"; exit 1; }
+grep '^{' "$O/bench_rehearsal2.log" | tail -1 > "$O/bench_rehearsal2.json"
 python - <<PY
 import json
 d=json.load(open("$O/bench_rehearsal2.json"))
-print("rehearsal n=2 final", d["final_cost"], "ms/step", d["ms_per_step"])
-PY
-# steady-state iteration time p and restart cost R from two restart periods: t(r) = r p + R
-for r in 15 30; do
-  timeout -k 10 200 python bench.py --steps 600 --warmup 30 --restart-every $r --no-cpu-baseline > $O/bench_restart$r.json 2>/dev/null || exit 1
-done
-python - <<PY
-import json
-t = {r: json.load(open("$O/bench_restart%d.json" % r))["ms_per_step"] * r for r in (15, 30)}
-p = (t[30] - t[15]) / 15.0
-print("steady-state iteration p = %.2f us, restart R = %.1f us" % (1e3 * p, 1e3 * (t[15] - 15 * p)))
+print("rehearsal n=2 final", d["final_cost"], "ms/step", d["ms_per_step"], "c5_strong", d["c5_strong"]["ms_per_step"], d["c5_strong"]["accepted_steps"])
 PY
