@@ -686,7 +686,7 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
   const int dbg = getenv("GVI_FUSED_DBG") ? atoi(getenv("GVI_FUSED_DBG")) : 0;
   static unsigned long long* stamps = nullptr;
   static int nprint = 0;
-  if ((dbg & 8) && !stamps) { if (hipMalloc(&stamps, 256 * 8) != hipSuccess) stamps = nullptr; }
+  if ((dbg & 8) && !stamps) { if (hipMalloc(&stamps, 320 * 8) != hipSuccess) stamps = nullptr; }
 #else
   const int dbg = 0;
   unsigned long long* stamps = nullptr;
@@ -695,9 +695,12 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
                         (dbg & 8) ? stamps : (unsigned long long*)nullptr);
 #ifdef GVI_FUSED_TIMING
   if ((dbg & 8) && stamps && ++nprint > 200 && nprint <= 202) {          // a few warm launches, 100 MHz ticks
-    unsigned long long h[256];
+    unsigned long long h[320];
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[prep stamps] block 0 wave 0, us after the block's start: [Sigma row loaded | Cholesky | L^-1 | LDS + Lam + stores | H, u0]:");
+    for (int i = 0; i < 6; ++i) fprintf(stderr, " %.2f", (double)(long long)(h[256 + i] - h[0]) * 0.01);
+    fprintf(stderr, "\n");
     unsigned long long t0 = ~0ull;
     for (int blk = 0; blk < 8; ++blk) if (h[blk * 32] && h[blk * 32] < t0) t0 = h[blk * 32];
     for (int blk = 0; blk < 8; ++blk) {
@@ -2111,6 +2114,7 @@ static int fused_nblk(const gvi_ctx* ctx) {
 
 static bool fused_ok(const gvi_ctx* ctx, int slot) {
   if (!ctx->fused || !ctx->pair_fuse || ctx->profile_all || ctx->sets.empty() || ctx->sets.size() > 2) return false;
+  if (ctx->update_rule != GVI_RULE_NGD) return false;     // the JKO map reads the sets' Sigma^-1 after the pass
   const int m = ctx->sets[0]->m;
   for (auto& sp : ctx->sets) {
     const FactorSet& s = *sp;
@@ -2137,7 +2141,7 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
   for (int si = 0; si < A.nsets; ++si) {
     FactorSet& s = *ctx->sets[si];
     FusedSet& F = A.s[si];
-    s.prep_slot = slot;
+    s.prep_slot = -1;                      // the fused pass keeps its products in LDS: nothing resident for a later pass
     s.nchunk = 4; s.chunk = s.table->Np;
     s.use_reg = s.use_split = false; s.use_orbit = true; s.fused_pair = true;
     F.f = s.dev();

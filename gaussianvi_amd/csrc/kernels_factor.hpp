@@ -323,9 +323,23 @@ __device__ __forceinline__ double chol_readlane(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 
+// -DGVI_FUSED_TIMING: 100 MHz stamps of wave 0 of block 0 inside the Cholesky prep (slots 8.. of the fused kernel's stamp
+// buffer; the kernel parks the pointer here)
+#ifdef GVI_FUSED_TIMING
+__device__ unsigned long long* gvi_prep_stamps;
+#define PREP_STAMP(i) do { if (gvi_prep_stamps && blockIdx.x == 0 && threadIdx.x == 0) gvi_prep_stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PREP_STAMP(i) do { } while (0)
+#endif
+
 // Zs (LDS, optional): a copy of S^-T for an epilogue in the same launch (factor_fused_kernel)
+// Hs / u0s (LDS, optional; factor_fused_kernel's lean form): the psi operands H (column c at Hs + c hstride) and u0 stay in LDS
+// for the walk of the same launch and NOTHING of the per-pass products goes to memory (no S / S^-T / Sigma^-1 / H / u0
+// stores, Sigma^-1 is not formed: the caller's epilogue re-forms what it needs from Zs)
 template <int DT>
-__device__ inline void prep_chol_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin, double* Zs = nullptr) {
+__device__ inline void prep_chol_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin, double* Zs = nullptr,
+                                      double* Hs = nullptr, double* u0s = nullptr, const int hstride = 0) {
+  const bool lean = Hs != nullptr;
   constexpr int d = DT, dd = DT * DT;
   const int lane = threadIdx.x & 63;      // one wave per factor (the fused kernel runs several per block)
   double* Ll = sm;            // [d][d] L, zeros above the diagonal
@@ -350,9 +364,11 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     }
     if (lane < mm) brow = f.b[(size_t)k * mm + lane];
   }
+  PREP_STAMP(0);
   double row[DT];
 #pragma unroll
   for (int c = 0; c < d; ++c) row[c] = c <= li ? Sg[li * d + c] : 0.0;      // lower triangle, like SelfAdjointEigenSolver
+  PREP_STAMP(1);
   double inv[DT];
 #pragma unroll
   for (int j = 0; j < d; ++j) {
@@ -368,6 +384,7 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
       row[c] = li >= c ? fma(-row[j], lcj, row[c]) : 0.0;
     }
   }
+  PREP_STAMP(2);
   // X = L^-1 by forward substitution: lane c owns column c
   double xcol[DT];
 #pragma unroll
@@ -377,6 +394,7 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     for (int q = 0; q < i; ++q) sacc = fma(-chol_readlane(row[q], i), xcol[q], sacc);
     xcol[i] = li <= i ? sacc * inv[i] : 0.0;
   }
+  PREP_STAMP(3);
   if (lane < d) {
 #pragma unroll
     for (int c = 0; c < d; ++c) { Ll[lane * d + c] = row[c]; Xl[c * d + lane] = xcol[c]; }
@@ -394,16 +412,21 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     }
   }
   wave_lds_sync();
-  for (int e = lane; e < dd; e += 64) {
-    const int i = e / d, j = e % d;
-    double lam = 0.0;
+  if (lean) {
+    for (int e = lane; e < dd; e += 64) Zs[e] = Xl[(e % d) * d + e / d];            // S^-T = X^T
+  } else {
+    for (int e = lane; e < dd; e += 64) {
+      const int i = e / d, j = e % d;
+      double lam = 0.0;
 #pragma unroll
-    for (int c = 0; c < d; ++c) lam = fma(Xl[c * d + i], Xl[c * d + j], lam);      // Sigma^-1 = X^T X
-    f.S[(size_t)k * dd + e] = Ll[e];
-    f.Sinv[(size_t)k * dd + e] = Xl[j * d + i];                                      // S^-T = X^T
-    f.Lam[(size_t)k * dd + e] = lam;
-    if (Zs) Zs[e] = Xl[j * d + i];
+      for (int c = 0; c < d; ++c) lam = fma(Xl[c * d + i], Xl[c * d + j], lam);      // Sigma^-1 = X^T X
+      f.S[(size_t)k * dd + e] = Ll[e];
+      f.Sinv[(size_t)k * dd + e] = Xl[j * d + i];                                      // S^-T = X^T
+      f.Lam[(size_t)k * dd + e] = lam;
+      if (Zs) Zs[e] = Xl[j * d + i];
+    }
   }
+  PREP_STAMP(4);
   if (f.m > 0) {
     const int m = f.m;
     const double* Ak = f.A + (size_t)k * m * d;
@@ -416,10 +439,13 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
           double h = 0.0;
 #pragma unroll
           for (int c = 0; c < d; ++c) h += arow[q][c] * Ll[c * d + a];
-          f.H[(size_t)k * m * d + a * m + r] = h;        // column-major [d][m]: a column's m entries contiguous
-          if (f.Hq) {
-            const int R = (m + 3) / 4;
-            f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+          if (lean) Hs[a * hstride + r] = h;             // the walk's LDS layout: column a at stride hstride
+          else {
+            f.H[(size_t)k * m * d + a * m + r] = h;      // column-major [d][m]: a column's m entries contiguous
+            if (f.Hq) {
+              const int R = (m + 3) / 4;
+              f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+            }
           }
         }
       }
@@ -440,9 +466,11 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
       double u = pre ? brow : f.b[(size_t)k * m + lane];
 #pragma unroll
       for (int c = 0; c < d; ++c) u += (pre ? Al[lane * d + c] : Ak[lane * d + c]) * mu[(size_t)kin * d + c];
-      f.u0[(size_t)k * m + lane] = u;
+      if (lean) u0s[lane] = u;
+      else f.u0[(size_t)k * m + lane] = u;
     }
   }
+  PREP_STAMP(5);
 }
 
 // the chain shapes of BASELINE.json get unrolled instances

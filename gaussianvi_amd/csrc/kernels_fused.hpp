@@ -18,7 +18,8 @@
 //             item i from LDS operands.
 // The light set rides in the shadow of the heavy one (as in moments_orbit_pair_kernel's stacked form), the latency-bound
 // phases 1 and 3 are paid once per block instead of once per launch with its ramp, and two kernel boundaries are gone.
-// The per-pass products still go to f.S / f.Sinv / f.Lam / f.H / f.u0 (a cost-only pass at the same state reuses them).
+// Nothing of the per-pass products goes to memory: S^-T, H and u0 stay in LDS between the phases (the host marks the sets'
+// products as not resident; a later pass at the same state runs its own prep).
 #pragma once
 #include "kernels_orbit.hpp"
 
@@ -72,9 +73,13 @@ __host__ __device__ inline size_t fused_region_doubles(int dmax, int M, int copi
   const size_t a = (size_t)orbit_lds_doubles(dmax, M, copies), b = fused_item_doubles(dmax);
   return ((a > b ? a : b) + 1) & ~(size_t)1;
 }
-// layout: [4 regions] [Z: items x dmax^2 (S^-T of every item)] [P: items x 4 x npairs(dmax) (chunk partials)]
+// per item, outside the regions: S^-T (phase 3), the psi operands H (walk layout) and u0 (phases 1 -> 2)
+__host__ __device__ inline size_t fused_keep_doubles(int dmax, int M) {
+  return (size_t)dmax * dmax + (size_t)dmax * orbit_hstride(M) + (size_t)(M + (M & 1));
+}
+// layout: [4 regions] [Z: items x (S^-T | H | u0)] [P: items x 4 x npairs(dmax) (chunk partials)]
 __host__ __device__ inline size_t fused_lds_doubles(int dmax, int M, int copies, int items) {
-  return 4 * fused_region_doubles(dmax, M, copies) + (size_t)items * ((size_t)dmax * dmax + 4 * (size_t)npairs(dmax));
+  return 4 * fused_region_doubles(dmax, M, copies) + (size_t)items * (fused_keep_doubles(dmax, M) + 4 * (size_t)npairs(dmax));
 }
 
 // D0 / D1: the factor dimensions of set 0 / set 1 at compile time (both sets on the Cholesky route): only the bodies of
@@ -88,6 +93,9 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
 #define FUSED_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0 && (blockIdx.x % 146) == 0) stamps[(blockIdx.x / 146) * 32 + (threadIdx.x >> 6) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FUSED_STAMP(i) do { } while (0)
+#endif
+#ifdef GVI_FUSED_TIMING
+  if (blockIdx.x == 0 && threadIdx.x == 0) gvi_prep_stamps = stamps ? stamps + 8 * 32 : nullptr;
 #endif
   FUSED_STAMP(0);
   if (pred_skip(A.tail.pred, A.tail.pred_val)) return;
@@ -104,8 +112,9 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
   const int c1 = K1 > b ? (K1 - b + A.nblk - 1) / A.nblk : 0;
   const int nitems = c0 + c1;                                  // <= FUSED_MAX_ITEMS (host)
   const size_t region = fused_region_doubles(dmax, M, copies_max);
-  double* Zbase = sm + 4 * region;                             // [items][dmax^2]
-  const size_t zs = (size_t)dmax * dmax, ps = (size_t)4 * npairs(dmax);
+  double* Zbase = sm + 4 * region;                             // [items][S^-T | H | u0]
+  const size_t zs = fused_keep_doubles(dmax, M), ps = (size_t)4 * npairs(dmax);
+  const size_t oH = (size_t)dmax * dmax, oU = oH + (size_t)dmax * orbit_hstride(M);
   double* Pbase = Zbase + (size_t)maxitems * zs;               // [items][4][npairs(dmax)]
   // ---- phase 1: wave i forms the products of item i ----
   if (wave < nitems) {
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
     double* area = sm + (size_t)wave * region;
     double* Zs = Zbase + (size_t)wave * zs;
     if (!A.gather) {
-      if (si == 0) prep_chol_body<D0>(f, S.mu, S.Sigma, k, area, k, Zs);
-      else prep_chol_body<D1>(f, S.mu, S.Sigma, k, area, k, Zs);
+      if (si == 0) prep_chol_body<D0>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
+      else prep_chol_body<D1>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
     } else {
       const int dp = d + (d & 1), n = A.n, nn = n * n;
       double* Sl = area + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;   // behind prep_body's own LDS
@@ -141,19 +150,21 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
         S.mu_k[(size_t)k * d + e] = v;
       }
       wave_lds_sync();
-      if (si == 0) prep_chol_body<D0>(f, ml, Sl, k, area, 0, Zs);
-      else prep_chol_body<D1>(f, ml, Sl, k, area, 0, Zs);
+      if (si == 0) prep_chol_body<D0>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
+      else prep_chol_body<D1>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
     }
   }
   FUSED_STAMP(1);
-  __syncthreads();                                             // H / u0 of the items are visible to the block
+  __syncthreads();                                             // S^-T / H / u0 of the items are in LDS
   FUSED_STAMP(2);
   // ---- phase 2: every wave walks its chunk of the orbit table, item after item ----
   for (int it = 0; it < nitems; ++it) {
     const int si = it < c0 ? 0 : 1;
     const int k = b + (it < c0 ? it : it - c0) * A.nblk;
     const FusedSet& S = A.s[si];
-    orbit_wave<M, SMAX, true, false, true>(S.oa, k, wave, sm + (size_t)wave * region, Pbase + (size_t)it * ps + (size_t)wave * npairs(S.f.d));
+    const double* Zi = Zbase + (size_t)it * zs;
+    orbit_wave<M, SMAX, true, false, true>(S.oa, k, wave, sm + (size_t)wave * region, Pbase + (size_t)it * ps + (size_t)wave * npairs(S.f.d),
+                                           Zi + oH, Zi + oU);
   }
   FUSED_STAMP(3);
   __syncthreads();

@@ -238,26 +238,35 @@ __device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, cons
 // FRESH: the psi operands were written earlier in THIS launch by another wave of the block (factor_fused_kernel): u0 must
 // then come through the vector path (a wave-uniform address would otherwise be served by the scalar cache, which stores of
 // this launch do not update)
+// Hpre / u0pre (LDS, optional): the psi operands of this factor as another wave of the block left them (column stride
+// orbit_hstride(M)); nothing is read from a.H / a.u0 then
 template <int M, int SMAX, bool FULL, bool SIGNED, bool FRESH = false>
-__device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, const int chunk, double* lds, double* out) {
+__device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, const int chunk, double* lds, double* out,
+                                           const double* Hpre = nullptr, const double* u0pre = nullptr) {
   const OrbitDev& ob = a.ob;
   const int lane = threadIdx.x & 63, d = a.d;
   const int NP = FULL ? (d + 1) * (d + 2) / 2 : 1;
-  double* Hl = lds;                              // [d][M]: column c of H = the M operands of coordinate c
+  const double* Hl = Hpre ? Hpre : lds;          // [d][M]: column c of H = the M operands of coordinate c
   // [NP][C] moment accumulators of this (factor, chunk): C private copies per entry, a lane adds to copy lane % C.  A
   // ds_add_f64 whose lanes hit one address costs ~3 cycles per lane (64-way: 192 cycles, tools/ubench/lds_atomic.hip);
   // with the copies and the strided orbit order (orbits.hpp) a wave instruction stays near the 8-cycle floor.
   const int C = a.copies;
-  double* accl = Hl + d * orbit_hstride(M);
-  const double* Hg = a.H + (size_t)k * M * d;    // stored [d][M] by the prep kernel
-  for (int e = lane; e < d * M; e += 64) Hl[(e / M) * orbit_hstride(M) + e % M] = Hg[e];
+  double* accl = lds + d * orbit_hstride(M);
+  if (!Hpre) {
+    const double* Hg = a.H + (size_t)k * M * d;  // stored [d][M] by the prep kernel
+    for (int e = lane; e < d * M; e += 64) lds[(e / M) * orbit_hstride(M) + e % M] = Hg[e];
+  }
   if (FULL)
     for (int e = lane; e < NP * C; e += 64) accl[e] = 0.0;
   double* accme = accl + (lane & (C - 1));
   double su0[M], sg[M], k0 = 0.0;
 #pragma unroll
   for (int r = 0; r < M; ++r) {
-    const double u = FRESH ? __builtin_nontemporal_load(a.u0 + (size_t)k * M + r) : a.u0[(size_t)k * M + r];
+    double u;
+    if (u0pre) {                                   // wave-uniform value through LDS: back into SGPRs
+      const double t = u0pre[r];
+      u = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)), __builtin_amdgcn_readfirstlane(__double2loint(t)));
+    } else u = FRESH ? __builtin_nontemporal_load(a.u0 + (size_t)k * M + r) : a.u0[(size_t)k * M + r];
     sg[r] = SIGNED ? a.sgn[(size_t)k * M + r] : 1.0;
     su0[r] = SIGNED ? sg[r] * u : u;               // unsigned: u0 itself -- a wave-uniform scalar load, it stays in SGPRs
     k0 = fma(su0[r], u, k0);
