@@ -686,7 +686,7 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
   const int dbg = getenv("GVI_FUSED_DBG") ? atoi(getenv("GVI_FUSED_DBG")) : 0;
   static unsigned long long* stamps = nullptr;
   static int nprint = 0;
-  if ((dbg & 8) && !stamps) { if (hipMalloc(&stamps, 320 * 8) != hipSuccess) stamps = nullptr; }
+  if ((dbg & 8) && !stamps) { if (hipMalloc(&stamps, 352 * 8) != hipSuccess) stamps = nullptr; else (void)hipMemset(stamps, 0, 352 * 8); }
 #else
   const int dbg = 0;
   unsigned long long* stamps = nullptr;
@@ -695,7 +695,7 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
                         (dbg & 8) ? stamps : (unsigned long long*)nullptr);
 #ifdef GVI_FUSED_TIMING
   if ((dbg & 8) && stamps && ++nprint > 200 && nprint <= 202) {          // a few warm launches, 100 MHz ticks
-    unsigned long long h[320];
+    unsigned long long h[352];
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
     fprintf(stderr, "[prep stamps] block 0 wave 0, us after the block's start: [Sigma row loaded | Cholesky | L^-1 | LDS + Lam + stores | H, u0]:");
@@ -703,11 +703,14 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
     fprintf(stderr, "\n");
     unsigned long long t0 = ~0ull;
     for (int blk = 0; blk < 8; ++blk) if (h[blk * 32] && h[blk * 32] < t0) t0 = h[blk * 32];
-    for (int blk = 0; blk < 8; ++blk) {
-      fprintf(stderr, "[fused stamps] block %4d wave 0 (absolute, us after the first start):", blk * 146);
-      for (int i = 0; i < 8; ++i) fprintf(stderr, " %.2f", (double)(long long)(h[blk * 32 + i] - t0) * 0.01);
-      fprintf(stderr, "\n");
-    }
+    for (int blk = 0; blk < 8; ++blk)
+      for (int w = 0; w < 4; ++w) {
+        const unsigned hw = (unsigned)h[320 + blk * 4 + w], xcc = (unsigned)(h[320 + blk * 4 + w] >> 32);
+        fprintf(stderr, "[fused stamps] block %4d wave %d (xcc %u se %u cu %2u simd %u slot %2u; absolute, us after the first start):", blk * 146, w,
+                xcc & 15, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %.2f", h[blk * 32 + w * 8 + i] ? (double)(long long)(h[blk * 32 + w * 8 + i] - t0) * 0.01 : -1.0);
+        fprintf(stderr, "\n");
+      }
   }
 #endif
   return GVI_OK;
@@ -2154,7 +2157,8 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
     GVICK(orbit_args(ctx, s, 1, &F.oa));
     F.oa.partial = nullptr;
     F.mu = s.mu_k[slot].d(); F.Sigma = s.Sigma_k[slot].d();
-    F.start = (const int32_t*)s.dstart.p; F.mu_k = s.mu_k[slot].d(); F.Sigma_k = s.Sigma_k[slot].d();
+    F.start = s.chain_structured ? nullptr : (const int32_t*)s.dstart.p;      // null: start[k] == k, one dependent load less
+    F.mu_k = s.mu_k[slot].d(); F.Sigma_k = s.Sigma_k[slot].d();
     F.Ephi = s.Ephi.d(); F.cost = s.cost.d(); F.Vdmu = s.Vdmu.d(); F.Vddmu = s.Vddmu.d();
     A.koff[si + 1] = A.koff[si] + s.K;
     A.cl.cost[si] = s.cost.d(); A.cl.K[si] = s.K;

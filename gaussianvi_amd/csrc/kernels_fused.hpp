@@ -98,6 +98,11 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
   if (blockIdx.x == 0 && threadIdx.x == 0) gvi_prep_stamps = stamps ? stamps + 8 * 32 : nullptr;
 #endif
   FUSED_STAMP(0);
+#ifdef GVI_FUSED_TIMING
+  if (stamps && (threadIdx.x & 63) == 0 && (blockIdx.x % 146) == 0)       // HW_ID (simd_id bits 5:4, cu_id 11:8, se_id 15:13) and XCC_ID
+    stamps[320 + (blockIdx.x / 146) * 4 + (threadIdx.x >> 6)] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
   if (pred_skip(A.tail.pred, A.tail.pred_val)) return;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = (int)blockIdx.x;
@@ -111,20 +116,36 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
   const int c0 = K0 > b ? (K0 - b + A.nblk - 1) / A.nblk : 0;
   const int c1 = K1 > b ? (K1 - b + A.nblk - 1) / A.nblk : 0;
   const int nitems = c0 + c1;                                  // <= FUSED_MAX_ITEMS (host)
+  // Which wave takes which item in phases 1 and 3.  Those phases are dependent chains of one wave per item (d = 12: 1500
+  // instructions, three times the d = 6 item) and a block has two idle waves in them, so what matters is which SIMD an item's
+  // wave sits on: the four resident blocks of a CU start their waves on the SIMDs in a rotating order, and with item i on
+  // wave i three of the four d = 12 items of a CU could share one SIMD (stamps + HW_ID of the timing build: phase 1 ended at
+  // 8 us in two residency slots and at 13 us in the other two).  The map is taken from the hardware ids instead: the wave on
+  // SIMD (slot + i) % 4 takes item i, slot = the block's wave slot on its SIMDs (distinct among the blocks of a CU).  It is
+  // a bijection whenever the block's four waves sit on four SIMDs (checked; else item i stays on wave i), and the results
+  // do not depend on it.
+  __shared__ int hw_simd[4];
+  const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);      // HW_ID.simd_id
+  const int slot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.wave_id
+  if ((threadIdx.x & 63) == 0) hw_simd[wave] = simd | (slot << 4);
+  __syncthreads();
+  const int h0 = hw_simd[0], h1 = hw_simd[1], h2 = hw_simd[2], h3 = hw_simd[3];
+  const bool spread = ((1 << (h0 & 3)) | (1 << (h1 & 3)) | (1 << (h2 & 3)) | (1 << (h3 & 3))) == 15;
+  const int iw = __builtin_amdgcn_readfirstlane(spread ? (simd - (h0 >> 4)) & 3 : wave);
   const size_t region = fused_region_doubles(dmax, M, copies_max);
   double* Zbase = sm + 4 * region;                             // [items][S^-T | H | u0]
   const size_t zs = fused_keep_doubles(dmax, M), ps = (size_t)4 * npairs(dmax);
   const size_t oH = (size_t)dmax * dmax, oU = oH + (size_t)dmax * orbit_hstride(M);
   double* Pbase = Zbase + (size_t)maxitems * zs;               // [items][4][npairs(dmax)]
   // ---- phase 1: wave i forms the products of item i ----
-  if (wave < nitems) {
-    const int si = wave < c0 ? 0 : 1;
-    const int k = b + (wave < c0 ? wave : wave - c0) * A.nblk;
+  if (iw < nitems) {
+    const int si = iw < c0 ? 0 : 1;
+    const int k = b + (iw < c0 ? iw : iw - c0) * A.nblk;
     const FusedSet& S = A.s[si];
     const FactorDev& f = S.f;
     const int d = f.d, dd = d * d, lane = threadIdx.x & 63;
     double* area = sm + (size_t)wave * region;
-    double* Zs = Zbase + (size_t)wave * zs;
+    double* Zs = Zbase + (size_t)iw * zs;
     if (!A.gather) {
       if (si == 0) prep_chol_body<D0>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
       else prep_chol_body<D1>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
@@ -132,7 +153,7 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
       const int dp = d + (d & 1), n = A.n, nn = n * n;
       double* Sl = area + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;   // behind prep_body's own LDS
       double* ml = Sl + dd;
-      const int s = S.start[k];
+      const int s = S.start ? S.start[k] : k;
       for (int e = lane; e < dd; e += 64) {
         const int r = e / d, c = e % d;
         double v;
@@ -169,21 +190,41 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
   FUSED_STAMP(3);
   __syncthreads();
   FUSED_STAMP(4);
-  if (wave >= nitems) return;
-  // ---- phase 3: wave i: ordered chunk sum, cost (+ tail), back-transform of item i ----
+  // ---- phase 3: the item's wave: ordered chunk sum, cost (+ tail), back-transform ----
+  // A block with at most two items has two idle waves here: wave (item + 2) runs the item's tail protocol (the cost needs only
+  // the m0 entries of the four chunks: same ordered sum, same division as the item's wave) while the item's wave goes straight
+  // through chunk sums and back-transform -- the ~1 us round trip of the arrival atomics leaves every item's chain.
+  const bool helpers = A.tail.on && nitems <= 2;
+  if (iw >= nitems) {
+    const int it = iw - 2;
+    if (!helpers || it < 0 || it >= nitems) return;
+    const int si = it < c0 ? 0 : 1;
+    const int k = b + (it < c0 ? it : it - c0) * A.nblk;
+    const FusedSet& S = A.s[si];
+    const double Tk = S.f.temperature[k];
+    const double* Pl = Pbase + (size_t)it * ps;
+    const int npo = npairs(S.f.d);
+    double m0 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m0 += Pl[(size_t)q * npo];      // the order of epilogue_body_t's chunk sum
+    const double costk = m0 / Tk;
+    epi_tail_arrive(A.cl, A.tail, S.cost + k, costk, (int)(threadIdx.x & 63), (unsigned)(A.koff[si] + k), (unsigned)A.koff[A.nsets],
+                    (int*)(sm + (size_t)wave * region));
+    return;
+  }
   {
-    const int si = wave < c0 ? 0 : 1;
-    const int k = b + (wave < c0 ? wave : wave - c0) * A.nblk;
+    const int si = iw < c0 ? 0 : 1;
+    const int k = b + (iw < c0 ? iw : iw - c0) * A.nblk;
     const FusedSet& S = A.s[si];
     const int d = S.f.d;
     double* area = sm + (size_t)wave * region;
-    double* Zs = Zbase + (size_t)wave * zs;
-    const double* Pl = Pbase + (size_t)wave * ps;
+    double* Zs = Zbase + (size_t)iw * zs;
+    const double* Pl = Pbase + (size_t)iw * ps;
     EpiArgs e;
     e.f = S.f; e.partial = nullptr; e.nchunk = 4; e.full = 1;
-    e.Ephi = S.Ephi; e.cost = S.cost; e.Vdmu = S.Vdmu; e.Vddmu = S.Vddmu; e.E_xmuphi = nullptr; e.E_xxphi = nullptr;
+    e.Ephi = S.Ephi; e.cost = helpers ? nullptr : S.cost; e.Vdmu = S.Vdmu; e.Vddmu = S.Vddmu; e.E_xmuphi = nullptr; e.E_xxphi = nullptr;
     auto epi = [&](int phase) { return si == 0 ? epilogue_body_t<D0>(e, k, area, phase, Pl, Zs) : epilogue_body_t<D1>(e, k, area, phase, Pl, Zs); };
-    if (!A.tail.on) { epi(0); return; }
+    if (!A.tail.on || helpers) { epi(0); return; }
     const double costk = epi(1);
     FUSED_STAMP(5);
     int* last = (int*)(area + epilogue_lds_doubles(d));

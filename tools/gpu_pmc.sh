@@ -9,7 +9,7 @@ O="gpurun_out/$R/pmc"
 mkdir -p "$O"
 run() { # name, counters...
   local name=$1; shift
-  timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$O/$name" -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS > "$O/$name.log" 2>&1 || { tail -5 "$O/$name.log"; return 1; }
+  timeout -k 10 400 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$O/$name" -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline $BENCH_ARGS > "$O/$name.log" 2>&1 || { tail -5 "$O/$name.log"; return 1; }
 }
 BENCH_ARGS="$*"
 run SQ1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES || exit 1
