@@ -247,11 +247,11 @@ struct gvi_ctx {
   const double* cur_pred = nullptr;
   double cur_pred_val = 0.0;
   DevMem pipe_dev;                    // doubles: [0..1] accept words (ring), [2..3] cost of the state in NGD slot 0 / 1
-  // GVI_PIPELINE=1 / option "pipeline": gvi_ngd_run queues iteration i + 1 (predicated) before it has read the cost of
-  // iteration i.  Off by default: measured per-iteration time is the same (129.7 vs 130.5 us at C3) because the early
-  // publish of the trial cost already gives the host its ~20 us; it removes the 4-7 us gaps that appear when the host
-  // is slowed down (e.g. under rocprofv3).
-  bool pipeline = false;
+  // Option "pipeline" (GVI_PIPELINE=0 switches it off): gvi_ngd_run queues iteration i + 1 (predicated) before it has read
+  // the cost of iteration i.  Round 2 measured no gain (129.7 vs 130.5 us per C3 iteration: the early publish of the trial
+  // cost already gave the host its head start); with the round-3 kernels the iteration is short enough for the host's
+  // hand-over to show again: 109.3 -> 107.4 us at C3, 45.8 -> 44.3 us at C2.  On by default since then.
+  bool pipeline = true;
   bool pipe_tail = false;             // tails take the accept decision on the device
   bool pipe_c0_imm = true;            // current cost as an immediate (known to the host) or from pipe_dev
   double pipe_c0 = 0.0;
@@ -2233,7 +2233,7 @@ static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot, int publish_slot = -1
 // assemble-on-load applies: every set chain-structured, the solve of this buffer will go out through the dual launch (or
 // the flushing solve), nobody needs [g | V_D | V_U] in memory before that
 static bool asm_on_load_ok(const gvi_ctx* ctx) {
-  if (!ctx->asm_on_load || dist_on(ctx) || ctx->pipeline || ctx->update_rule != GVI_RULE_NGD || ctx->sets.empty()) return false;
+  if (!ctx->asm_on_load || dist_on(ctx) || ctx->update_rule != GVI_RULE_NGD || ctx->sets.empty()) return false;
   if (!(ctx->dual_chain && ctx->side_solve && chain_supported(ctx->n) && ctx->T > 1)) return false;
   for (auto& s : ctx->sets)
     if (!s->chain_structured) return false;
@@ -2648,7 +2648,7 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
 namespace {
 struct PipeSnapshot {
   int cur, gcur, grad_slot;
-  bool grad_valid, have_trial, spec_ready, cost_valid[2], solve_deferred[2], solve_pending[2], last_first_accepted;
+  bool grad_valid, have_trial, spec_ready, cost_valid[2], solve_deferred[2], solve_pending[2], asm_pending[2], last_first_accepted;
   double cost[2];
   NgdState::GatherPending gpend[2];
   int64_t n_full, n_cost;
@@ -2662,7 +2662,7 @@ void pipe_save(const gvi_ctx* c, PipeSnapshot& p) {
   p.spec_ready = g.spec_ready; p.last_first_accepted = c->last_first_accepted;
   for (int i = 0; i < 2; ++i) {
     p.cost_valid[i] = g.cost_valid[i]; p.cost[i] = g.cost[i]; p.gpend[i] = g.gpend[i];
-    p.solve_deferred[i] = c->solve_deferred[i]; p.solve_pending[i] = c->solve_pending[i];
+    p.solve_deferred[i] = c->solve_deferred[i]; p.solve_pending[i] = c->solve_pending[i]; p.asm_pending[i] = c->asm_pending[i];
   }
   p.n_full = c->n_full_pass; p.n_cost = c->n_cost_pass; p.profile_count = c->profile_count;
   p.prep_slot.clear(); p.warm_count.clear();
@@ -2675,7 +2675,7 @@ void pipe_restore(gvi_ctx* c, const PipeSnapshot& p) {
   g.spec_ready = p.spec_ready; c->last_first_accepted = p.last_first_accepted;
   for (int i = 0; i < 2; ++i) {
     g.cost_valid[i] = p.cost_valid[i]; g.cost[i] = p.cost[i]; g.gpend[i] = p.gpend[i];
-    c->solve_deferred[i] = p.solve_deferred[i]; c->solve_pending[i] = p.solve_pending[i];
+    c->solve_deferred[i] = p.solve_deferred[i]; c->solve_pending[i] = p.solve_pending[i]; c->asm_pending[i] = p.asm_pending[i];
   }
   c->n_full_pass = p.n_full; c->n_cost_pass = p.n_cost; c->profile_count = p.profile_count;
   for (size_t i = 0; i < c->sets.size(); ++i) { c->sets[i]->prep_slot = p.prep_slot[i]; c->sets[i]->warm_count = p.warm_count[i]; }

@@ -207,9 +207,9 @@ gvi_status gvi_ngd_step(gvi_ctx* ctx, double step_size_base, int max_backtrack, 
  * one iteration and the launches of the next.  Stops early after an iteration whose backtracking was exhausted
  * (accepted = 0): optimize() then switches the temperature or declares convergence (:96-108) -- the caller's move.
  * Outputs are per iteration, any may be NULL; *iters_done counts the iterations run.  Same numbers as the same sequence
- * of gvi_ngd_step calls.  With option "pipeline" = 1 (GVI_PIPELINE=1) the launches of iteration i + 1 are queued --
- * predicated on a device-side accept word -- before the host has read the cost of iteration i (single process, chain
- * pattern on the sign-orbit kernel; otherwise the plain loop). */
+ * of gvi_ngd_step calls.  With option "pipeline" = 1 (the default; GVI_PIPELINE=0 switches it off) the launches of iteration
+ * i + 1 are queued -- predicated on a device-side accept word -- before the host has read the cost of iteration i (single
+ * process, chain pattern on the sign-orbit kernel; otherwise the plain loop). */
 gvi_status gvi_ngd_run(gvi_ctx* ctx, int max_iters, double step_size_base, int max_backtrack, double* cost_iter,
                        int* accepted, double* new_cost, int* ntrials, int* iters_done);
 /* Scheduling of gvi_ngd_step (results are identical in every mode):
