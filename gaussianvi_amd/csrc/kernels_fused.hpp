@@ -82,6 +82,39 @@ __host__ __device__ inline size_t fused_lds_doubles(int dmax, int M, int copies,
   return 4 * fused_region_doubles(dmax, M, copies) + (size_t)items * (fused_keep_doubles(dmax, M) + 4 * (size_t)npairs(dmax));
 }
 
+
+// (mu_k, Sigma_k) of factor k out of the chain arrays (the trial mean gmu + gstep gdmu formed on the fly), into LDS for the
+// prep and into the set's arrays.  Compile-time d: ALL loads of the wave are issued before the first store -- with the
+// runtime-d loop (division, three rounds of load -> store) the gather alone took 3.3 us of the launch's first phase.
+template <int DT>
+__device__ __forceinline__ void fused_gather(const FusedArgs& A, const FusedSet& S, const int k, const int lane, double* Sl, double* ml) {
+  constexpr int dd = DT * DT, NI = (dd + 63) / 64;
+  const int n = A.n, nn = n * n;
+  const int s = S.start ? S.start[k] : k;
+  double v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = lane + 64 * i, r = e / DT, c = e % DT;
+    const double* p;
+    if (r < n && c < n) p = A.SigD + (size_t)s * nn + r * n + c;
+    else if (r >= n && c >= n) p = A.SigD + (size_t)(s + 1) * nn + (r - n) * n + (c - n);
+    else if (r < n) p = A.SigU + (size_t)s * nn + r * n + (c - n);
+    else p = A.SigU + (size_t)s * nn + c * n + (r - n);
+    v[i] = e < dd ? *p : 0.0;
+  }
+  double m = 0.0;
+  if (lane < DT) {
+    const size_t j = (size_t)s * n + lane;
+    m = A.gdmu ? A.gmu[j] + A.gstep * A.gdmu[j] : A.gmu[j];
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = lane + 64 * i;
+    if (e < dd) { Sl[e] = v[i]; S.Sigma_k[(size_t)k * dd + e] = v[i]; }
+  }
+  if (lane < DT) { ml[lane] = m; S.mu_k[(size_t)k * DT + lane] = m; }
+}
+
 // D0 / D1: the factor dimensions of set 0 / set 1 at compile time (both sets on the Cholesky route): only the bodies of
 // these two shapes are compiled in -- with the runtime-d dispatch of prep_body_d / epilogue_body_p every shape's body was
 // inlined into one 230 KB kernel, whose phase 1 then ran at the speed of its instruction fetches (30 us instead of 4)
@@ -150,26 +183,11 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
       if (si == 0) prep_chol_body<D0>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
       else prep_chol_body<D1>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
     } else {
-      const int dp = d + (d & 1), n = A.n, nn = n * n;
+      const int dp = d + (d & 1);
       double* Sl = area + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;   // behind prep_body's own LDS
       double* ml = Sl + dd;
-      const int s = S.start ? S.start[k] : k;
-      for (int e = lane; e < dd; e += 64) {
-        const int r = e / d, c = e % d;
-        double v;
-        if (r < n && c < n) v = A.SigD[(size_t)s * nn + r * n + c];
-        else if (r >= n && c >= n) v = A.SigD[(size_t)(s + 1) * nn + (r - n) * n + (c - n)];
-        else if (r < n) v = A.SigU[(size_t)s * nn + r * n + (c - n)];
-        else v = A.SigU[(size_t)s * nn + c * n + (r - n)];
-        Sl[e] = v;
-        S.Sigma_k[(size_t)k * dd + e] = v;
-      }
-      for (int e = lane; e < d; e += 64) {
-        const size_t j = (size_t)s * n + e;
-        const double v = A.gdmu ? A.gmu[j] + A.gstep * A.gdmu[j] : A.gmu[j];
-        ml[e] = v;
-        S.mu_k[(size_t)k * d + e] = v;
-      }
+      if (si == 0) fused_gather<D0>(A, S, k, lane, Sl, ml);
+      else fused_gather<D1>(A, S, k, lane, Sl, ml);
       wave_lds_sync();
       if (si == 0) prep_chol_body<D0>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
       else prep_chol_body<D1>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));

@@ -67,7 +67,7 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 
 // one orbit per lane, support size S (all lanes of the wave: tiles are uniform in S)
 template <int M, int S, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_walk(const int d, const int C, const uint64_t cpk, const double (&mg)[S], const double w,
+__device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint64_t cpk, const double (&mg)[S], const double w,
                                            const double* Hl, double* accl, const double (&su0)[M], const double (&sg)[M],
                                            const double k0, double& m0) {
   int c[S];
@@ -207,31 +207,32 @@ __device__ __forceinline__ void orbit_walk(const int d, const int C, const uint6
   const double wp = w + w;
   m0 = fma(wp, E0, m0);
   if (FULL) {
-    // accl points at this lane's copy: entry e lives at accl[e * C]
+    // accl points at this lane's copy: entry e lives at accl[e * C], C = 1 << lc.  Index arithmetic in shifts and 24-bit
+    // multiplies: v_mul_lo_u32 is a quarter-rate instruction and the s = 4 tile had 18 of them (288 of its 1560 VALU cycles)
     const double w4 = wp + wp;
     int e = 0;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       const int a = c[i];
       const double wm = wp * mg[i];
-      lds_add_f64(accl + (1 + a) * C, w4 * mg[i] * Oi[i]);
-      const int row = 1 + d + a * d - a * (a - 1) / 2 - a;       // packed index of (a, b) = row + b
-      lds_add_f64(accl + (row + a) * C, wm * mg[i] * E0);
+      lds_add_f64(accl + ((1 + a) << lc), w4 * mg[i] * Oi[i]);
+      const int row = 1 + d + __mul24(a, d) - (__mul24(a, a - 1) >> 1) - a;       // packed index of (a, b) = row + b
+      lds_add_f64(accl + ((row + a) << lc), wm * mg[i] * E0);
 #pragma unroll
-      for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + (row + c[j]) * C, wm * mg[j] * Eij[e]); ++e; }
+      for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + ((row + c[j]) << lc), wm * mg[j] * Eij[e]); ++e; }
     }
   }
 }
 
 template <int M, int S, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, const int C, const int64_t o, const double* Hl, double* accl,
+__device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, const int lc, const int64_t o, const double* Hl, double* accl,
                                            const double (&su0)[M], const double (&sg)[M], const double k0, double& m0) {
   const uint64_t cpk = ob.cpk[o];
   const double w = ob.w[o];
   double mg[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) mg[j] = ob.mag[(size_t)j * ob.norb_p + o];
-  orbit_walk<M, S, FULL, SIGNED>(d, C, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
+  orbit_walk<M, S, FULL, SIGNED>(d, lc, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
 }
 
 // out: where the chunk's partial sums go -- the set's partial array (stand-alone launches) or LDS (factor_fused_kernel).
@@ -250,7 +251,7 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   // [NP][C] moment accumulators of this (factor, chunk): C private copies per entry, a lane adds to copy lane % C.  A
   // ds_add_f64 whose lanes hit one address costs ~3 cycles per lane (64-way: 192 cycles, tools/ubench/lds_atomic.hip);
   // with the copies and the strided orbit order (orbits.hpp) a wave instruction stays near the 8-cycle floor.
-  const int C = a.copies;
+  const int C = a.copies, lc = __builtin_ctz((unsigned)C);      // (a power of two: launch_orbit / gvi_set_option)
   double* accl = lds + d * orbit_hstride(M);
   if (!Hpre) {
     const double* Hg = a.H + (size_t)k * M * d;  // stored [d][M] by the prep kernel
@@ -278,14 +279,14 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
     const int s = __builtin_amdgcn_readfirstlane(ob.tile_s[t]);
     const int64_t o = (int64_t)ob.tile_first[t] + lane;
     if constexpr (SMAX > 4) {
-      if (s == 6) { orbit_tile<M, 6, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); continue; }
-      if (s == 5) { orbit_tile<M, 5, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); continue; }
+      if (s == 6) { orbit_tile<M, 6, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); continue; }
+      if (s == 5) { orbit_tile<M, 5, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); continue; }
     }
     switch (s) {
-      case 1: orbit_tile<M, 1, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
-      case 2: orbit_tile<M, 2, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
-      case 3: orbit_tile<M, 3, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
-      default: orbit_tile<M, 4, FULL, SIGNED>(ob, d, C, o, Hl, accme, su0, sg, k0, m0); break;
+      case 1: orbit_tile<M, 1, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
+      case 2: orbit_tile<M, 2, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
+      case 3: orbit_tile<M, 3, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
+      default: orbit_tile<M, 4, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
     }
   }
 #pragma unroll
