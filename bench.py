@@ -29,6 +29,7 @@ What the JSON line reports
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -334,6 +335,11 @@ def main():
         step_fn(); pos += 1
     barrier()
     ctx.ngd_counters(reset=True)
+    # No cyclic-GC pass of the interpreter inside the timed region (what timeit does): with torch imported a full collection
+    # walks ~10^6 objects and takes ~40 ms -- observed as ONE restart block of 6.35 ms per step among 84 blocks of 0.11 ms in a
+    # planar1k run (0.205 instead of 0.13 ms per step), and as the occasional 0.17 ms c3 line.
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     kern_ms, log, block_ms = [], [], []
     if single and not args.per_step_calls:
@@ -364,6 +370,7 @@ def main():
                     pass
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     n_full, n_cost = ctx.ngd_counters()
 
     # A/B leg (not part of `value`): the reference's pass order -- a cost-only pass per trial and a separate
@@ -457,10 +464,13 @@ def main():
         t_build = time.perf_counter() - t_build
         barrier()
         ctx5.ngd_counters(reset=True)
+        gc.collect()
+        gc.disable()
         t5 = time.perf_counter()
         log5 = [ctx5.ngd_step(0.55, 10) for _ in range(2)]
         barrier()
         t5 = time.perf_counter() - t5
+        gc.enable()
         f5, c5c = ctx5.ngd_counters()
         ev5 = sum(K * N for (K, d, p, N) in ctx5.sets)
         st5 = torch.tensor([t5, float((f5 + c5c) * ev5)], dtype=torch.float64, device="cuda")
