@@ -547,17 +547,19 @@ def main():
             executed_note = ("fp64 VALU instructions per 64-point step counted in the ISA of the instance (REG_KERNEL_FP64_PER_EVAL), each as one "
                              "FMA = 2 flop; the SDF look-up adds 4 x 8 B of gathered reads per evaluation from L2")
         traffic, traffic_source, valu_issue = None, None, None
-        tpath = os.path.join(ROOT, TRAFFIC_FILE)
-        if args.config == "c3" and world == 1 and os.path.exists(tpath):
+        # PMC passes are separate runs (tools/gpu_pmc.sh); their per-launch figures are committed per config
+        tfile = TRAFFIC_FILE if args.config == "c3" else TRAFFIC_FILE.replace(".json", f"_{args.config}.json")
+        tpath = os.path.join(ROOT, tfile)
+        if world == 1 and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if kernel_name.split("<")[0] in tj.get("kernel", ""):     # counters of the kernel that actually ran
                     traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_source = (f"{TRAFFIC_FILE} (git blob {git_blob_sha1(tpath)}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                    traffic_source = (f"{tfile} (git blob {git_blob_sha1(tpath)}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                       "command; not re-measured in this run)")
                     valu_issue = {"busy_frac": tj["derived"]["valu_pipe_busy"], "valu_instructions_per_launch": tj["sq"]["SQ_INSTS_VALU"],
                                   "wait_frac_of_wave_cycles": tj["derived"]["wait_fraction_of_wave_cycles"],
-                                  "source": TRAFFIC_FILE + " (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles; counts every VALU "
+                                  "source": tfile + " (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / kernel cycles; counts every VALU "
                                             "instruction, fp64 or integer -- the resource this kernel is bound by)"}
             except Exception:
                 traffic = None
