@@ -784,6 +784,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   a.f = s.dev(); a.mu = mu; a.psi_ext = psi_ext; a.partial = s.partial.d();
   a.chunk = s.chunk; a.nchunk = s.nchunk; a.full = full; a.flush = c->split_flush;
   a.mchunk = 0;
+  a.pred = c->cur_pred; a.pred_val = c->cur_pred_val;
   if (s.table->Nmp > 0) {                                   // same number of chunks over the mirror-half table
     const int64_t tiles = s.table->Nmp / 64;
     a.mchunk = (tiles + s.nchunk - 1) / s.nchunk * 64;
@@ -2236,7 +2237,7 @@ static bool asm_on_load_ok(const gvi_ctx* ctx) {
   if (!ctx->asm_on_load || dist_on(ctx) || ctx->update_rule != GVI_RULE_NGD || ctx->sets.empty()) return false;
   if (!(ctx->dual_chain && ctx->side_solve && chain_supported(ctx->n) && ctx->T > 1)) return false;
   for (auto& s : ctx->sets)
-    if (!s->chain_structured) return false;
+    if (!s->chain_structured && !(s->d == ctx->n && s->K <= ASM_SPARSE_MAX)) return false;    // (sparse unary sets: AsmSet::sp)
   return true;
 }
 
@@ -2246,6 +2247,11 @@ static AsmList make_asm_list(gvi_ctx* ctx) {
   for (int i = 0; i < L.nsets; ++i) {
     FactorSet& s = *ctx->sets[i];
     L.s[i].K = s.K; L.s[i].d = s.d; L.s[i].Vdmu = s.Vdmu.d(); L.s[i].Vddmu = s.Vddmu.d();
+    L.s[i].nsp = 0;
+    if (!s.chain_structured) {
+      L.s[i].nsp = s.K;
+      for (int k = 0; k < s.K && k < ASM_SPARSE_MAX; ++k) L.s[i].sp[k] = s.start[k];
+    }
   }
   return L;
 }
@@ -2681,16 +2687,16 @@ void pipe_restore(gvi_ctx* c, const PipeSnapshot& p) {
   for (size_t i = 0; i < c->sets.size(); ++i) { c->sets[i]->prep_slot = p.prep_slot[i]; c->sets[i]->warm_count = p.warm_count[i]; }
 }
 
-// every launch of a queued iteration must be one of the predicated kernels: the dual chain launches, the prep launch with
-// the fused gather, the two-set sign-orbit launch, the epilogue with its tail, the assemble
+// every launch of a queued iteration must be one of the predicated kernels: the dual chain launches, the fused factor pass or
+// the prep launch with the fused gather + the sets' moments launches (every MomArgs / OrbitArgs kernel) + the epilogue with its
+// tail, the assemble
 bool pipe_ok(const gvi_ctx* c) {
   if (!c->pipeline || dist_on(c) || c->update_rule != GVI_RULE_NGD || !c->speculate || c->fuse_trial == 0) return false;
   if (!(c->dual_chain && c->side_solve && chain_supported(c->n) && c->T > 1)) return false;
-  if (!c->fuse_gather || !c->pair_fuse || c->profile_all || c->sets.size() != 2) return false;
-  const FactorSet& s0 = *c->sets[0];
-  const FactorSet& s1 = *c->sets[1];
-  return orbit_supported(c, s0) && orbit_supported(c, s1) && s0.m == s1.m && s0.all_pos && s1.all_pos && !s0.closed_form &&
-         !s1.closed_form && s0.K > 0 && s1.K > 0;
+  if (!c->fuse_gather || !c->pair_fuse || c->profile_all || c->sets.empty() || (int)c->sets.size() > MAX_SETS) return false;
+  for (const auto& s : c->sets)
+    if (s->K <= 0 || s->kind == KIND_HOST_CALLBACK) return false;       // (host-evaluated psi: the host is in the loop anyway)
+  return true;
 }
 }  // namespace
 

@@ -100,7 +100,10 @@ struct ChainArgs {
 // Chain-structured factor sets for the assemble-on-load: factor k of a binary set (d = 2n) couples states k, k + 1, factor
 // k of a unary set (d = n) sits on state k -- start[k] = k, so no CSR indirection (three INDEPENDENT loads per element
 // instead of ptr -> idx -> value).  Other graphs keep the stand-alone assemble launch.
-struct AsmSet { int K, d; const double* Vdmu; const double* Vddmu; };
+// nsp > 0: a SPARSE unary set (d = n) of nsp <= ASM_SPARSE_MAX factors on arbitrary states sp[] (the anchors of a planning
+// graph: start / goal): compared against immediates, no index load
+constexpr int ASM_SPARSE_MAX = 4;
+struct AsmSet { int K, d; const double* Vdmu; const double* Vddmu; int nsp; int sp[ASM_SPARSE_MAX]; };
 struct AsmList { int nsets; AsmSet s[MAX_SETS]; };
 
 // element (r, c) of V_D[t] (which = 0) / V_U[t] (which = 1), or entry r of g[t] (which = 2): bt_scatter_all_kernel's sums
@@ -111,7 +114,15 @@ __device__ __forceinline__ double asm_element(const AsmList& L, const int n, con
     const int d = a.d;
     const bool two = d == 2 * n;
     double s = 0.0;
-    if (which == 2) {
+    if (a.nsp > 0) {                                   // sparse unary set: factor k sits on state sp[k] (ascending k = CSR order)
+#pragma unroll
+      for (int k = 0; k < ASM_SPARSE_MAX; ++k) {
+        if (k < a.nsp && a.sp[k] == t) {
+          if (which == 2) s += a.Vdmu[(size_t)k * d + r];
+          else if (which == 0) s += a.Vddmu[(size_t)k * d * d + r * d + c];
+        }
+      }
+    } else if (which == 2) {
       if (t < a.K) s += a.Vdmu[(size_t)t * d + r];
       if (two && t > 0 && t - 1 < a.K) s += a.Vdmu[(size_t)(t - 1) * d + n + r];
     } else if (which == 0) {

@@ -763,6 +763,8 @@ struct MomArgs {
   int full;                // 1: all moments, 0: m0 only (cost pass)
   int flush;               // split kernel: steps between second-level flushes (SPLIT_FLUSH; 0 = plain recursive sums, A/B only)
   int64_t mchunk;          // mirror-half table: representatives per chunk (same nchunk)
+  const double* pred;      // predicated launch (device_common.hpp, pred_skip) or null
+  double pred_val;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -773,6 +775,7 @@ struct MomArgs {
 // sigma-point kernels, so the epilogue (back-transform, Lambda, temperature) is shared.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void moments_closed_kernel(MomArgs a) {
+  if (pred_skip(a.pred, a.pred_val)) return;
   const FactorDev& f = a.f;
   const int d = f.d, m = f.m, k = blockIdx.x;
   const double* H = f.H + (size_t)k * d * m;      // [d][m]
@@ -809,6 +812,7 @@ constexpr int GEN_BS = 256;
 constexpr int GEN_MAX_OUT = 3;   // outputs per thread: npairs(d) <= 768 -> d <= 37
 
 __global__ __launch_bounds__(GEN_BS) void moments_generic_kernel(MomArgs a) {
+  if (pred_skip(a.pred, a.pred_val)) return;
   extern __shared__ double sm[];
   const FactorDev& f = a.f;
   const int d = f.d, m = f.m, k = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
@@ -990,6 +994,7 @@ template <int D> using PsiHingeSdf2D = PsiHingeSdf<D, KIND_HINGE_SDF_2D>;
 
 template <int D, typename Psi, bool FULL>
 __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
+  if (pred_skip(a.pred, a.pred_val)) return;
   constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
   constexpr int NB = (NP + 15) / 16;
   __shared__ double hs[4][Psi::LDS];
@@ -1305,6 +1310,7 @@ constexpr int SPLIT_LDS_DOUBLES(int D) { return 256 + 2 * D + 8 + 2 * 4 * 64 + 4
 
 template <int D, int R, bool FULL>
 __global__ __launch_bounds__(256, 2) void moments_split_kernel(MomArgs a) {
+  if (pred_skip(a.pred, a.pred_val)) return;
   extern __shared__ double sm[];
   double* lut = sm;                        // [256]
   double* hs = lut + 256;                  // u0 [4 R] | sgn [4 R]  (rows >= m: 0)
@@ -1636,6 +1642,7 @@ __device__ __forceinline__ void sreg_pipe_dispatch(const MomArgs& a, const int b
 // argument the compiler may take 256 + spill AGPRs and silently halve the occupancy
 template <int D, int M, bool FULL, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void moments_sreg_kernel(MomArgs a) {
+  if (pred_skip(a.pred, a.pred_val)) return;
   __shared__ double us[4 * 2 * M];
   __shared__ double red[4 * 16 * 65];
   if constexpr (FULL && PIPE) sreg_pipe_dispatch<D, M>(a, blockIdx.x, blockIdx.y, us, red);
@@ -1647,6 +1654,7 @@ __global__ __launch_bounds__(256, 2) void moments_sreg_kernel(MomArgs a) {
 // blocks fill the tail of the large one.  Blocks [0, nb0) belong to set 0 (x fastest), the rest to set 1.
 template <int D0, int M0, int D1, int M1, bool FULL, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void moments_sreg_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
+  if (pred_skip(a0.pred, a0.pred_val)) return;
   constexpr int MM = M0 > M1 ? M0 : M1;
   __shared__ double us[4 * 2 * MM];
   __shared__ double red[4 * 16 * 65];
@@ -1777,12 +1785,14 @@ __device__ __forceinline__ void scost_body(const MomArgs& a, const int bx, const
 
 template <int D, int M, int F>
 __global__ __launch_bounds__(256) void moments_scost_kernel(MomArgs a) {
+  if (pred_skip(a.pred, a.pred_val)) return;
   __shared__ double us[4 * F * 3 * M];
   scost_body<D, M, F>(a, blockIdx.x, blockIdx.y, us);
 }
 
 template <int D0, int M0, int D1, int M1, int F>
 __global__ __launch_bounds__(256) void moments_scost_pair_kernel(MomArgs a0, MomArgs a1, int nbx0, int nb0, int nbx1) {
+  if (pred_skip(a0.pred, a0.pred_val)) return;
   constexpr int MM = M0 > M1 ? M0 : M1;
   __shared__ double us[4 * F * 3 * MM];
   const int b = blockIdx.x;
