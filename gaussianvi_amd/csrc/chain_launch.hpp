@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "kernels_chain.hpp"
+#include "kernels_chain_wave.hpp"
 
 namespace gvi {
 
@@ -106,6 +107,11 @@ inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1
   return hipGetLastError();
 }
 
+// Short chains of 2 x 2 blocks (T <= 65, n <= 2) run lane-per-node in ONE wave per operation (kernels_chain_wave.hpp);
+// chain_wave_enabled() = false keeps them on the generic kernels (A/B leg, GVI_CHAIN_WAVE=0)
+inline bool& chain_wave_enabled() { static bool on = true; return on; }
+inline bool chain_wave_applies(int T, int n) { return chain_wave_enabled() && n >= 1 && n <= chain_wave::WN && T >= 1 && T <= chain_wave::WT_MAX; }
+
 // n: the caller's block size (a0.n / a1.n are set here).  AL: the factor sets of an assemble-on-load (a0.asm_on / a1.asm_on), else null
 inline hipError_t chain_launch(int n, const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st,
                                const AsmList* AL = nullptr) {
@@ -113,6 +119,12 @@ inline hipError_t chain_launch(int n, const ChainPlan& pl, ChainArgs a0, ChainAr
   AsmList none{};
   const AsmList& L = AL ? *AL : none;
   if (!AL) a0.asm_on = a1.asm_on = 0;
+  if (chain_wave_applies(on0 ? a0.T : a1.T, n)) {
+    const int nb0 = on0 ? 1 : 0, nb = nb0 + (on1 ? 1 : 0);
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(chain_wave_kernel, dim3(nb), dim3(64), 0, st, a0, a1, nb0, L);
+    return hipGetLastError();
+  }
   switch (chain_padded(n)) {
     case 1: return chain_launch_t<1>(pl, a0, a1, on0, on1, st, L);
     case 2: return chain_launch_t<2>(pl, a0, a1, on0, on1, st, L);

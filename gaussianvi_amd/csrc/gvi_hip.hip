@@ -989,6 +989,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_FUSED")) c->fused = atoi(w) != 0;
   if (const char* w = getenv("GVI_ASM_ON_LOAD")) c->asm_on_load = atoi(w) != 0;
   if (const char* w = getenv("GVI_PIPELINE")) c->pipeline = atoi(w) != 0;
+  if (const char* w = getenv("GVI_CHAIN_WAVE")) chain_wave_enabled() = atoi(w) != 0;     // (process-wide: A/B leg of kernels_chain_wave.hpp)
   if (const char* w = getenv("GVI_CHOL_SQRT")) c->chol_sqrt = atoi(w) != 0;
   if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
   if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
@@ -3141,6 +3142,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "fused") ctx->fused = value != 0;
   else if (n == "assemble_on_load") ctx->asm_on_load = value != 0;
   else if (n == "pipeline") ctx->pipeline = value != 0;
+  else if (n == "chain_wave") chain_wave_enabled() = value != 0;
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") {
     // the threshold compares SQUARED off-diagonal mass with squared diagonal mass: anything looser than 1e-20 (1e-10 relative)

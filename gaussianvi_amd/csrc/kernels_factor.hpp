@@ -2072,7 +2072,9 @@ __device__ __forceinline__ void epi_tail_arrive(const CostList& cl, const EpiTai
     int l = 0;
     if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
       __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-      l = __hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
+      // (a single group -- <= EPI_GROUP factors, BASELINE configs[1] -- needs no second level: one atomic round trip less
+      // on the chain that ends in the publish)
+      l = ngrp == 1 ? 1 : (__hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1);
     }
     *last = l;
   }

@@ -325,8 +325,10 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * sum, cost and back-transform of a factor in one workgroup; 0: the three launches prep -> psi -> epilogue),
  * "jacobi_tol_exp" (stopping threshold 10^value of the symmetric-root solve, on SQUARED off-diagonal / diagonal mass; values
  * above -20 return GVI_ERR_ARG -- the environment form GVI_JACOBI_TOL_EXP clamps to -20 instead).
+ * chain_wave (default 1; process-wide, environment GVI_CHAIN_WAVE): chains of T <= 65 states of size n <= 2 run on the
+ * lane-per-node kernel (one wave per chain operation) instead of the generic block-cyclic-reduction kernels.
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,
- * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline. */
+ * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline, chain_wave. */
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus
