@@ -134,6 +134,35 @@ __device__ __forceinline__ double asm_element(const AsmList& L, const int n, con
   return acc;
 }
 
+// asm_element for the two elements a thread of the load phase handles, (V_D, V_U) of each, in ONE sweep over the sets: every
+// load of a set is issued before the first add.  asm_element's loop waits for its loads inside every iteration, so four calls
+// in a row were up to 4 x nsets dependent round trips in front of a pass's first level.  Same sums, same order.
+__device__ __forceinline__ void asm_pair(const AsmList& L, const int n, const int (&t)[2], const int (&r)[2], const int (&c)[2],
+                                         const bool (&onD)[2], const bool (&onU)[2], double (&vD)[2], double (&vU)[2]) {
+  vD[0] = vD[1] = vU[0] = vU[1] = 0.0;
+  for (int si = 0; si < L.nsets; ++si) {
+    const AsmSet& a = L.s[si];
+    const int d = a.d;
+    const bool two = d == 2 * n;
+    double d0[2] = {0.0, 0.0}, d1[2] = {0.0, 0.0}, u0[2] = {0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!onD[u]) continue;
+      if (a.nsp > 0) {
+#pragma unroll
+        for (int k = 0; k < ASM_SPARSE_MAX; ++k)
+          if (k < a.nsp && a.sp[k] == t[u]) d0[u] += a.Vddmu[(size_t)k * d * d + r[u] * d + c[u]];
+      } else {
+        if (t[u] < a.K) d0[u] = a.Vddmu[(size_t)t[u] * d * d + r[u] * d + c[u]];
+        if (two && t[u] > 0 && t[u] - 1 < a.K) d1[u] = a.Vddmu[(size_t)(t[u] - 1) * d * d + (n + r[u]) * d + n + c[u]];
+        if (onU[u] && two && t[u] < a.K) u0[u] = a.Vddmu[(size_t)t[u] * d * d + r[u] * d + n + c[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { vD[u] += (0.0 + d0[u]) + d1[u]; vU[u] += 0.0 + u0[u]; }
+  }
+}
+
 #ifndef GVI_CHAIN_THREADS_SMALL
 #define GVI_CHAIN_THREADS_SMALL 1024
 #endif
@@ -530,6 +559,22 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
   for (int e0 = tid; e0 < cnt * nn; e0 += 2 * nthr) {
     double dv[2], cu[2];
     bool on[2], hasc[2];
+    // assemble-on-load: the V_D / V_U elements of both elements of this round in one sweep over the factor sets
+    double aD[2] = {0.0, 0.0}, aU[2] = {0.0, 0.0};
+    if (first && a.asm_on) {
+      int at[2], ar[2], ac[2];
+      bool aon[2], aonU[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = e0 + u * nthr;
+        const bool o = e < cnt * nn;
+        const int j = o ? e / nn : 0, el = o ? e % nn : 0, x = x0 + j * st;
+        const int xe = ext_el<N>(a.n, el);
+        at[u] = x; ar[u] = xe >= 0 ? xe / a.n : 0; ac[u] = xe >= 0 ? xe % a.n : 0;
+        aon[u] = o && xe >= 0; aonU[u] = aon[u] && x + st < T;
+      }
+      asm_pair(AL, a.n, at, ar, ac, aon, aonU, aD, aU);
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {                   // all loads of the round are issued before the first use
       const int e = e0 + u * nthr;
@@ -544,16 +589,10 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
           const int xe = ext_el<N>(a.n, el);
           const size_t ge = (size_t)x * (a.n * a.n) + xe, gu = (size_t)(T + x) * (a.n * a.n) + xe;
           const bool asmv = a.asm_on != 0 && xe >= 0;
-          const int er = xe >= 0 ? xe / a.n : 0, ec = xe >= 0 ? xe % a.n : 0;
-          double vD = 0.0, vU = 0.0;
-          if (asmv) {                                     // assembled V_D / V_U element (independent loads, issued with the rest)
-            vD = asm_element(AL, a.n, x, 0, er, ec);
-            if (hasc[u]) vU = asm_element(AL, a.n, x, 1, er, ec);
-          }
+          const double vD = aD[u], vU = aU[u];
           if (HAS_Y && asmv) {                            // the solve operates ON the assembled matrix and leaves it in memory
-            dv[u] = vD;
-            a.asmD[ge] = vD;
-            if (hasc[u]) { cu[u] = vU; a.asmU[ge] = vU; }
+            dv[u] = vD;                                   // (written out with the other stores of the round, below)
+            if (hasc[u]) cu[u] = vU;
           } else {
             dv[u] = xe >= 0 ? a.D[ge] : ((el / N == el % N) ? 1.0 : 0.0);                            // identity padding
             if (mix && xe >= 0) { const double mv = asmv ? vD : a.mixV[ge]; dv[u] = dv[u] + a.mix_step * (mv - dv[u]); }   // trial_kernel's arithmetic
@@ -580,6 +619,10 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
         const int xe = first ? ext_el<N>(a.n, el) : -1;
         sm[oDl + e] = dv[u];
         if (mix && xe >= 0) a.mixOut[(size_t)x * (a.n * a.n) + xe] = dv[u];
+        if (HAS_Y && first && a.asm_on && xe >= 0) {
+          a.asmD[(size_t)x * (a.n * a.n) + xe] = dv[u];
+          if (hasc[u]) a.asmU[(size_t)x * (a.n * a.n) + xe] = cu[u];
+        }
         if (j == 0 && !TOP) ws_mat<N>(a, W_DEFF)[g] = dv[u];             // the survivor's base for the next pass
         if (hasc[u]) {
           if (first) { const int r = el / N, c = el % N; sm[oCt + j * nn + c * N + r] = cu[u]; }   // transposed
