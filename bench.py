@@ -639,10 +639,10 @@ def main():
             out["c5_strong"] = c5_block
             # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU stage times of round 3
             # (profiles/r03_*): the factor pass W shards, the chain operations + assemble R are replicated, the exchange X is added.
-            W, R, X = 0.046, 0.062, 0.030                     # ms; round-3 constants (profiles/r03_a_kernel_stats.csv), not measured in this run
+            W, R, X = 0.043, 0.062, 0.030                     # ms; round-3 constants (profiles/r03_f_kernel_stats_c3.csv), not measured in this run
             out["strong_scaling_model"] = {"W_ms_sharded": W, "R_ms_replicated": R, "X_ms_exchange": X,
                                            "expected_speedup_at_n": (W + R) / (W / world + R + X),
-                                           "constants": "round-3 one-GPU kernel times (profiles/r03_a_kernel_stats.csv); not re-measured here",
+                                           "constants": "round-3 one-GPU kernel times (profiles/r03_f_kernel_stats_c3.csv: factor pass 43 us; chain passes 18 + 22 + 8 us, stand-alone assemble 7.5 us and the host hand-over of the non-pipelined sharded iteration); not re-measured here",
                                            "note": "t(N) = W / N + R + X; the ceiling as N grows is (W + R) / (R + X)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds, dom if not chain_pattern else 0)
