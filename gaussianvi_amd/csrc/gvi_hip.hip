@@ -1822,11 +1822,21 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out, double seq_exp
   // Spin on the host-mapped sequence word: a blocking stream sync costs tens of us of wake-up latency and would
   // also wait for the speculative work queued behind the publish.  The spin is bounded by WALL TIME (2 ms -- an
   // iteration is < 1 ms); past that the wait sleeps between polls (below).
-  volatile double* slot = ctx->host_slot + 2 * rg;
+  // {value, sequence} is ONE 16-byte device store (publish_to_host) and is read here with ONE 16-byte load (movdqa: a single
+  // access on every AVX-capable x86), so value and sequence always belong to the same publish -- no "new sequence, old value"
+  // window between two 8-byte loads
+  const double* slot = ctx->host_slot + 2 * rg;
+  typedef double v2d __attribute__((vector_size(16), aligned(16)));
+  auto poll = [&](double* val) {
+    const v2d both = *(const volatile v2d*)(const void*)slot;        // (volatile: re-read at every poll)
+    *val = both[0];
+    return both[1] == want;
+  };
   bool seen = false;
+  double v = 0.0;
   const auto t0 = std::chrono::steady_clock::now();
   for (long spins = 0;; ++spins) {
-    if (slot[1] == want) { seen = true; break; }
+    if (poll(&v)) { seen = true; break; }
     cpu_relax();
     if ((spins & 1023) == 1023 &&
         std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(ctx->spin_ms)) break;
@@ -1835,7 +1845,7 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out, double seq_exp
     // long passes (config 5: seconds per pass): sleep-poll the word and, every millisecond, the stream itself, so a
     // device fault or a drained stream without a publish ends the wait with an error instead of spinning
     for (long polls = 0;; ++polls) {
-      if (slot[1] == want) { seen = true; break; }
+      if (poll(&v)) { seen = true; break; }
       std::this_thread::sleep_for(std::chrono::microseconds(20));
       if ((polls & 63) == 63) {
         const hipError_t q = hipStreamQuery(ctx->stream);
@@ -1843,12 +1853,11 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out, double seq_exp
         if (q != hipErrorNotReady) return fail(ctx, GVI_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
       }
     }
-    if (!seen && slot[1] != want)
+    if (!seen && !poll(&v))
       return fail(ctx, GVI_ERR_STATE, "cost publish did not arrive (sequence word stale after the stream drained)");
   }
   __sync_synchronize();
-  const double v = slot[0];                          // cost_value = sum of factor costs + 1/2 log det (added on the device)
-  g.cost[i] = v;
+  g.cost[i] = v;                                     // cost_value = sum of factor costs + 1/2 log det (added on the device)
   g.cost_valid[i] = true;
   if (out) *out = v;
   return GVI_OK;

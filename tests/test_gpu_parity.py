@@ -1167,6 +1167,39 @@ def test_ngd_run_equals_the_same_sequence_of_steps(name):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["tiny", "c2"])
+def test_lane_per_node_chain_kernel_matches_the_generic_chain_kernels(name):
+    """kernels_chain_wave.hpp (lane = node, one wave per chain operation; T <= 65, n <= 2) against kernels_chain.hpp on the same
+    chains: chain operators (log-det, marginals, solve) to 1e-13 and six NGD iterations with the same accept decisions, costs
+    to 1e-12.  Same elimination tree and the same arithmetic per node; the log-det's pivot product is reduced in another
+    order, hence not bit for bit.  The switch is process-wide: restored in any case."""
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    try:
+        res = []
+        for wave in (1, 0):
+            ctx.set_option("chain_wave", wave)
+            fac = (np.array([ctx.bt_logdet(ch["D0"], ch["U0"])]),) + tuple(ctx.bt_marginals(ch["D0"], ch["U0"]))
+            rhs = np.random.default_rng(3).normal(size=(ch["T"], ch["n"]))
+            x = ctx.bt_solve(ch["D0"], ch["U0"], rhs)
+            ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+            log = ctx.ngd_run(6, 0.9, 10)
+            res.append((fac, x, log, ctx.ngd_get_state()))
+    finally:
+        ctx.set_option("chain_wave", 1)
+        ctx.close()
+    (fa, xa, la, sa), (fb, xb, lb, sb) = res
+    for u, v in zip(fa, fb):
+        assert rel(np.asarray(u), np.asarray(v)) < 1e-13
+    assert rel(xa, xb) < 1e-13
+    assert len(la) == len(lb)
+    for a, b in zip(la, lb):
+        assert a["accepted"] == b["accepted"] and a["ntrials"] == b["ntrials"]
+        assert abs(a["new_cost"] - b["new_cost"]) <= 1e-12 * abs(b["new_cost"])
+    for k in sb:
+        assert rel(sa[k], sb[k]) < 1e-10, k
+
+
 def test_asymmetric_user_table_keeps_the_unpaired_kernel():
     """gvi_factors_set_table with a table that is NOT mirror-symmetric (one weight perturbed): the +-pairing must not be
     used; results follow the oracle on that very table."""
