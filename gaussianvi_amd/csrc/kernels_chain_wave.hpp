@@ -119,11 +119,16 @@ __device__ __forceinline__ void asm_node(const AsmList& L, const int n, const in
 #pragma unroll
   for (int i = 0; i < 4; ++i) A.D[i] = A.U[i] = B.D[i] = B.U[i] = 0.0;
   A.g[0] = A.g[1] = B.g[0] = B.g[1] = 0.0;
-  for (int si = 0; si < L.nsets; ++si) {
+  for (int si = 0; si < L.nsets; si += 2) {           // two sets per round: their loads are in flight together
+    const bool second = si + 1 < L.nsets;
     const AsmSet& a = L.s[si];
+    const AsmSet& b = L.s[second ? si + 1 : si];
     double d0[4], d1[4], u0[4], g0[2], g1[2], e0[4], e1[4], w0[4], h0[2], h1[2];
+    double p0[4], p1[4], q0[4], r0[2], r1[2], s0[4], s1[4], x0[4], y0[2], y1[2];
     asm_loads(a, n, t, on, hasc, d0, d1, u0, g0, g1);
     asm_loads(a, n, t2, on2, false, e0, e1, w0, h0, h1);
+    asm_loads(b, n, t, on && second, hasc, p0, p1, q0, r0, r1);
+    asm_loads(b, n, t2, on2 && second, false, s0, s1, x0, y0, y1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       A.D[i] += (0.0 + d0[i]) + d1[i]; A.U[i] += 0.0 + u0[i];
@@ -131,6 +136,15 @@ __device__ __forceinline__ void asm_node(const AsmList& L, const int n, const in
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) { A.g[r] += (0.0 + g0[r]) + g1[r]; B.g[r] += (0.0 + h0[r]) + h1[r]; }
+    if (second) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        A.D[i] += (0.0 + p0[i]) + p1[i]; A.U[i] += 0.0 + q0[i];
+        B.D[i] += (0.0 + s0[i]) + s1[i]; B.U[i] += 0.0 + x0[i];
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { A.g[r] += (0.0 + r0[r]) + r1[r]; B.g[r] += (0.0 + y0[r]) + y1[r]; }
+    }
   }
 }
 
@@ -138,29 +152,54 @@ __device__ __forceinline__ void asm_node(const AsmList& L, const int n, const in
 // Loads only; what the pass leaves in memory on the way (trial precision, assembled matrix and gradient) is written by
 // store_side AFTER every load of the lane has been issued -- a store between two elements' loads orders them (the store needs
 // its value), and ten elements per lane then cost ten memory round trips (measured: 16.7 instead of 10.3 us per launch).
+// the caller's own arrays first (requested before the assemble's sweep over the sets): D, U and the mixed-in matrix
+struct RawBlock { double D[4], U[4], mD[4], mU[4], y[2]; };
 template <bool HAS_Y>
-__device__ __forceinline__ void load_block(const ChainArgs& a, const double (&aD)[4], const double (&aU)[4], const int t, const bool on,
-                                           const bool hasc, const bool mix, double (&D)[4], double (&C)[4]) {
+__device__ __forceinline__ void raw_loads(const ChainArgs& a, const int t, const bool on, const bool hasc, const bool mix, RawBlock& R) {
   const int n = a.n, T = a.T;
+  const bool asmv = a.asm_on != 0;
+#pragma unroll
+  for (int el = 0; el < 4; ++el) {
+    const int r = el >> 1, c = el & 1;
+    R.D[el] = R.U[el] = R.mD[el] = R.mU[el] = 0.0;
+    if (on && r < n && c < n) {
+      const int xe = r * n + c;
+      const size_t ge = (size_t)t * (n * n) + xe, gu = (size_t)(T + t) * (n * n) + xe;
+      if (!(HAS_Y && asmv)) {
+        R.D[el] = a.D[ge];
+        if (mix && !asmv) R.mD[el] = a.mixV[ge];
+        if (hasc) {
+          R.U[el] = a.U[ge];
+          if (mix && !asmv) R.mU[el] = a.mixV[gu];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) R.y[r] = (HAS_Y && on && r < n && !asmv) ? a.rhs[(size_t)t * n + r] : 0.0;
+}
+
+template <bool HAS_Y>
+__device__ __forceinline__ void load_block(const ChainArgs& a, const RawBlock& R, const double (&aD)[4], const double (&aU)[4], const bool on,
+                                           const bool hasc, const bool mix, double (&D)[4], double (&C)[4]) {
+  const int n = a.n;
 #pragma unroll
   for (int el = 0; el < 4; ++el) {
     const int r = el >> 1, c = el & 1;
     double dv = r == c ? 1.0 : 0.0, cu = 0.0;            // identity padding / absent node
     const bool in = on && r < n && c < n;
     if (in) {
-      const int xe = r * n + c;
-      const size_t ge = (size_t)t * (n * n) + xe, gu = (size_t)(T + t) * (n * n) + xe;
       const bool asmv = a.asm_on != 0;
       const double vD = aD[el], vU = aU[el];            // (zero when nothing is assembled)
       if (HAS_Y && asmv) {
         dv = vD;
         if (hasc) cu = vU;
       } else {
-        dv = a.D[ge];
-        if (mix) { const double mv = asmv ? vD : a.mixV[ge]; dv = dv + a.mix_step * (mv - dv); }
+        dv = R.D[el];
+        if (mix) { const double mv = asmv ? vD : R.mD[el]; dv = dv + a.mix_step * (mv - dv); }
         if (hasc) {
-          cu = a.U[ge];
-          if (mix) { const double mv = asmv ? vU : a.mixV[gu]; cu = cu + a.mix_step * (mv - cu); }
+          cu = R.U[el];
+          if (mix) { const double mv = asmv ? vU : R.mU[el]; cu = cu + a.mix_step * (mv - cu); }
         }
       }
     }
@@ -170,7 +209,7 @@ __device__ __forceinline__ void load_block(const ChainArgs& a, const double (&aD
 }
 
 template <bool HAS_Y>
-__device__ __forceinline__ void load_rhs(const ChainArgs& a, const double (&ag)[2], const int t, const bool on, double (&y)[2], double (&g)[2]) {
+__device__ __forceinline__ void load_rhs(const ChainArgs& a, const RawBlock& R, const double (&ag)[2], const bool on, double (&y)[2], double (&g)[2]) {
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     double v = 0.0, gv = 0.0;
@@ -178,7 +217,7 @@ __device__ __forceinline__ void load_rhs(const ChainArgs& a, const double (&ag)[
       if (a.asm_on) {
         gv = ag[r];
         v = a.rhs_scale * gv;
-      } else v = a.rhs_scale * a.rhs[(size_t)t * a.n + r];
+      } else v = a.rhs_scale * R.y[r];
     }
     y[r] = v;
     g[r] = gv;
@@ -338,17 +377,20 @@ __device__ __forceinline__ void body(const ChainArgs& a, const AsmList& AL) {
   double g1[2], g2[2];
   AsmAcc A1, A2;                                     // assemble-on-load: V_D / V_U / g of the lane's node and of node 64
   const bool hc = on && lane + 1 < T, on2 = two && lane == 0;
+  RawBlock R1, R2;
+  raw_loads<HAS_Y>(a, lane, on, hc, mix, R1);
+  raw_loads<HAS_Y>(a, 64, on2, false, mix, R2);
   if (a.asm_on) asm_node(AL, n, lane, on, hc, 64, on2, A1, A2);
   else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) A1.D[i] = A1.U[i] = A2.D[i] = A2.U[i] = 0.0;
     A1.g[0] = A1.g[1] = A2.g[0] = A2.g[1] = 0.0;
   }
-  load_block<HAS_Y>(a, A1.D, A1.U, lane, on, hc, mix, nd.DL, C);
-  load_rhs<HAS_Y>(a, A1.g, lane, on, nd.yl, g1);
+  load_block<HAS_Y>(a, R1, A1.D, A1.U, on, hc, mix, nd.DL, C);
+  load_rhs<HAS_Y>(a, R1, A1.g, on, nd.yl, g1);
   double DL2[4], C2[4], yl2[2];                      // node 64
-  load_block<HAS_Y>(a, A2.D, A2.U, 64, on2, false, mix, DL2, C2);
-  load_rhs<HAS_Y>(a, A2.g, 64, on2, yl2, g2);
+  load_block<HAS_Y>(a, R2, A2.D, A2.U, on2, false, mix, DL2, C2);
+  load_rhs<HAS_Y>(a, R2, A2.g, on2, yl2, g2);
   store_side<HAS_Y>(a, lane, on, on && lane + 1 < T, mix, nd.DL, C, g1);
   store_side<HAS_Y>(a, 64, two && lane == 0, false, mix, DL2, C2, g2);
 #pragma unroll
