@@ -172,7 +172,11 @@ constexpr int chain_threads(int n) { return n <= 8 ? GVI_CHAIN_THREADS_SMALL : 5
 #ifdef GVI_CHAIN_TIMING
 __device__ unsigned long long gvi_chain_stamps[256];
 __device__ int gvi_chain_nstamp;
+#ifdef GVI_CHAIN_TIMING_A       // block 0 of the segmented passes (grids of more than two blocks) instead of the top pass
+#define CHAIN_STAMP(on) do { if (gridDim.x > 2 && blockIdx.x == 0 && threadIdx.x == 0) { const int i__ = gvi_chain_nstamp; if (i__ < 256) { gvi_chain_stamps[i__] = __builtin_amdgcn_s_memtime(); gvi_chain_nstamp = i__ + 1; } } } while (0)
+#else
 #define CHAIN_STAMP(on) do { if ((on) && threadIdx.x == 0) { const int i__ = gvi_chain_nstamp; if (i__ < 256) { gvi_chain_stamps[i__] = __builtin_amdgcn_s_memtime(); gvi_chain_nstamp = i__ + 1; } } } while (0)
+#endif
 #else
 #define CHAIN_STAMP(on) do { } while (0)
 #endif
@@ -516,6 +520,7 @@ __host__ __device__ constexpr size_t bwd_lds_doubles(int S) {
 template <bool PIVOT, bool HAS_E, bool HAS_Y, bool TOP, int N>
 __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& AL, const int bid, double* sm) {
   constexpr int nn = N * N;
+  const LazyPred lpred = pred_issue(a.pred, a.pred_val);        // checked in front of the first store (device_common.hpp)
   const int T = a.T, S = a.S, st = 1 << a.level0;
   // the wave index as a SCALAR: everything derived from it (node, offsets, has_b) is then wave-uniform for the compiler too
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = blockDim.x >> 6, nthr = blockDim.x;
@@ -610,6 +615,7 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
         }
       }
     }
+    if (pred_fail(lpred)) return;                   // (block-uniform; nothing has been written yet)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = e0 + u * nthr;
@@ -632,6 +638,7 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
       }
     }
   }
+  if (pred_fail(lpred)) return;
   for (int e = tid; e < (S + 1) * nn; e += nthr) sm[oRl + e] = 0.0;
   for (int e = tid; e < (S + 1 - cnt) * nn; e += nthr) sm[oDl + cnt * nn + e] = 0.0;
   if (tid < N + (N & 1)) sm[oZero + tid] = 0.0;
@@ -819,6 +826,7 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
 template <bool HAS_E, bool HAS_Y, int N>
 __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid, double* sm) {
   constexpr int nn = N * N;
+  const LazyPred lpred = pred_issue(a.pred, a.pred_val);        // checked behind the load phase, in front of the first store
   const int T = a.T, S = a.S, st = 1 << a.level0;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nwaves = blockDim.x >> 6, nthr = blockDim.x;
   const int x0 = bid * S * st;
@@ -844,6 +852,7 @@ __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid,
     }
     if (tid < N) sm[oxl + tid] = tid < a.n ? a.x[(size_t)x0 * a.n + tid] : 0.0;
     if (ext_right && tid >= 64 && tid < 64 + N) sm[oxl + S * N + tid - 64] = tid - 64 < a.n ? a.x[(size_t)xn * a.n + tid - 64] : 0.0;
+    if (pred_fail(lpred)) return;                      // (block-uniform; only LDS has been written)
     __syncthreads();
     for (int lam = a.m - 1; lam >= 0; --lam) {
       const int h2 = 1 << lam;
@@ -918,6 +927,7 @@ __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid,
         sm[oSRt + c * N + r] = v;
       }
     }
+    if (pred_fail(lpred)) return;                      // (block-uniform; only LDS has been written)
     __syncthreads();
     for (int lam = a.m - 1; lam >= 0; --lam) {
       const int h2 = 1 << lam;
@@ -955,25 +965,15 @@ __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid,
 template <int N, bool TOP>
 __global__ __launch_bounds__(chain_threads(N)) void chain_forward_kernel(ChainArgs a0, ChainArgs a1, int nb0, AsmList AL) {
   extern __shared__ double sm[];
-  if ((int)blockIdx.x < nb0) {
-    if (pred_skip(a0.pred, a0.pred_val)) return;
-    chain::forward_body<false, true, false, TOP, N>(a0, AL, (int)blockIdx.x, sm);
-  } else {
-    if (pred_skip(a1.pred, a1.pred_val)) return;
-    chain::forward_body<true, false, true, TOP, N>(a1, AL, (int)blockIdx.x - nb0, sm);
-  }
+  if ((int)blockIdx.x < nb0) chain::forward_body<false, true, false, TOP, N>(a0, AL, (int)blockIdx.x, sm);    // (predicate: inside)
+  else chain::forward_body<true, false, true, TOP, N>(a1, AL, (int)blockIdx.x - nb0, sm);
 }
 
 template <int N>
 __global__ __launch_bounds__(chain_threads(N)) void chain_backward_kernel(ChainArgs a0, ChainArgs a1, int nb0) {
   extern __shared__ double sm[];
-  if ((int)blockIdx.x < nb0) {
-    if (pred_skip(a0.pred, a0.pred_val)) return;
-    chain::backward_body<true, false, N>(a0, (int)blockIdx.x, sm);
-  } else {
-    if (pred_skip(a1.pred, a1.pred_val)) return;
-    chain::backward_body<false, true, N>(a1, (int)blockIdx.x - nb0, sm);
-  }
+  if ((int)blockIdx.x < nb0) chain::backward_body<true, false, N>(a0, (int)blockIdx.x, sm);      // (predicate: inside)
+  else chain::backward_body<false, true, N>(a1, (int)blockIdx.x - nb0, sm);
 }
 
 }  // namespace gvi

@@ -367,6 +367,7 @@ __device__ __forceinline__ void store_block(double* g, const int n, const double
 
 template <bool PIVOT, bool HAS_E, bool HAS_Y>
 __device__ __forceinline__ void body(const ChainArgs& a, const AsmList& AL) {
+  const LazyPred lpred = pred_issue(a.pred, a.pred_val);     // checked behind the loads, in front of the first store
   const int lane = threadIdx.x & 63, T = a.T, n = a.n;
   const bool two = T == WT_MAX;                      // node 64 lives in lane 0's second register set
   const bool mix = a.mixV != nullptr || (a.asm_on && !HAS_Y);
@@ -391,6 +392,7 @@ __device__ __forceinline__ void body(const ChainArgs& a, const AsmList& AL) {
   double DL2[4], C2[4], yl2[2];                      // node 64
   load_block<HAS_Y>(a, R2, A2.D, A2.U, on2, false, mix, DL2, C2);
   load_rhs<HAS_Y>(a, R2, A2.g, on2, yl2, g2);
+  if (pred_fail(lpred)) return;
   store_side<HAS_Y>(a, lane, on, on && lane + 1 < T, mix, nd.DL, C, g1);
   store_side<HAS_Y>(a, 64, two && lane == 0, false, mix, DL2, C2, g2);
 #pragma unroll
@@ -594,13 +596,8 @@ __device__ __forceinline__ void body(const ChainArgs& a, const AsmList& AL) {
 }  // namespace chain_wave
 
 __global__ __launch_bounds__(64) void chain_wave_kernel(ChainArgs a0, ChainArgs a1, int nb0, AsmList AL) {
-  if ((int)blockIdx.x < nb0) {
-    if (pred_skip(a0.pred, a0.pred_val)) return;
-    chain_wave::body<false, true, false>(a0, AL);
-  } else {
-    if (pred_skip(a1.pred, a1.pred_val)) return;
-    chain_wave::body<true, false, true>(a1, AL);
-  }
+  if ((int)blockIdx.x < nb0) chain_wave::body<false, true, false>(a0, AL);      // (predicate: inside)
+  else chain_wave::body<true, false, true>(a1, AL);
 }
 
 }  // namespace gvi

@@ -87,7 +87,8 @@ __host__ __device__ inline size_t fused_lds_doubles(int dmax, int M, int copies,
 // prep and into the set's arrays.  Compile-time d: ALL loads of the wave are issued before the first store -- with the
 // runtime-d loop (division, three rounds of load -> store) the gather alone took 3.3 us of the launch's first phase.
 template <int DT>
-__device__ __forceinline__ void fused_gather(const FusedArgs& A, const FusedSet& S, const int k, const int lane, double* Sl, double* ml) {
+__device__ __forceinline__ bool fused_gather(const FusedArgs& A, const FusedSet& S, const int k, const int lane, double* Sl, double* ml,
+                                             const LazyPred& lpred) {
   constexpr int dd = DT * DT, NI = (dd + 63) / 64;
   const int n = A.n, nn = n * n;
   const int s = S.start ? S.start[k] : k;
@@ -107,12 +108,14 @@ __device__ __forceinline__ void fused_gather(const FusedArgs& A, const FusedSet&
     const size_t j = (size_t)s * n + lane;
     m = A.gdmu ? A.gmu[j] + A.gstep * A.gdmu[j] : A.gmu[j];
   }
+  if (pred_fail(lpred)) return true;             // the launch's predicate (block-uniform), in front of the first store
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int e = lane + 64 * i;
     if (e < dd) { Sl[e] = v[i]; S.Sigma_k[(size_t)k * dd + e] = v[i]; }
   }
   if (lane < DT) { ml[lane] = m; S.mu_k[(size_t)k * DT + lane] = m; }
+  return false;
 }
 
 // D0 / D1: the factor dimensions of set 0 / set 1 at compile time (both sets on the Cholesky route): only the bodies of
@@ -136,12 +139,15 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
     stamps[320 + (blockIdx.x / 146) * 4 + (threadIdx.x >> 6)] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                                                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #endif
-  if (pred_skip(A.tail.pred, A.tail.pred_val)) return;
+  // the launch's predicate (pipelined iterations): requested here, waited for in front of the first store to memory
+  const LazyPred lpred = pred_issue(A.tail.pred, A.tail.pred_val);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = (int)blockIdx.x;
   if (b >= A.nblk) {                                          // chain-level trial mean (gather mode only)
     const int64_t j = (int64_t)(b - A.nblk) * 256 + threadIdx.x;
-    if (j < A.nmu) A.mu_out[j] = A.gmu[j] + A.gstep * A.gdmu[j];
+    const double v = j < A.nmu ? A.gmu[j] + A.gstep * A.gdmu[j] : 0.0;
+    if (pred_fail(lpred)) return;
+    if (j < A.nmu) A.mu_out[j] = v;
     return;
   }
   // items of this block: set 0's b, b + nblk, ...; then set 1's
@@ -186,14 +192,14 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
       const int dp = d + (d & 1);
       double* Sl = area + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;   // behind prep_body's own LDS
       double* ml = Sl + dd;
-      if (si == 0) fused_gather<D0>(A, S, k, lane, Sl, ml);
-      else fused_gather<D1>(A, S, k, lane, Sl, ml);
+      if (si == 0 ? fused_gather<D0>(A, S, k, lane, Sl, ml, lpred) : fused_gather<D1>(A, S, k, lane, Sl, ml, lpred)) return;
       wave_lds_sync();
       if (si == 0) prep_chol_body<D0>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
       else prep_chol_body<D1>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
     }
   }
   FUSED_STAMP(1);
+  if (pred_fail(lpred)) return;                                // (waves without an item, and the route without the gather)
   __syncthreads();                                             // S^-T / H / u0 of the items are in LDS
   FUSED_STAMP(2);
   // ---- phase 2: every wave walks its chunk of the orbit table, item after item ----

@@ -258,6 +258,17 @@ static int run(int T, int n, int reps, bool with_old) {
   time_it("new: factor only", [&]() { CK(chain_launch(n, pl, a0, a1, true, false, st)); });
   time_it("new: solve only", [&]() { CK(chain_launch(n, pl, a0, a1, false, true, st)); });
   if constexpr (N > 0) { if (with_old) time_it("old: factor || solve", [&]() { old_launch<N>(T, o0, o1, st); }); }
+  {
+    // the same launches with a predicate that does not hold: every block returns at its first instruction -- what the launch
+    // configuration itself costs (dispatch of 2 x 33 workgroups of 16 waves with ~100 KB of LDS each, kernel arguments, drain)
+    double* dpred = nullptr;
+    CK(hipMalloc(&dpred, 8));
+    CK(hipMemset(dpred, 0, 8));
+    ChainArgs s0 = a0, s1 = a1;
+    s0.pred = s1.pred = dpred; s0.pred_val = s1.pred_val = 1.0;
+    time_it("skipped (predicate): both", [&]() { CK(chain_launch(n, pl, s0, s1, true, true, st)); });
+    CK(hipFree(dpred));
+  }
   return fail;
 }
 
