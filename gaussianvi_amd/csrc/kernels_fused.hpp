@@ -9,13 +9,15 @@
 //
 // Block b owns a few ITEMS (factors): item b of every set, plus the items b + nblk, b + 2 nblk, ... where a set is longer
 // than the grid (the chain pattern: prior b and unary factor b; block 0 also takes the 1025th unary factor) -- at most 4.
-//   phase 1   wave i forms the per-pass products of item i (gather of (mu_k, Sigma_k) from the chain, Cholesky route: ~3 us
-//             of dependent work per item, the items side by side) and leaves S^-T in LDS for phase 3;
+//   phase 1   ONE wave per item forms its per-pass products (gather of (mu_k, Sigma_k) from the chain, Cholesky route: ~4 us
+//             of dependent work per item, the items side by side) and leaves S^-T, H, u0 in LDS.  Which wave takes which item
+//             is read from the hardware SIMD ids, so that the d = 12 items of a CU's four resident blocks sit on four SIMDs;
 //   phase 2   all four waves walk the orbit table for one item after the other, wave w = chunk w; the chunk partials stay
 //             in LDS (no partial[K][nchunk][91] round trip through HBM: 3.1 of the 4.2 MB the psi launch moved at C3,
 //             profiles/r02_traffic.json);
-//   phase 3   wave i: ordered chunk sum, cost, tail protocol (arrival count, the last one publishes), back-transform of
-//             item i from LDS operands.
+//   phase 3   the item's wave: ordered chunk sum, back-transform from LDS operands; an IDLE wave of the block (blocks of at
+//             most two items) forms the same cost from the m0 entries and runs the tail protocol (arrival count, the last one
+//             sums and publishes) beside it.
 // The light set rides in the shadow of the heavy one (as in moments_orbit_pair_kernel's stacked form), the latency-bound
 // phases 1 and 3 are paid once per block instead of once per launch with its ramp, and two kernel boundaries are gone.
 // Nothing of the per-pass products goes to memory: S^-T, H and u0 stay in LDS between the phases (the host marks the sets'
