@@ -402,7 +402,7 @@ __device__ __forceinline__ void body(const ChainArgs& a, const AsmList& AL) {
   double fE[4] = {1.0, 0.0, 0.0, 1.0}, fGA[4] = {0, 0, 0, 0}, fGB[4] = {0, 0, 0, 0}, fv[2] = {0, 0};
   double lpm = 1.0;
   int lpe = 0, bad = 0;
-  const double ident[4] = {1.0, 0.0, 0.0, 1.0}, zero4[4] = {0.0, 0.0, 0.0, 0.0}, zero2[2] = {0.0, 0.0};
+  const double ident[4] = {1.0, 0.0, 0.0, 1.0}, zero4[4] = {0.0, 0.0, 0.0, 0.0};
   const int tl = T < 64 ? T : 64;                    // nodes that sit in lanes
   // ---- forward levels inside the lanes ----
   for (int h = 1; h < tl; h <<= 1) {
