@@ -224,6 +224,127 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
   }
 }
 
+// m = 12 with s = 4 / 5 / 6 (BASELINE configs[4]: d = 24, degree 7): the twelve rows as TWO walks of six.  Every accumulated
+// quantity is LINEAR in the two scalars of a point, q = sum_r s_r v_r^2 (+ k0) and l = sum_r s_r u0_r v_r, and both are sums
+// over the rows: the first walk accumulates with (q over rows 0..5 + k0, l over rows 0..5), the second with the rest, into the
+// same registers.  What that buys: the support's columns of six rows fit the registers (36 doubles at s = 6), so no column is
+// fetched from LDS inside the walk -- orbit_walk at m = 12 fetches twelve doubles at (almost) every Gray step, and its wave
+// waits for LDS in 15 % of its cycles -- and the Walsh butterfly of the sign-weighted sums (registers again) applies at
+// s = 5 / 6 as it does at m = 6.  Same number of fp64 instructions per orbit; sums re-associated (rows 0..5 first).
+#ifndef GVI_ORBIT_SPLIT12
+#define GVI_ORBIT_SPLIT12 1
+#endif
+template <int S, bool SIGNED>
+__device__ __forceinline__ void orbit_walk_split(const int d, const int lc, const uint64_t cpk, const double (&mg)[S], const double w,
+                                                 const double* Hl, double* accl, const double (&su0)[12], const double (&sg)[12],
+                                                 const double k0, double& m0) {
+  constexpr int MH = 6, HS = orbit_hstride(12), NH = 1 << (S - 1), LB = 3, BLK = 8;
+  static_assert(S >= 4 && S <= 6, "split walk: s = 4, 5, 6 (blocks of 8 Gray steps)");
+  int c[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) c[j] = (int)((cpk >> (8 * j)) & 255u);
+  double E0 = 0.0, Eij[S * (S - 1) / 2], Oi[S];
+#pragma unroll
+  for (int e = 0; e < S * (S - 1) / 2; ++e) Eij[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < S; ++j) Oi[j] = 0.0;
+#pragma clang loop unroll(disable)
+  for (int half = 0; half < 2; ++half) {
+    double suh[MH], sgh[MH];
+#pragma unroll
+    for (int r = 0; r < MH; ++r) {
+      suh[r] = half ? su0[MH + r] : su0[r];
+      sgh[r] = SIGNED ? (half ? sg[MH + r] : sg[r]) : 1.0;
+    }
+    const double kk = half ? 0.0 : k0;
+    double hcol[S][MH];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const double* hp = Hl + c[j] * HS + half * MH;
+#pragma unroll
+      for (int r = 0; r < MH; ++r) hcol[j][r] = hp[r];
+    }
+    int sig[S];                                      // corner (-, ..., -, +), as orbit_walk
+#pragma unroll
+    for (int j = 0; j < S; ++j) sig[j] = j == S - 1 ? 1 : -1;
+    double v[MH];
+#pragma unroll
+    for (int r = 0; r < MH; ++r) v[r] = mg[S - 1] * hcol[S - 1][r];
+#pragma unroll
+    for (int j = 0; j < S - 1; ++j) {
+#pragma unroll
+      for (int r = 0; r < MH; ++r) v[r] = fma(-mg[j], hcol[j][r], v[r]);
+    }
+    double cpv[BLK], lv[BLK];
+#pragma unroll
+    for (int g = 0; g < NH; ++g) {
+      const int jn = g + 1 < NH ? __builtin_ctz(g + 1) : 0;
+      double q = 0.0, l = 0.0;
+#pragma unroll
+      for (int r = 0; r < MH; ++r) {
+        q = SIGNED ? fma(sgh[r] * v[r], v[r], q) : fma(v[r], v[r], q);
+        l = fma(suh[r], v[r], l);
+      }
+      const double cp = q + kk;
+      int b = 0;
+#pragma unroll
+      for (int j = 0; j < LB; ++j) b |= (sig[j] > 0 ? 1 : 0) << j;
+      cpv[b] = cp;
+      lv[b] = l;
+      if ((g & (BLK - 1)) == BLK - 1) {
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+#pragma unroll
+          for (int bb = 0; bb < BLK; ++bb) {
+            if (!(bb & (1 << j))) {
+              const double c0v = cpv[bb], c1v = cpv[bb | (1 << j)], l0v = lv[bb], l1v = lv[bb | (1 << j)];
+              cpv[bb] = c0v + c1v; cpv[bb | (1 << j)] = c1v - c0v;
+              lv[bb] = l0v + l1v; lv[bb | (1 << j)] = l1v - l0v;
+            }
+          }
+        }
+        E0 += cpv[0];
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          {
+            const double t = i < LB ? lv[1 << i] : lv[0];
+            const bool pos = i < LB || sig[i] > 0;
+            Oi[i] = pos ? Oi[i] + t : Oi[i] - t;
+          }
+#pragma unroll
+          for (int j = i + 1; j < S; ++j) {
+            const double t = j < LB ? cpv[(1 << i) | (1 << j)] : (i < LB ? cpv[1 << i] : cpv[0]);
+            const bool pos = (j < LB ? 1 : sig[j]) * (i < LB ? 1 : sig[i]) > 0;
+            Eij[e] = pos ? Eij[e] + t : Eij[e] - t;
+            ++e;
+          }
+        }
+      }
+      if (g + 1 < NH) {
+        sig[jn] = -sig[jn];
+        const double t2 = (sig[jn] > 0 ? 2.0 : -2.0) * mg[jn];
+#pragma unroll
+        for (int r = 0; r < MH; ++r) v[r] = fma(t2, hcol[jn][r], v[r]);
+      }
+    }
+  }
+  const double wp = w + w;
+  m0 = fma(wp, E0, m0);
+  const double w4 = wp + wp;
+  int e = 0;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const int a = c[i];
+    const double wm = wp * mg[i];
+    lds_add_f64(accl + ((1 + a) << lc), w4 * mg[i] * Oi[i]);
+    const int row = 1 + d + __mul24(a, d) - (__mul24(a, a - 1) >> 1) - a;
+    lds_add_f64(accl + ((row + a) << lc), wm * mg[i] * E0);
+#pragma unroll
+    for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + ((row + c[j]) << lc), wm * mg[j] * Eij[e]); ++e; }
+  }
+}
+
 template <int M, int S, bool FULL, bool SIGNED>
 __device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, const int lc, const int64_t o, const double* Hl, double* accl,
                                            const double (&su0)[M], const double (&sg)[M], const double k0, double& m0) {
@@ -232,7 +353,8 @@ __device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, cons
   double mg[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) mg[j] = ob.mag[(size_t)j * ob.norb_p + o];
-  orbit_walk<M, S, FULL, SIGNED>(d, lc, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
+  if constexpr (M == 12 && S >= 4 && FULL && GVI_ORBIT_SPLIT12 != 0) orbit_walk_split<S, SIGNED>(d, lc, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
+  else orbit_walk<M, S, FULL, SIGNED>(d, lc, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
 }
 
 // out: where the chunk's partial sums go -- the set's partial array (stand-alone launches) or LDS (factor_fused_kernel).
