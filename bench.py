@@ -158,8 +158,9 @@ def orbit_exec_ops(d: int, p: int, m: int, full: bool, signed: bool = False) -> 
     its sum: 2, sign-weighted sums: s + s (s - 1) / 2]  +  (2^(s-1) - 1) flips x (m + 1)  +  the per-orbit scaling
     (3 + 5 s + 2 s (s - 1) / 2 multiplies); the cost pass keeps q, c+ and the flips only.  For s <= 4 the full pass forms
     the sign-weighted sums by a butterfly after the walk instead (checked against the ISA: 251 fp64 instructions in the s = 4
-    tile body, 130 at s = 3).  The LDS atomics that fold an
-    orbit into the factor's accumulators are not VALU instructions."""
+    tile body, 130 at s = 3).  m = 12, s >= 4 runs as two walks of six rows with the butterfly at every s (orbit_walk_split):
+    about the same instruction count (PMC: 4.43e10 vs 4.31e10 VALU instructions per (24,7) launch), so the count above is kept.
+    The LDS atomics that fold an orbit into the factor's accumulators are not VALU instructions."""
     import numpy as np
     from gaussianvi_amd import api
     Z, w, _ = api.spgh_nodes(d, p)
@@ -447,7 +448,7 @@ def main():
             ctx.profile_enable(0)
 
     # ---- N > 1: BASELINE configs[4] (4096 factors, d = 24, p = 7; fp64) sharded over the same ranks, two iterations:
-    # the workload whose factor pass (0.13 s on one GPU) dwarfs the replicated chain operations, i.e. where sharding has
+    # the workload whose factor pass (0.095 s on one GPU) dwarfs the replicated chain operations, i.e. where sharding has
     # work to split (strong scaling).  GVI_BENCH_C5_CONFIG selects a smaller d = 24 chain for rehearsals.
     c5_block = None
     if world > 1 and not args.no_c5_strong:
