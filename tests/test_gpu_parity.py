@@ -1038,10 +1038,11 @@ def test_sign_orbit_kernel_vs_lane_per_point_and_oracle(kind, d, m, p, K):
         assert rel(cost, r["cost"]) < lim
 
 
-def test_sign_orbit_kernel_indefinite_weight():
-    """psi with an indefinite Qinv (some sgn = -1): the SIGNED instantiation of the orbit kernel."""
+@pytest.mark.parametrize("K,n,p", [(5, 6, 4), (2, 12, 5)])
+def test_sign_orbit_kernel_indefinite_weight(K, n, p):
+    """psi with an indefinite Qinv (some sgn = -1): the SIGNED instantiation of the orbit kernel; n = 12 (m = 12, supports up to
+    s = 4): the signed form of the two-walks-of-six split (orbit_walk_split)."""
     rng = np.random.default_rng(77)
-    K, n, p = 5, 6, 4
     d = 2 * n
     Phi, _ = quad_params(rng, K, n)
     Qh = rng.normal(size=(K, n, n))
@@ -1056,8 +1057,9 @@ def test_sign_orbit_kernel_indefinite_weight():
     ctx.close()
     Z, w = oracle_table(d, p)
     r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_quad_prior(Phi, Qinv), np.ones(K))
-    assert rel(got[0], r["E_phi"]) < TIGHT and rel(got[1], r["Vdmu"]) < TIGHT and rel(got[2], r["Vddmu"]) < 10 * TIGHT
-    assert rel(cost, r["cost"]) < TIGHT
+    lim = TIGHT if n <= 6 else 10 * TIGHT
+    assert rel(got[0], r["E_phi"]) < lim and rel(got[1], r["Vdmu"]) < lim and rel(got[2], r["Vddmu"]) < 10 * lim
+    assert rel(cost, r["cost"]) < lim
 
 
 @pytest.mark.parametrize("kind,d,p,K", [("quad", 12, 5, 9), ("fixed", 6, 5, 7), ("quad", 8, 4, 5), ("quad", 4, 3, 6), ("fixed", 12, 3, 4), ("fixed", 2, 3, 6)])
