@@ -124,14 +124,22 @@ class Context:
         self._ck(self.lib.gvi_chain_set(self.h, T, n))
         self.T, self.n, self.sets = T, n, []
 
-    def factors_add(self, d, p, start, kind, params=None, temperature=None):
+    def factors_add(self, d, p, start, kind, params=None, temperature=None, table=None):
+        """table = (Z [N][d], w [N]): the set takes the caller's quadrature table, nothing is generated
+        (gvi_factors_add_table: the shared QuadratureWeightsMap of the reference's factor constructors)."""
         start = np.ascontiguousarray(start, dtype=np.int32)
         K = len(start)
         params = None if params is None else (_f64(params).reshape(K, -1) if K else np.zeros((0, int(np.prod(np.shape(params)[1:])) or 1)))
         temperature = None if temperature is None else _f64(temperature)
         sid = C.c_int()
-        self._ck(self.lib.gvi_factors_add(self.h, K, d, p, _p(start), kind, _p(params),
-                                          0 if params is None else params.shape[1], _p(temperature), C.byref(sid)))
+        if table is None:
+            self._ck(self.lib.gvi_factors_add(self.h, K, d, p, _p(start), kind, _p(params),
+                                              0 if params is None else params.shape[1], _p(temperature), C.byref(sid)))
+        else:
+            Z, w = _f64(table[0]), _f64(table[1])
+            self._ck(self.lib.gvi_factors_add_table(self.h, K, d, p, _p(start), kind, _p(params),
+                                                    0 if params is None else params.shape[1], _p(temperature),
+                                                    len(w), _p(Z), _p(w), C.byref(sid)))
         k_, d_, p_, N = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
         self._ck(self.lib.gvi_factors_info(self.h, sid.value, C.byref(k_), C.byref(d_), C.byref(p_), C.byref(N)))
         self.sets.append((K, d, p, N.value))

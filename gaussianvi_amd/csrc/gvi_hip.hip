@@ -1107,9 +1107,11 @@ gvi_status gvi_chain_set(gvi_ctx* ctx, int T, int n) {
   return GVI_OK;
 }
 
-gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
-                           const double* psi_params, int64_t params_per_factor, const double* temperature,
-                           int* set_id) {
+// gvi_factors_add / gvi_factors_add_table: tabZ != NULL takes the caller's table (private to the set) instead of the
+// generated (d, p) one
+static gvi_status factors_add_impl(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
+                                   const double* psi_params, int64_t params_per_factor, const double* temperature,
+                                   int64_t tabN, const double* tabZ, const double* tabw, int* set_id) {
   if (!ctx) return GVI_ERR_ARG;
   if (ctx->T < 1) return fail(ctx, GVI_ERR_STATE, "call gvi_chain_set first");
   // K == 0 is a valid EMPTY set: the shard of a rank that received none of a small set's factors (set ids stay
@@ -1143,7 +1145,12 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   s->K = K; s->d = d; s->p = p; s->m = m; s->kind = psi_kind;
   if (K > 0) s->start.assign(start, start + K);
   // quadrature table: shared between sets with the same (d, p)
-  for (auto& t : ctx->tables) if (t->d == d && t->p == p) s->table = t;
+  if (tabZ) {
+    auto t = std::make_shared<Table>();
+    GVICK(upload_table(ctx, *t, d, -1, tabN, tabZ, tabw));
+    s->table = t;
+  }
+  for (auto& t : ctx->tables) if (!s->table && t->d == d && t->p == p) s->table = t;
   if (!s->table) {
     SparseGrid g;
     if (spgh_generate(d, p, g)) return fail(ctx, GVI_ERR_NOTABLE, "(d, p) outside the tabulated rules");
@@ -1240,6 +1247,20 @@ gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* sta
   ctx->ngd.ready = false;
   if (set_id) *set_id = (int)ctx->sets.size() - 1;
   return GVI_OK;
+}
+
+gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
+                           const double* psi_params, int64_t params_per_factor, const double* temperature,
+                           int* set_id) {
+  return factors_add_impl(ctx, K, d, p, start, psi_kind, psi_params, params_per_factor, temperature, 0, nullptr, nullptr, set_id);
+}
+
+gvi_status gvi_factors_add_table(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
+                                 const double* psi_params, int64_t params_per_factor, const double* temperature,
+                                 int64_t N, const double* Z, const double* w, int* set_id) {
+  if (!ctx) return GVI_ERR_ARG;
+  if (N < 1 || !Z || !w) return fail(ctx, GVI_ERR_ARG, "bad table");
+  return factors_add_impl(ctx, K, d, p, start, psi_kind, psi_params, params_per_factor, temperature, N, Z, w, set_id);
 }
 
 gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const double* Z, const double* w) {

@@ -48,6 +48,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -59,6 +60,23 @@
 #include <Eigen/Sparse>
 #define GVI_HOST_HAVE_EIGEN 1
 #endif
+#endif
+
+// The key hash of QuadratureWeightsMap, defined where and how the reference defines it (a specialisation in namespace
+// std, helpers/SerializeEigenMaps.h:29-41), so that `std::unordered_map<std::tuple<double, double>, ...>` spelled by a
+// caller is the same type here.  A translation unit that already carries that specialisation defines
+// GVI_HOST_NO_TUPLE_HASH.
+#ifndef GVI_HOST_NO_TUPLE_HASH
+namespace std {
+template <>
+struct hash<std::tuple<double, double>> {
+  size_t operator()(const std::tuple<double, double>& key) const {
+    const size_t hash1 = std::hash<double>{}(std::get<0>(key));
+    const size_t hash2 = std::hash<double>{}(std::get<1>(key));
+    return hash1 ^ (hash2 << 1);
+  }
+};
+}  // namespace std
 #endif
 
 namespace gvi {
@@ -227,6 +245,11 @@ class SpMat {
 
 struct NoneType {};
 
+// quadrature/SparseGHQuadratureWeights.h:14-16: (dimension, degree) -> (zero-mean points N x d, weights N)
+using DimDegTuple = std::tuple<double, double>;
+using PointsWeightsTuple = std::tuple<MatrixXd, VectorXd>;
+using QuadratureWeightsMap = std::unordered_map<DimDegTuple, PointsWeightsTuple>;
+
 class GviError : public std::runtime_error {
  public:
   GviError(int status, const std::string& m) : std::runtime_error("gvi status " + std::to_string(status) + ": " + m), status(status) {}
@@ -338,28 +361,78 @@ inline void upload_psi_shared(const Device& dev, int set_id, const DevicePsi& dp
 // SparseGaussHermite (quadrature/SparseGaussHermite.h): table lookup, symmetric-sqrt expand on the
 // device, weighted reduction of an arbitrary host function.
 // ------------------------------------------------------------------------------------------------
+// Fills a QuadratureWeightsMap from the reference's table file -- what `cereal::BinaryInputArchive archive(ifs);
+// archive(nodes_weights_map);` does at quadrature/SparseGaussHermite.h:62-71 / :95-108 -- through gvi_table_file_list /
+// gvi_table_file_read (layout helpers/SerializeEigenMaps.h:195-224).  Same failure as :58-61: std::runtime_error.
+inline QuadratureWeightsMap read_quadrature_weights_map(const std::string& map_file) {
+  const std::string error_msg = "Failed to open file for GH weights reading in file: " + map_file;
+  int64_t count = 0;
+  if (gvi_table_file_list(map_file.c_str(), 0, &count, nullptr, nullptr, nullptr) != GVI_OK) throw std::runtime_error(error_msg);
+  std::vector<double> dims((size_t)count), degs((size_t)count);
+  std::vector<int64_t> rows((size_t)count);
+  if (count && gvi_table_file_list(map_file.c_str(), count, &count, dims.data(), degs.data(), rows.data()) != GVI_OK)
+    throw std::runtime_error(error_msg);
+  QuadratureWeightsMap map;
+  for (int64_t e = 0; e < count; ++e) {
+    const int d = (int)dims[(size_t)e], p = (int)degs[(size_t)e];
+    int64_t N = rows[(size_t)e];
+    MatrixXd Z((int)N, d);
+    VectorXd w((int)N);
+    if (gvi_table_file_read(map_file.c_str(), d, p, &N, Z.data(), w.data()) != GVI_OK) throw std::runtime_error(error_msg);
+    map[std::make_tuple(dims[(size_t)e], degs[(size_t)e])] = std::make_tuple(std::move(Z), std::move(w));
+  }
+  return map;
+}
+inline std::shared_ptr<QuadratureWeightsMap> read_quadrature_weights_map_shared(const std::string& map_file) {
+  return std::make_shared<QuadratureWeightsMap>(read_quadrature_weights_map(map_file));
+}
+// (dim, deg) -> the map's entry, or nullptr (the lookup of SparseGaussHermite::computeSigmaPtsWeights, :138-166)
+inline const PointsWeightsTuple* find_points_weights(const QuadratureWeightsMap& map, int dim, int deg) {
+  const auto it = map.find(std::make_tuple((double)dim, (double)deg));
+  return it == map.end() ? nullptr : &it->second;
+}
+
 template <typename Function = std::function<MatrixXd(const VectorXd&)>>
 class SparseGaussHermite {
  public:
-  SparseGaussHermite(int deg, int dim, const VectorXd& mean, const MatrixXd& P, std::shared_ptr<Device> dev = nullptr)
+  virtual ~SparseGaussHermite() {}
+  // The reference's three constructors (quadrature/SparseGaussHermite.h:38-77, :79-117, :120-132) + the device context
+  // as an optional trailing argument.  Without a map the reference reads the table FILE at every construction
+  // (:53-71); here the built-in nwspgr generator supplies the same table (bit-exact nodes, weights to 1e-13).  Like
+  // the reference, the first two are told apart by the type of the fifth argument; only the second keeps its default
+  // so that a four-argument call stays unambiguous.
+  SparseGaussHermite(const int& deg, const int& dim, const VectorXd& mean, const MatrixXd& P,
+                     std::optional<QuadratureWeightsMap> weight_sigpts_map_option, std::shared_ptr<Device> dev = nullptr)
       : _deg(deg), _dim(dim), _mean(mean), _P(P), _dev(dev ? dev : std::make_shared<Device>()) {
+    if (weight_sigpts_map_option.has_value()) _nodes_weights_map = std::make_shared<QuadratureWeightsMap>(weight_sigpts_map_option.value());
     computeSigmaPtsWeights();
   }
+  SparseGaussHermite(const int& deg, const int& dim, const VectorXd& mean, const MatrixXd& P,
+                     std::optional<std::shared_ptr<QuadratureWeightsMap>> weight_sigpts_map_option = std::nullopt,
+                     std::shared_ptr<Device> dev = nullptr)
+      : _deg(deg), _dim(dim), _mean(mean), _P(P), _dev(dev ? dev : std::make_shared<Device>()) {
+    if (weight_sigpts_map_option.has_value()) _nodes_weights_map = weight_sigpts_map_option.value();
+    computeSigmaPtsWeights();
+  }
+  SparseGaussHermite(const int& deg, const int& dim, const VectorXd& mean, const MatrixXd& P, const QuadratureWeightsMap& weights_map,
+                     std::shared_ptr<Device> dev = nullptr)
+      : _deg(deg), _dim(dim), _mean(mean), _P(P), _dev(dev ? dev : std::make_shared<Device>()) {
+    computeSigmaPtsWeights(weights_map);
+  }
+
   void computeSigmaPtsWeights() {   // :138-166
+    if (_nodes_weights_map) { lookup(*_nodes_weights_map, false); return; }
     int64_t N = 0;
     gvi_status s = gvi_spgh_count(_dim, _deg, &N);
-    if (s != GVI_OK) {                                    // reference: prints "key does not exist"
-      std::printf("(dimension, degree) (%d, %d) key does not exist in the GH weight map.\n", _dim, _deg);
-      return;
-    }
+    if (s != GVI_OK) { missing_key(); return; }
     _zeromeanpts = MatrixXd((int)N, _dim);
     _Weights = VectorXd((int)N);
     _dev->check(gvi_spgh_nodes(_dim, _deg, N, _zeromeanpts.data(), _Weights.data(), nullptr));
-    _dev->check(gvi_chain_set(_dev->get(), 1, _dim));
-    const int32_t start = 0;
-    _dev->check(gvi_factors_add(_dev->get(), 1, _dim, _deg, &start, GVI_PSI_HOST_CALLBACK, nullptr, 0, nullptr, &_set));
+    device_set(false);
     update_sigmapoints();
   }
+  void computeSigmaPtsWeights(const QuadratureWeightsMap& weights_map) { lookup(weights_map, true); }   // :171-193
+
   MatrixXd Integrate(const Function& function) {      // :197-221
     MatrixXd res = function(_mean);
     res.setZero();
@@ -372,25 +445,59 @@ class SparseGaussHermite {
     }
     return res;
   }
-  void update_mean(const VectorXd& mean) { _mean = mean; }
-  void update_P(const MatrixXd& P) { _P = P; }
+  inline void update_mean(const VectorXd& mean) { _mean = mean; }
+  inline void update_P(const MatrixXd& P) { _P = P; }
   void update_sigmapoints() {                          // :231-243, on the device
     const int N = _Weights.size();
+    if (_set < 0 || N == 0) { _sigmapts = MatrixXd(0, _dim); return; }
     std::vector<double> X((size_t)_dim * N);
     _dev->check(gvi_expand(_dev->get(), _set, _mean.data(), _P.data(), X.data()));
     _sigmapts = MatrixXd(N, _dim);
     for (int a = 0; a < _dim; ++a)
       for (int i = 0; i < N; ++i) _sigmapts(i, a) = X[(size_t)a * N + i];
   }
-  VectorXd weights() const { return _Weights; }
-  MatrixXd sigmapts() const { return _sigmapts; }
-  VectorXd mean() const { return _mean; }
+  inline void set_polynomial_deg(const int& deg) { _deg = deg; computeSigmaPtsWeights(); }                 // :249-252
+  inline void update_dimension(const int& dim) { _dim = dim; computeSigmaPtsWeights(); }                   // :254-257
+  inline void update_parameters(const int& deg, const int& dim, const VectorXd& mean, const MatrixXd& P) {   // :259-271
+    _deg = deg; _dim = dim; _mean = mean; _P = P;
+    computeSigmaPtsWeights();
+  }
+  inline VectorXd weights() const { return _Weights; }
+  inline MatrixXd sigmapts() const { return _sigmapts; }
+  inline VectorXd mean() const { return _mean; }
+  inline MatrixXd zeromeanpts() const { return _zeromeanpts; }
+
  protected:
+  void missing_key() {                                  // the reference only prints (:159-162) and keeps what it had
+    std::printf("(dimension, degree) (%d, %d) key does not exist in the GH weight map.\n", _dim, _deg);
+  }
+  void lookup(const QuadratureWeightsMap& map, bool announce) {
+    const PointsWeightsTuple* e = find_points_weights(map, _dim, _deg);
+    if (!e) { missing_key(); return; }
+    if (announce) std::printf("(dimension, degree) tuple: (%d, %d) exists in the GH weight map.\n", _dim, _deg);
+    _zeromeanpts = std::get<0>(*e);
+    _Weights = std::get<1>(*e);
+    if (_zeromeanpts.rows() != _Weights.size() || _zeromeanpts.cols() != _dim || _Weights.size() < 1)
+      throw std::invalid_argument("SparseGaussHermite: map entry is not (N x dim points, N weights)");
+    device_set(true);
+    update_sigmapoints();
+  }
+  // one single-factor device set carrying the table: the generated (dim, deg) one or the caller's
+  void device_set(bool from_map) {
+    _dev->check(gvi_chain_set(_dev->get(), 1, _dim));
+    const int32_t start = 0;
+    if (from_map)
+      _dev->check(gvi_factors_add_table(_dev->get(), 1, _dim, _deg, &start, GVI_PSI_HOST_CALLBACK, nullptr, 0, nullptr,
+                                        _Weights.size(), _zeromeanpts.data(), _Weights.data(), &_set));
+    else
+      _dev->check(gvi_factors_add(_dev->get(), 1, _dim, _deg, &start, GVI_PSI_HOST_CALLBACK, nullptr, 0, nullptr, &_set));
+  }
   int _deg, _dim, _set = -1;
   VectorXd _mean;
   MatrixXd _P;
   VectorXd _Weights;
   MatrixXd _sigmapts, _zeromeanpts;
+  std::shared_ptr<QuadratureWeightsMap> _nodes_weights_map;
   std::shared_ptr<Device> _dev;
 };
 
@@ -685,6 +792,8 @@ class GVIFactorizedBase {
   virtual int gh_degree() const { return 0; }
   virtual const DevicePsi& device_psi() const { static const DevicePsi none{}; return none; }
   virtual bool closed_form() const { return false; }            // NGDFactorizedLinear: no sigma points
+  // the caller's shared quadrature table (weight_sigpts_map_option of the GH factor constructors); null = built-in
+  virtual std::shared_ptr<QuadratureWeightsMap> weights_map() const { return nullptr; }
   virtual double psi(const VectorXd& x) const { (void)x; return 0.0; }   // the opaque host cost function
 
   // lazily batched device set serving this factor's operator calls (owned by the optimiser once the factor joins one;
@@ -856,8 +965,31 @@ inline std::shared_ptr<FactorBatch> make_factor_batch(const std::shared_ptr<Devi
     params.insert(params.end(), q.params.begin(), q.params.end());
   }
   int id = -1;
-  dev->check(gvi_factors_add(dev->get(), (int)K, f0._dim, f0.gh_degree(), start.data(), dp.kind, params.empty() ? nullptr : params.data(),
-                             (int64_t)dp.params.size(), temp.data(), &id));
+  const std::shared_ptr<QuadratureWeightsMap> map = f0.weights_map();
+  if (map && !f0.closed_form()) {
+    // a caller-supplied QuadratureWeightsMap: ONE upload per set (gvi_factors_add_table); SparseGaussHermite's lookup
+    // (quadrature/SparseGaussHermite.h:138-166).  A missing key only prints there and leaves the factor without sigma
+    // points -- every integral is then a sum over zero rows; a one-point table of weight 0 gives exactly that.
+    const PointsWeightsTuple* e = find_points_weights(*map, f0._dim, f0.gh_degree());
+    MatrixXd Z0(1, f0._dim);
+    VectorXd w0(1);
+    const MatrixXd* Z = &Z0;
+    const VectorXd* w = &w0;
+    if (e) {
+      Z = &std::get<0>(*e);
+      w = &std::get<1>(*e);
+      if (Z->rows() != w->size() || Z->cols() != f0._dim || w->size() < 1)
+        throw std::invalid_argument("QuadratureWeightsMap entry is not (N x dim points, N weights)");
+    } else {
+      std::printf("(dimension, degree) (%d, %d) key does not exist in the GH weight map.\n", f0._dim, f0.gh_degree());
+    }
+    dev->check(gvi_factors_add_table(dev->get(), (int)K, f0._dim, f0.gh_degree(), start.data(), dp.kind,
+                                     params.empty() ? nullptr : params.data(), (int64_t)dp.params.size(), temp.data(),
+                                     w->size(), Z->data(), w->data(), &id));
+  } else {
+    dev->check(gvi_factors_add(dev->get(), (int)K, f0._dim, f0.gh_degree(), start.data(), dp.kind, params.empty() ? nullptr : params.data(),
+                               (int64_t)dp.params.size(), temp.data(), &id));
+  }
   upload_psi_shared(*dev, id, dp);
   if (f0.closed_form()) dev->check(gvi_factors_set_closed_form(dev->get(), id, 1));
   return std::make_shared<FactorBatch>(dev, id, f0._dim, dp.kind, members);
@@ -874,7 +1006,15 @@ inline FactorBatch& GVIFactorizedBase::batch() {
 // gvibase/GVIFactorizedBaseGH.h: the three Gauss-Hermite integrals of the factor at its current marginal
 class GVIFactorizedBaseGH : public GVIFactorizedBase {
  public:
-  using GVIFactorizedBase::GVIFactorizedBase;
+  GVIFactorizedBaseGH() {}
+  // gvibase/GVIFactorizedBaseGH.h:35-40.  The map is what the factor's SparseGaussHermite looks (dimension, degree) up
+  // in (ngd/NGDFactorizedBaseGH.h:49); here it becomes the table of the factor's device set.
+  GVIFactorizedBaseGH(int dimension, int state_dim, int num_states, int start_index, double temperature = 10.0,
+                      double high_temperature = 100.0,
+                      std::optional<std::shared_ptr<QuadratureWeightsMap>> weight_sigpts_map_option = std::nullopt)
+      : GVIFactorizedBase(dimension, state_dim, num_states, start_index, temperature, high_temperature),
+        _weights_map(weight_sigpts_map_option.has_value() ? weight_sigpts_map_option.value() : nullptr) {}
+  std::shared_ptr<QuadratureWeightsMap> weights_map() const override { return _weights_map; }
   // updateGH(x, P) (:44-49) has no separate state here: the integrals below run at (_mu, _covariance)
   void updateGH(const VectorXd& x, const MatrixXd& P) { _mu = x; _covariance = P; _precision_stale = true; }
   inline double E_Phi() { double e; VectorXd a; MatrixXd b; batch().raw(_batch_index, e, a, b); return e; }          // :54-56
@@ -886,6 +1026,8 @@ class GVIFactorizedBaseGH : public GVIFactorizedBase {
     return r;
   }
   inline MatrixXd E_xMuxMuTPhi() { double e; VectorXd a; MatrixXd b; batch().raw(_batch_index, e, a, b); return b; }   // :62-64
+ protected:
+  std::shared_ptr<QuadratureWeightsMap> _weights_map;
 };
 
 // Shared implementation of the GH factor classes: calculate_partial_V (ngd/NGDFactorizedBaseGH.h:53-74 =
@@ -908,14 +1050,21 @@ template <typename CostClass = NoneType>
 class NGDFactorizedBaseGH : public NGDFactorDeviceOps {
  public:
   using Function = std::function<double(const VectorXd&, const CostClass&)>;
-  // Reference signature (ngd/NGDFactorizedBaseGH.h:37-44) + an optional device psi descriptor.  Without one the factor's
-  // psi stays the opaque host function (device expand -> host psi -> device reduction).
+  // The reference's signature (ngd/NGDFactorizedBaseGH.h:37-44), weight_sigpts_map_option included, + an optional device
+  // psi descriptor as an eleventh argument.  Without one the factor's psi stays the opaque host function (device expand
+  // -> host psi -> device reduction).
   NGDFactorizedBaseGH(int dimension, int state_dim, int gh_degree, const Function& function, const CostClass& cost_class,
                       int num_states, int start_index, double temperature = 1.0, double high_temperature = 10.0,
+                      std::optional<std::shared_ptr<QuadratureWeightsMap>> weight_sigpts_map_option = std::nullopt,
                       std::optional<DevicePsi> device_psi = std::nullopt)
-      : NGDFactorDeviceOps(dimension, state_dim, num_states, start_index, temperature, high_temperature),
+      : NGDFactorDeviceOps(dimension, state_dim, num_states, start_index, temperature, high_temperature, weight_sigpts_map_option),
         _gh_degree(gh_degree), _function(function), _cost_class(cost_class),
         _psi(device_psi ? *device_psi : DevicePsi{}) {}
+  // shorthand: a device psi and the built-in table
+  NGDFactorizedBaseGH(int dimension, int state_dim, int gh_degree, const Function& function, const CostClass& cost_class,
+                      int num_states, int start_index, double temperature, double high_temperature, const DevicePsi& device_psi)
+      : NGDFactorizedBaseGH(dimension, state_dim, gh_degree, function, cost_class, num_states, start_index, temperature,
+                            high_temperature, std::nullopt, device_psi) {}
   double psi(const VectorXd& x) const override { return _function(x, _cost_class); }
   int gh_degree() const override { return _gh_degree; }
   const DevicePsi& device_psi() const override { return _psi; }
@@ -948,8 +1097,10 @@ class NGDFactorizedLinearGH : public NGDFactorDeviceOps {
  public:
   using CostFunction = std::function<double(const VectorXd&, const Factor&)>;
   NGDFactorizedLinearGH(const int& dimension, int dim_state, int gh_degree, const CostFunction& function, const Factor& linear_factor,
-                        int num_states, int start_indx, double temperature, double high_temperature)
-      : NGDFactorDeviceOps(dimension, dim_state, num_states, start_indx, temperature, high_temperature), _gh_degree(gh_degree),
+                        int num_states, int start_indx, double temperature, double high_temperature,
+                        std::optional<std::shared_ptr<QuadratureWeightsMap>> weight_sigpts_map_option = std::nullopt)   // :27-37
+      : NGDFactorDeviceOps(dimension, dim_state, num_states, start_indx, temperature, high_temperature, weight_sigpts_map_option),
+        _gh_degree(gh_degree),
         _function(function), _linear_factor(linear_factor), _psi(linear_factor.device_psi()),
         _target_mean(linear_factor.get_mu()), _target_precision(linear_factor.get_precision()), _Lambda(linear_factor.get_Lambda()),
         _Psi(linear_factor.get_Psi()), _constant(linear_factor.get_Constant()) {}
@@ -1418,7 +1569,7 @@ class GVIGH {
       for (; s < _sets.size(); ++s) {
         const auto& f0 = _vec_factors[_sets[s].members[0]];
         if (_sets[s].d == f->_dim && _sets[s].p == f->gh_degree() && f0->device_psi().same_group(dp) &&
-            f0->closed_form() == f->closed_form())
+            f0->closed_form() == f->closed_form() && f0->weights_map() == f->weights_map())
           break;
       }
       if (s == _sets.size()) _sets.push_back({f->_dim, f->gh_degree(), {}});

@@ -110,6 +110,15 @@ gvi_status gvi_chain_set(gvi_ctx* ctx, int T, int n);
 gvi_status gvi_factors_add(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
                            const double* psi_params, int64_t params_per_factor,
                            const double* temperature, int* set_id);
+/* gvi_factors_add with a caller-supplied quadrature table instead of the generated one: the counterpart of passing
+ * weight_sigpts_map_option (a shared QuadratureWeightsMap) to the factor constructors
+ * (ngd/NGDFactorizedBaseGH.h:41, ngd/NGDFactorizedLinearGH.h:36, gvibase/GVIFactorizedBaseGH.h:37) whose
+ * SparseGaussHermite then looks (d, p) up in that map (quadrature/SparseGaussHermite.h:138-166).  Z [N][d], w [N],
+ * host; nothing is generated (p is only recorded).  The table is private to the set. */
+gvi_status gvi_factors_add_table(gvi_ctx* ctx, int K, int d, int p, const int32_t* start, int psi_kind,
+                                 const double* psi_params, int64_t params_per_factor,
+                                 const double* temperature, int64_t N, const double* Z, const double* w,
+                                 int* set_id);
 /* Replace the set's quadrature table by a caller-supplied one (e.g. read from the reference's
  * cereal file quadrature/SparseGHQuadratureWeights_cereal.bin): Z [N][d], w [N], host. */
 gvi_status gvi_factors_set_table(gvi_ctx* ctx, int set_id, int64_t N, const double* Z, const double* w);

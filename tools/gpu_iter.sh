@@ -4,7 +4,7 @@
 # kernel trace of the default.  Output under gpurun_out/$R (R defaults to r03).
 set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}"
-R="${R:-r03}"
+R="${R:-r04}"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT="gpurun_out/$R"
 mkdir -p "$OUT"
