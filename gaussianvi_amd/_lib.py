@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgvi_hip.so")
+# GVI_LIB_PATH: an A/B build of the same sources (tools/build_variant.py); the default is the in-tree library
+LIB_PATH = os.environ.get("GVI_LIB_PATH") or os.path.join(HERE, "libgvi_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

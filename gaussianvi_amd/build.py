@@ -38,7 +38,9 @@ def lib_sources():
     return srcs
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+def build_lib(force: bool = False, verbose: bool = False, out: str | None = None, defines: tuple = ()) -> str:
+    """out / defines: an A/B build beside the in-tree library (tools/build_variant.py)."""
+    LIB = out or globals()["LIB"]
     if not force and not _stale(LIB, lib_sources()):
         return LIB
     tmp = LIB + f".tmp{os.getpid()}"          # written aside and renamed: a concurrent reader never sees a partial file
@@ -47,7 +49,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
            "-I", os.path.join(ROOT, "include"),
            os.path.join(CSRC, "gvi_hip.hip"), "-x", "hip", os.path.join(CSRC, "spgh.cpp"), os.path.join(CSRC, "table_io.cpp"),
            "-o", tmp]
-    for define in os.environ.get("GVI_BUILD_DEFINES", "").split():      # profiling builds, e.g. GVI_BCR_TIMING
+    for define in list(defines) + os.environ.get("GVI_BUILD_DEFINES", "").split():      # profiling builds, e.g. GVI_FUSED_TIMING
         cmd.insert(1, "-D" + define)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -62,7 +62,7 @@ struct Table {
   bool coded = false;
   // sign-orbit form (orbits.hpp; moments_orbit_kernel): host copy keeps only the tile lists, the rest lives on the device
   OrbitHost orb;
-  DevMem orb_cpk, orb_mag, orb_w, orb_ts, orb_tf;
+  DevMem orb_cpk, orb_rpk, orb_mag, orb_w;
   std::map<int, std::unique_ptr<DevMem>> orb_bounds;   // nchunk -> [nchunk + 1] tile bounds
 };
 
@@ -429,16 +429,15 @@ gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const dou
     OrbitHost o = build_orbits(d, N, Z, w, true);
     if (o.ok && o.smax >= 1) {
       HIPCK(c, t.orb_cpk.ensure(o.cpk.size() * 8));
+      HIPCK(c, t.orb_rpk.ensure(o.rpk.size() * 8));
+      HIPCK(c, hipMemcpy(t.orb_rpk.p, o.rpk.data(), o.rpk.size() * 8, hipMemcpyHostToDevice));
       HIPCK(c, t.orb_mag.ensure(o.mag.size() * 8));
       HIPCK(c, t.orb_w.ensure(o.w.size() * 8));
-      HIPCK(c, t.orb_ts.ensure(o.tile_s.size() * 4));
-      HIPCK(c, t.orb_tf.ensure(o.tile_first.size() * 4));
       HIPCK(c, hipMemcpy(t.orb_cpk.p, o.cpk.data(), o.cpk.size() * 8, hipMemcpyHostToDevice));
       HIPCK(c, hipMemcpy(t.orb_mag.p, o.mag.data(), o.mag.size() * 8, hipMemcpyHostToDevice));
       HIPCK(c, hipMemcpy(t.orb_w.p, o.w.data(), o.w.size() * 8, hipMemcpyHostToDevice));
-      HIPCK(c, hipMemcpy(t.orb_ts.p, o.tile_s.data(), o.tile_s.size() * 4, hipMemcpyHostToDevice));
-      HIPCK(c, hipMemcpy(t.orb_tf.p, o.tile_first.data(), o.tile_first.size() * 4, hipMemcpyHostToDevice));
       std::vector<uint64_t>().swap(o.cpk);
+      std::vector<uint64_t>().swap(o.rpk);
       std::vector<double>().swap(o.mag);
       std::vector<double>().swap(o.w);
       t.orb = std::move(o);
@@ -623,9 +622,23 @@ gvi_status orbit_args(gvi_ctx* c, FactorSet& s, int full, OrbitArgs* out) {
   const size_t lds_cap = std::min<size_t>(64 * 1024, 160 * 1024 / waves);
   a.copies = 1;
   while (a.copies * 2 <= c->orbit_copies && (size_t)4 * orbit_lds_doubles(s.d, s.m, a.copies * 2) * 8 <= lds_cap) a.copies *= 2;
-  a.ob.cpk = (const uint64_t*)t.orb_cpk.p; a.ob.mag = t.orb_mag.d(); a.ob.w = t.orb_w.d();
-  a.ob.tile_s = t.orb_ts.i(); a.ob.tile_first = t.orb_tf.i(); a.ob.bounds = it->second->i();
+  a.ob.cpk = (const uint64_t*)t.orb_cpk.p; a.ob.rpk = (const uint64_t*)t.orb_rpk.p; a.ob.mag = t.orb_mag.d(); a.ob.w = t.orb_w.d();
+  a.ob.bounds = it->second->i();
   a.ob.norb_p = t.orb.norb_p; a.ob.w0 = t.orb.w0;
+  {   // the tile list as kernel arguments (OrbitDev): class ends and, for up to four chunks, the chunk bounds
+    int32_t cum = 0;
+    for (int sz = 7; sz >= 0; --sz) {
+      if (sz >= 1 && sz <= t.orb.smax) cum += (int32_t)((t.orb.count[sz] + 63) / 64);
+      a.ob.cend[sz] = sz > t.orb.smax ? 0 : cum;
+    }
+    a.ob.nb = 0;
+    for (int i = 0; i < 5; ++i) a.ob.bnd[i] = 0;
+    if (s.nchunk <= 4) {
+      const std::vector<int32_t> b = orbit_chunk_bounds(t.orb, s.nchunk);
+      a.ob.nb = s.nchunk;
+      for (int i = 0; i <= s.nchunk; ++i) a.ob.bnd[i] = b[(size_t)i];
+    }
+  }
   (void)full;
   *out = a;
   return GVI_OK;
@@ -686,7 +699,7 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
   const int dbg = getenv("GVI_FUSED_DBG") ? atoi(getenv("GVI_FUSED_DBG")) : 0;
   static unsigned long long* stamps = nullptr;
   static int nprint = 0;
-  if ((dbg & 8) && !stamps) { if (hipMalloc(&stamps, 352 * 8) != hipSuccess) stamps = nullptr; else (void)hipMemset(stamps, 0, 352 * 8); }
+  if ((dbg & 8) && !stamps) { if (hipMalloc(&stamps, 1120 * 8) != hipSuccess) stamps = nullptr; else (void)hipMemset(stamps, 0, 1120 * 8); }
 #else
   const int dbg = 0;
   unsigned long long* stamps = nullptr;
@@ -695,9 +708,16 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
                         (dbg & 8) ? stamps : (unsigned long long*)nullptr);
 #ifdef GVI_FUSED_TIMING
   if ((dbg & 8) && stamps && ++nprint > 200 && nprint <= 202) {          // a few warm launches, 100 MHz ticks
-    unsigned long long h[352];
+    unsigned long long h[1120];
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+    for (int blk = 0; blk < 8; ++blk)
+      for (int w = 0; w < 4; ++w)
+        for (int it = 0; it < 2; ++it) {
+          const unsigned long long* ws = h + 352 + ((blk * 4 + w) * 2 + it) * 12;
+          fprintf(stderr, "[walk stamps] block %4d wave %d item %d: shader cycles prologue %llu | s=1 %llu (%llu tiles) | s=2 %llu (%llu) | s=3 %llu (%llu) | s=4 %llu (%llu) | reduction %llu\n",
+                  blk * 146, w, it, ws[0], ws[1], ws[7], ws[2], ws[8], ws[3], ws[9], ws[4], ws[10], ws[5]);
+        }
     fprintf(stderr, "[prep stamps] block 0 wave 0, us after the block's start: [Sigma row loaded | Cholesky | L^-1 | LDS + Lam + stores | H, u0]:");
     for (int i = 0; i < 6; ++i) fprintf(stderr, " %.2f", (double)(long long)(h[256 + i] - h[0]) * 0.01);
     fprintf(stderr, "\n");

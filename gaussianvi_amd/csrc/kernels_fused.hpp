@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
 #define FUSED_STAMP(i) do { } while (0)
 #endif
 #ifdef GVI_FUSED_TIMING
-  if (blockIdx.x == 0 && threadIdx.x == 0) gvi_prep_stamps = stamps ? stamps + 8 * 32 : nullptr;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { gvi_prep_stamps = stamps ? stamps + 8 * 32 : nullptr; gvi_walk_stamps = stamps ? stamps + 352 : nullptr; }
 #endif
   FUSED_STAMP(0);
 #ifdef GVI_FUSED_TIMING

@@ -32,16 +32,67 @@ namespace gvi {
 #define ORBIT_WHT 1      // 0: per-point accumulation of the sign-weighted sums for every support size (A/B build)
 #endif
 
+#ifdef GVI_FUSED_TIMING
+__device__ unsigned long long* gvi_walk_stamps;
+#endif
+
 struct OrbitDev {
   const uint64_t* cpk;       // [norb_p] support coordinates, one byte each
+  const uint64_t* rpk;       // [norb_p] packed-triangle row bases of the coordinates, ten bits each (OrbitRec)
   const double* mag;         // [smax][norb_p]
   const double* w;           // [norb_p]
-  const int32_t* tile_s;     // [ntiles]
-  const int32_t* tile_first; // [ntiles]
   const int32_t* bounds;     // [nchunk + 1] tile ranges of the chunks
   int64_t norb_p;
   double w0;                 // weight of the origin
+  // The tile list without memory accesses: the classes are stored by descending support size, every class padded to whole
+  // tiles, so tile t starts at orbit 64 t and has support s iff cend[s + 1] <= t < cend[s] (cend[s] = one past the last
+  // tile of class s; 0 above the table's largest support).  bnd: the chunk bounds themselves when nchunk <= 4 (nb =
+  // nchunk; else 0 and `bounds` is read).  A wave used to start every tile with two dependent round trips to memory
+  // (tile_s / tile_first, then the orbit records): ~1200 cycles per tile whatever its support (walk stamps of the timing
+  // build: 1450 / 2290 / 2950 / 3450 cycles per s = 1 / 2 / 3 / 4 tile against 280 / 440 / 720 / 1340 of VALU issue).
+  int32_t cend[8];
+  int32_t bnd[5];
+  int32_t nb;
 };
+
+// the record of one orbit (one lane of a tile).  rpk: ten bits per support coordinate, R_i = packed-triangle index of
+// (c_i, 0) in the accumulator layout [m0 | m1[d] | upper triangle by rows], i.e. entry (c_i, c_j) sits at R_i + c_j
+// (orbits.hpp) -- computing it per orbit cost ~6 integer instructions per coordinate in a walk that is bound by VALU issue
+template <int S>
+struct OrbitRec { uint64_t cpk, rpk; double w; double mg[S]; };
+// element `boff` BYTES behind a wave-uniform base: scalar base + 32-bit lane offset, no 64-bit address arithmetic
+template <typename T>
+__device__ __forceinline__ T orbit_ld(const T* base, const uint32_t boff) { return *(const T*)((const char*)base + boff); }
+// boff = 8 * orbit index (< 2^31 orbits, host-checked: 8 smax norb_p < 2^32 too)
+template <int S>
+__device__ __forceinline__ void orbit_load(const OrbitDev& ob, const uint32_t boff, OrbitRec<S>& r) {
+  r.cpk = orbit_ld(ob.cpk, boff);
+  if constexpr (S >= 1) r.rpk = orbit_ld(ob.rpk, boff);
+  r.w = orbit_ld(ob.w, boff);
+#pragma unroll
+  for (int j = 0; j < S; ++j) r.mg[j] = orbit_ld(ob.mag + (size_t)j * ob.norb_p, boff);
+}
+struct OrbitNoPre { __device__ __forceinline__ void operator()() const {} };
+
+// 64-bit DPP move (two 32-bit halves): cross-lane sums without the LDS pipe -- __shfl_xor is ds_bpermute, which queues
+// behind the wave's own and the other waves' accumulator atomics
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(const double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, valid in every lane's SGPR copy (fixed association: quads, rows of 16, then the four rows)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);        // quad_perm [1, 0, 3, 2]
+  v += dpp_f64<0x4E>(v);        // quad_perm [2, 3, 0, 1]
+  v += dpp_f64<0x124>(v);       // row_ror 4
+  v += dpp_f64<0x128>(v);       // row_ror 8
+  auto row = [&](int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  };
+  return (row(0) + row(16)) + (row(32) + row(48));
+}
 
 // one factor set on the orbit kernel: the psi operands of prep_kernel + the orbit table
 struct OrbitArgs {
@@ -64,19 +115,83 @@ __host__ __device__ constexpr int orbit_hstride(int M) { return M == 12 ? 14 : M
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// The accumulator adds of one orbit.  Values and LDS addresses are formed FIRST (the record's registers die there), then
+// pre() requests the next tile's records into those registers, then the adds go out.  accb: byte address of this lane's
+// copy of entry 0; entry e lives at accb + (e << sh), sh = log2(copies) + 3.
+template <int S, typename Pre>
+__device__ __forceinline__ void orbit_accumulate(const int sh, const int (&c)[S], const uint64_t rpk, const double (&mg)[S], const double wp,
+                                                 const double E0, const double (&Eij)[S * (S - 1) / 2 + 1], const double (&Oi)[S],
+                                                 double* accb, Pre&& pre) {
+  constexpr int NV = 2 * S + S * (S - 1) / 2;
+  const double w4 = wp + wp;
+  double val[NV];
+  {
+    // The scale factors w m_i, w m_i m_j depend on the record alone: left to itself the scheduler forms all of them at the
+    // top of the tile and keeps fourteen doubles alive through the walk (28 registers: the kernel then spills inside its
+    // hot loop, 26 -> 39 us).  The empty asm ties the magnitudes to E0, which is final only here.
+    double mgl[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) { mgl[j] = mg[j]; asm volatile("" : "+v"(mgl[j]) : "v"(E0)); }
+    int n = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      const double wm = wp * mgl[i];
+      val[n++] = w4 * mgl[i] * Oi[i];
+      val[n++] = wm * mgl[i] * E0;
+#pragma unroll
+      for (int j = i + 1; j < S; ++j) val[n++] = wm * mgl[j] * Eij[e++];
+    }
+  }
+  pre();
+  char* const base = (char*)accb;
+  char* const base1 = base + (1u << sh);                         // m1[0]
+  unsigned A[S], B[S];
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    const unsigned lo = (unsigned)rpk, hi = (unsigned)(rpk >> 32);
+    const unsigned R = i < 3 ? (lo >> (10 * i)) & 1023u : (hi >> (10 * (i - 3))) & 1023u;
+    A[i] = R << sh;
+    B[i] = (unsigned)c[i] << sh;
+  }
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    lds_add_f64((double*)(base1 + B[i]), val[n++]);
+    lds_add_f64((double*)(base + (A[i] + B[i])), val[n++]);
+#pragma unroll
+    for (int j = i + 1; j < S; ++j) lds_add_f64((double*)(base + (A[i] + B[j])), val[n++]);
+  }
+}
+
+#ifndef ORBIT_LB4
+#define ORBIT_LB4 2
+#endif
+#ifndef GVI_EXP_EXTRA_FMA
+#define GVI_EXP_EXTRA_FMA 0      // timing experiment: this many extra independent fp64 FMAs per half-point
+#endif
+#ifndef GVI_EXP_NOCOL
+#define GVI_EXP_NOCOL 0        // timing experiment (WRONG results): the columns of H are made up instead of read from LDS
+#endif
+#ifndef GVI_EXP_NOATOM
+#define GVI_EXP_NOATOM 0       // timing experiment (WRONG results): the accumulator adds of supports <= this size are skipped
+#endif
 
 // one orbit per lane, support size S (all lanes of the wave: tiles are uniform in S)
-template <int M, int S, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint64_t cpk, const double (&mg)[S], const double w,
+// pre(): called between the Gray walk and the accumulator adds -- where the walk's registers are dead -- to request the
+// NEXT tile's records (orbit_class)
+template <int M, int S, bool FULL, bool SIGNED, typename Pre>
+__device__ __forceinline__ void orbit_walk(const int lc, const uint64_t cpk, const uint64_t rpk, const double (&mg)[S], const double w,
                                            const double* Hl, double* accl, const double (&su0)[M], const double (&sg)[M],
-                                           const double k0, double& m0) {
+                                           const double k0, double& m0, Pre&& pre) {
   int c[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) c[j] = (int)((cpk >> (8 * j)) & 255u);
   // the support's columns of H: in registers while they fit (M S <= 36 doubles); otherwise the column of the NEXT flip is
   // fetched from LDS while the current point is evaluated (the compiler barrier keeps the loads from being hoisted back
   // into one register-resident block)
-  constexpr bool HREG = M * S <= 36;
+  // m = 6, s = 4 (24 doubles) would fit too, but the kernel then needs more than the 128 registers of four waves per SIMD
+  // and spills inside this loop (measured: 26 -> 39 us); its columns stay in LDS, column 0 in registers (H0REG)
+  constexpr bool HREG = M * S <= 36 && !(M == 6 && S >= 4);
   constexpr int NH = 1 << (S - 1);
   double hcol[HREG ? S : 1][M];
   const double* hp[S];
@@ -85,7 +200,7 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
     hp[j] = Hl + c[j] * orbit_hstride(M);
     if constexpr (HREG) {
 #pragma unroll
-      for (int r = 0; r < M; ++r) hcol[j][r] = hp[j][r];
+      for (int r = 0; r < M; ++r) hcol[j][r] = GVI_EXP_NOCOL ? (double)(c[j] + r) * w : hp[j][r];
     }
   }
   // start at the corner (-, ..., -, +): the last coordinate keeps its sign, the other S-1 are walked in Gray order
@@ -94,7 +209,7 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
   for (int j = 0; j < S; ++j) sig[j] = j == S - 1 ? 1 : -1;
   double v[M];
 #pragma unroll
-  for (int r = 0; r < M; ++r) v[r] = mg[S - 1] * hp[S - 1][r];
+  for (int r = 0; r < M; ++r) v[r] = mg[S - 1] * (HREG ? hcol[S - 1][r] : hp[S - 1][r]);
 #pragma unroll
   for (int j = 0; j < S - 1; ++j) {
     if constexpr (!HREG) {                                      // one column in flight at a time
@@ -102,7 +217,7 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
       for (int r = 0; r < M; ++r) asm volatile("" : "+v"(v[r]) :: "memory");
     }
 #pragma unroll
-    for (int r = 0; r < M; ++r) v[r] = fma(-mg[j], hp[j][r], v[r]);
+    for (int r = 0; r < M; ++r) v[r] = fma(-mg[j], HREG ? hcol[j][r] : hp[j][r], v[r]);
   }
   // !HREG: the column of coordinate 0 -- flipped at every other step of the Gray walk -- stays in registers when H0REG
   constexpr bool H0REG = !HREG && M * (S + 9) <= 168;     // m = 12: s <= 5 (s = 6 would spill)
@@ -118,7 +233,12 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
   // block's sums.  WHT_BIG: also for s = 5, 6 (needs the registers: not at m = 12).
   constexpr bool WHT_BIG = M <= 6;
   constexpr bool WHT = FULL && S >= 2 && ORBIT_WHT && (S <= 4 || WHT_BIG);
-  constexpr int LB = S - 1 < 3 ? S - 1 : 3;          // coordinates whose signs vary inside a block of 2^LB consecutive Gray steps
+  // coordinates whose signs vary inside a block of 2^LB consecutive Gray steps.  s = 4 takes two blocks of four instead of
+  // one of eight: the same number of additions (two 4-point butterflies per scalar + 11 signed adds for the second block
+  // against one 8-point butterfly) with 16 fewer live registers -- which is what lets the next tile's records be requested
+  // under the current tile's accumulator adds without spilling (orbit_class)
+  constexpr int LBMAX = S == 4 ? ORBIT_LB4 : 3;
+  constexpr int LB = S - 1 < LBMAX ? S - 1 : LBMAX;
   constexpr int BLK = 1 << LB;
   double cpv[WHT ? BLK : 1], lv[WHT ? BLK : 1];
   double E0 = 0.0, Eij[S * (S - 1) / 2 + 1], Oi[S];
@@ -126,6 +246,9 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
   for (int e = 0; e < S * (S - 1) / 2 + 1; ++e) Eij[e] = 0.0;
 #pragma unroll
   for (int j = 0; j < S; ++j) Oi[j] = 0.0;
+#if GVI_EXP_EXTRA_FMA
+  double xdum[6] = {0, 0, 0, 0, 0, 0};
+#endif
 #pragma unroll
   for (int g = 0; g < NH; ++g) {
     const int jn = g + 1 < NH ? __builtin_ctz(g + 1) : 0;        // coordinate of the next flip (compile-time after unrolling)
@@ -145,6 +268,10 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
       q = SIGNED ? fma(sg[r] * v[r], v[r], q) : fma(v[r], v[r], q);
       if (FULL) l = fma(su0[r], v[r], l);
     }
+#if GVI_EXP_EXTRA_FMA
+#pragma unroll
+    for (int r = 0; r < GVI_EXP_EXTRA_FMA; ++r) xdum[r % 6] = fma(v[r % M], v[(r + 1) % M], xdum[r % 6]);
+#endif
     const double cp = q + k0;
     if constexpr (WHT) {
       // keep (c+, l) of this sign pattern of the low coordinates; at the end of a block: butterfly, then add the block's
@@ -206,21 +333,21 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
   }
   const double wp = w + w;
   m0 = fma(wp, E0, m0);
-  if (FULL) {
-    // accl points at this lane's copy: entry e lives at accl[e * C], C = 1 << lc.  Index arithmetic in shifts and 24-bit
-    // multiplies: v_mul_lo_u32 is a quarter-rate instruction and the s = 4 tile had 18 of them (288 of its 1560 VALU cycles)
-    const double w4 = wp + wp;
-    int e = 0;
+#if GVI_EXP_EXTRA_FMA
+  m0 = fma(1e-300, ((xdum[0] + xdum[1]) + (xdum[2] + xdum[3])) + (xdum[4] + xdum[5]), m0);
+#endif
+  if constexpr (FULL && S <= GVI_EXP_NOATOM) {
+    double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-      const int a = c[i];
-      const double wm = wp * mg[i];
-      lds_add_f64(accl + ((1 + a) << lc), w4 * mg[i] * Oi[i]);
-      const int row = 1 + d + __mul24(a, d) - (__mul24(a, a - 1) >> 1) - a;       // packed index of (a, b) = row + b
-      lds_add_f64(accl + ((row + a) << lc), wm * mg[i] * E0);
+    for (int i = 0; i < S; ++i) t += Oi[i];
 #pragma unroll
-      for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + ((row + c[j]) << lc), wm * mg[j] * Eij[e]); ++e; }
-    }
+    for (int e = 0; e < S * (S - 1) / 2; ++e) t += Eij[e];
+    m0 = fma(1e-300, t, m0);
+    pre();
+  } else if constexpr (FULL) {
+    orbit_accumulate<S>(lc + 3, c, rpk, mg, wp, E0, Eij, Oi, accl, pre);
+  } else {
+    pre();
   }
 }
 
@@ -234,18 +361,18 @@ __device__ __forceinline__ void orbit_walk(const int d, const int lc, const uint
 #ifndef GVI_ORBIT_SPLIT12
 #define GVI_ORBIT_SPLIT12 1
 #endif
-template <int S, bool SIGNED>
-__device__ __forceinline__ void orbit_walk_split(const int d, const int lc, const uint64_t cpk, const double (&mg)[S], const double w,
+template <int S, bool SIGNED, typename Pre>
+__device__ __forceinline__ void orbit_walk_split(const int lc, const uint64_t cpk, const uint64_t rpk, const double (&mg)[S], const double w,
                                                  const double* Hl, double* accl, const double (&su0)[12], const double (&sg)[12],
-                                                 const double k0, double& m0) {
+                                                 const double k0, double& m0, Pre&& pre) {
   constexpr int MH = 6, HS = orbit_hstride(12), NH = 1 << (S - 1), LB = 3, BLK = 8;
   static_assert(S >= 4 && S <= 6, "split walk: s = 4, 5, 6 (blocks of 8 Gray steps)");
   int c[S];
 #pragma unroll
   for (int j = 0; j < S; ++j) c[j] = (int)((cpk >> (8 * j)) & 255u);
-  double E0 = 0.0, Eij[S * (S - 1) / 2], Oi[S];
+  double E0 = 0.0, Eij[S * (S - 1) / 2 + 1], Oi[S];
 #pragma unroll
-  for (int e = 0; e < S * (S - 1) / 2; ++e) Eij[e] = 0.0;
+  for (int e = 0; e < S * (S - 1) / 2 + 1; ++e) Eij[e] = 0.0;
 #pragma unroll
   for (int j = 0; j < S; ++j) Oi[j] = 0.0;
 #pragma clang loop unroll(disable)
@@ -331,30 +458,45 @@ __device__ __forceinline__ void orbit_walk_split(const int d, const int lc, cons
   }
   const double wp = w + w;
   m0 = fma(wp, E0, m0);
-  const double w4 = wp + wp;
-  int e = 0;
-#pragma unroll
-  for (int i = 0; i < S; ++i) {
-    const int a = c[i];
-    const double wm = wp * mg[i];
-    lds_add_f64(accl + ((1 + a) << lc), w4 * mg[i] * Oi[i]);
-    const int row = 1 + d + __mul24(a, d) - (__mul24(a, a - 1) >> 1) - a;
-    lds_add_f64(accl + ((row + a) << lc), wm * mg[i] * E0);
-#pragma unroll
-    for (int j = i + 1; j < S; ++j) { lds_add_f64(accl + ((row + c[j]) << lc), wm * mg[j] * Eij[e]); ++e; }
-  }
+  orbit_accumulate<S>(lc + 3, c, rpk, mg, wp, E0, Eij, Oi, accl, pre);
 }
 
+// the tiles [t0, t1) of ONE support-size class, software-pipelined: the records of tile t + 1 are requested while tile t
+// still has its accumulator adds to issue, so that their round trip overlaps the adds and the next tile's column reads
+#ifndef ORBIT_PIPE_SMAX
+#define ORBIT_PIPE_SMAX 3
+#endif
+// t0, t1 are wave-uniform (SGPRs); lane8 = 8 * lane.  (Requesting the chunk's first tile ahead of orbit_wave's prologue was
+// tried: the record stays live through every class loop -- 14 registers, spills -- for no gain.)
 template <int M, int S, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_tile(const OrbitDev& ob, const int d, const int lc, const int64_t o, const double* Hl, double* accl,
-                                           const double (&su0)[M], const double (&sg)[M], const double k0, double& m0) {
-  const uint64_t cpk = ob.cpk[o];
-  const double w = ob.w[o];
-  double mg[S];
+__device__ __forceinline__ void orbit_class(const OrbitDev& ob, const int lc, const int t0, const int t1, const uint32_t lane8,
+                                            const double* Hl, double* accl, const double (&su0)[M], const double (&sg)[M], const double k0,
+                                            double& m0) {
+  if (t0 >= t1) return;
+  // s >= 4: a tile is long enough (290 VALU instructions and more) for its own load latency not to matter, and its walk
+  // leaves no 14 registers for the next tile's records
+  constexpr bool PIPE = S <= ORBIT_PIPE_SMAX;
+  OrbitRec<S> cur;
+  if constexpr (PIPE) orbit_load<S>(ob, (uint32_t)t0 * 512u + lane8, cur);
+  for (int t = t0; t < t1; ++t) {
+    if constexpr (!PIPE) orbit_load<S>(ob, (uint32_t)t * 512u + lane8, cur);
+    const int tn = t + 1 < t1 ? t + 1 : t;                      // (the last tile requests itself again: no branch)
+    // the next tile's records go straight into cur: by the time pre() runs the walk has consumed the current ones
+    auto pre = [&]() {
+      if constexpr (PIPE) {
+        __builtin_amdgcn_sched_barrier(0);
+        orbit_load<S>(ob, (uint32_t)tn * 512u + lane8, cur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    const uint64_t cpk = cur.cpk, rpk = cur.rpk;
+    const double w = cur.w;
+    double mg[S];
 #pragma unroll
-  for (int j = 0; j < S; ++j) mg[j] = ob.mag[(size_t)j * ob.norb_p + o];
-  if constexpr (M == 12 && S >= 4 && FULL && GVI_ORBIT_SPLIT12 != 0) orbit_walk_split<S, SIGNED>(d, lc, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
-  else orbit_walk<M, S, FULL, SIGNED>(d, lc, cpk, mg, w, Hl, accl, su0, sg, k0, m0);
+    for (int j = 0; j < S; ++j) mg[j] = cur.mg[j];
+    if constexpr (M == 12 && S >= 4 && FULL && GVI_ORBIT_SPLIT12 != 0) orbit_walk_split<S, SIGNED>(lc, cpk, rpk, mg, w, Hl, accl, su0, sg, k0, m0, pre);
+    else orbit_walk<M, S, FULL, SIGNED>(lc, cpk, rpk, mg, w, Hl, accl, su0, sg, k0, m0, pre);
+  }
 }
 
 // out: where the chunk's partial sums go -- the set's partial array (stand-alone launches) or LDS (factor_fused_kernel).
@@ -368,7 +510,16 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
                                            const double* Hpre = nullptr, const double* u0pre = nullptr) {
   const OrbitDev& ob = a.ob;
   const int lane = threadIdx.x & 63, d = a.d;
+#ifdef GVI_FUSED_TIMING
+  const long long wt_start = clock64();
+#endif
   const int NP = FULL ? (d + 1) * (d + 2) / 2 : 1;
+  int tb, te;
+  if (ob.nb) { tb = ob.bnd[chunk]; te = ob.bnd[chunk + 1]; }
+  else { tb = ob.bounds[chunk]; te = ob.bounds[chunk + 1]; }
+  tb = __builtin_amdgcn_readfirstlane(tb);       // (wave-uniform: the tile loops run on the scalar unit)
+  te = __builtin_amdgcn_readfirstlane(te);
+  const uint32_t lane8 = (uint32_t)lane * 8u;
   const double* Hl = Hpre ? Hpre : lds;          // [d][M]: column c of H = the M operands of coordinate c
   // [NP][C] moment accumulators of this (factor, chunk): C private copies per entry, a lane adds to copy lane % C.  A
   // ds_add_f64 whose lanes hit one address costs ~3 cycles per lane (64-way: 192 cycles, tools/ubench/lds_atomic.hip);
@@ -396,34 +547,67 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
   }
   wave_lds_sync();
   double m0 = 0.0;
-  const int tb = ob.bounds[chunk], te = ob.bounds[chunk + 1];
-  for (int t = tb; t < te; ++t) {
-    const int s = __builtin_amdgcn_readfirstlane(ob.tile_s[t]);
-    const int64_t o = (int64_t)ob.tile_first[t] + lane;
-    if constexpr (SMAX > 4) {
-      if (s == 6) { orbit_tile<M, 6, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); continue; }
-      if (s == 5) { orbit_tile<M, 5, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); continue; }
-    }
-    switch (s) {
-      case 1: orbit_tile<M, 1, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
-      case 2: orbit_tile<M, 2, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
-      case 3: orbit_tile<M, 3, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
-      default: orbit_tile<M, 4, FULL, SIGNED>(ob, d, lc, o, Hl, accme, su0, sg, k0, m0); break;
-    }
+#ifdef GVI_FUSED_TIMING
+  // shader-clock cycles of this wave per tile class (timing build): [prologue | s = 1..4 | reduction] + tile counts
+  long long wt_last = clock64(), wt_acc[6] = {0, 0, 0, 0, 0, 0}, wt_n[5] = {0, 0, 0, 0, 0};
+  wt_acc[0] = wt_last - wt_start;
+#define ORBIT_CLASS_STAMP(S_, n_) do { if ((S_) <= 4) { const long long now = clock64(); wt_acc[S_] += now - wt_last; wt_n[S_] += (n_); wt_last = now; } } while (0)
+#else
+#define ORBIT_CLASS_STAMP(S_, n_) do { } while (0)
+#endif
+  // class after class (descending support size); the classes' tile ranges are kernel arguments, tile t starts at orbit 64 t
+  int tcur = tb;
+#define ORBIT_RUN_CLASS(S_)                                                                           \
+  {                                                                                                   \
+    const int e_ = te < ob.cend[S_] ? te : ob.cend[S_];                                                \
+    if (tcur < e_) { orbit_class<M, S_, FULL, SIGNED>(ob, lc, tcur, e_, lane8, Hl, accme, su0, sg, k0, m0); ORBIT_CLASS_STAMP(S_, e_ - tcur); tcur = e_; } \
   }
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) m0 += __shfl_xor(m0, sh);
+  if constexpr (SMAX > 4) {
+    ORBIT_RUN_CLASS(6)
+    ORBIT_RUN_CLASS(5)
+  }
+  ORBIT_RUN_CLASS(4)
+  ORBIT_RUN_CLASS(3)
+  ORBIT_RUN_CLASS(2)
+  ORBIT_RUN_CLASS(1)
+#undef ORBIT_RUN_CLASS
+#undef ORBIT_CLASS_STAMP
+  m0 = wave_sum_f64(m0);
   if (chunk == 0) m0 = fma(ob.w0, k0, m0);       // the origin: psi(0) = sum_r s_r u0_r^2
   wave_lds_sync();
   if (lane == 0) out[0] = m0;
-  if (FULL)
-    for (int e = 1 + lane; e < NP; e += 64) {
-      // copies in a fixed, lane-rotated order: with every lane starting at copy 0 each fourth lane sits on the same banks
-      const int rot = (lane >> 2) & (C - 1);
-      double t = accl[e * C + rot];
-      for (int q = 1; q < C; ++q) t += accl[e * C + ((q + rot) & (C - 1))];
-      out[e] = t;
+  if (FULL) {
+    // copies in a fixed, lane-rotated order: with every lane starting at copy 0 each fourth lane sits on the same banks.
+    // The usual eight copies: all reads of an entry in flight before the first add (with the run-time copy count the loop
+    // below is eight DEPENDENT LDS round trips per entry: 4400 cycles of a wave's 30 000 at (12,5), walk stamps)
+    if (C == 8) {
+      for (int e = 1 + lane; e < NP; e += 64) {
+        const int rot = (lane >> 2) & 7;
+        double c8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c8[q] = accl[e * 8 + ((q + rot) & 7)];
+        double t = c8[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += c8[q];
+        out[e] = t;
+      }
+    } else {
+      for (int e = 1 + lane; e < NP; e += 64) {
+        const int rot = (lane >> 2) & (C - 1);
+        double t = accl[e * C + rot];
+        for (int q = 1; q < C; ++q) t += accl[e * C + ((q + rot) & (C - 1))];
+        out[e] = t;
+      }
     }
+  }
+#ifdef GVI_FUSED_TIMING
+  if (gvi_walk_stamps && lane == 0 && (blockIdx.x % 146) == 0) {
+    wt_acc[5] = clock64() - wt_last;
+    unsigned long long* ws = gvi_walk_stamps + (((blockIdx.x / 146) * 4 + (threadIdx.x >> 6)) * 2 + (d == 12 ? 0 : 1)) * 12;
+    for (int i = 0; i < 6; ++i) ws[i] = (unsigned long long)wt_acc[i];
+    for (int i = 1; i < 5; ++i) ws[6 + i] = (unsigned long long)wt_n[i];
+  }
+#endif
 }
 
 template <bool FULL>

@@ -24,6 +24,9 @@ struct OrbitHost {
   // orbits sorted by support size DESCENDING, each size class padded to a multiple of 64 with zero-weight orbits
   int64_t norb_p = 0;
   std::vector<uint64_t> cpk;                      // [norb_p] coordinates, one byte each (c_0 in the low byte)
+  // [norb_p] ten bits per coordinate: R_i = 1 + d + c_i d - c_i (c_i - 1) / 2 - c_i, the index of (c_i, 0) in the packed
+  // accumulator layout [m0 | m1[d] | upper triangle by rows] -- entry (c_i, c_j), i <= j, is R_i + c_j
+  std::vector<uint64_t> rpk;
   std::vector<double> mag;                        // [smax][norb_p]
   std::vector<double> w;                          // [norb_p]
   std::vector<int32_t> tile_s, tile_first;        // per 64-orbit tile: support size, first orbit index
@@ -34,7 +37,7 @@ struct OrbitHost {
 // constructs the grid by reflection.
 inline OrbitHost build_orbits(int d, int64_t N, const double* Z, const double* w, bool verify) {
   OrbitHost o;
-  if (d > 255) return o;
+  if (d > 32) return o;                                         // (rpk: ten bits per row base)
   struct Rep { int64_t row; int s; };
   std::vector<Rep> reps;
   int64_t covered = 0;
@@ -89,6 +92,7 @@ inline OrbitHost build_orbits(int d, int64_t N, const double* Z, const double* w
   o.norb_p = 0;
   for (int s = o.smax; s >= 1; --s) o.norb_p += (o.count[s] + 63) / 64 * 64;
   o.cpk.assign(o.norb_p, 0);
+  o.rpk.assign(o.norb_p, 0);
   o.mag.assign((size_t)o.smax * o.norb_p, 0.0);
   o.w.assign(o.norb_p, 0.0);
   int64_t pos = 0;
@@ -111,16 +115,23 @@ inline OrbitHost build_orbits(int d, int64_t N, const double* Z, const double* w
     for (int64_t q = 0; q < cnt; ++q) {
       const Rep& rep = reps[class_first + (size_t)((q * P) % cnt)];
       const double* z = Z + (size_t)rep.row * d;
-      uint64_t pk = 0;
+      uint64_t pk = 0, rk = 0;
       int j = 0;
       for (int a = 0; a < d; ++a)
-        if (z[a] != 0.0) { pk |= (uint64_t)a << (8 * j); o.mag[(size_t)j * o.norb_p + pos + q] = z[a]; ++j; }
+        if (z[a] != 0.0) {
+          pk |= (uint64_t)a << (8 * j);
+          const uint64_t R = (uint64_t)(1 + d + a * d - a * (a - 1) / 2 - a);
+          rk |= R << (j < 3 ? 10 * j : 32 + 10 * (j - 3));
+          o.mag[(size_t)j * o.norb_p + pos + q] = z[a];
+          ++j;
+        }
       o.cpk[pos + q] = pk;
+      o.rpk[pos + q] = rk;
       o.w[pos + q] = w[rep.row];
     }
     pos += padded;
   }
-  if (o.norb_p >= ((int64_t)1 << 31)) return OrbitHost();
+  if (o.norb_p >= ((int64_t)1 << 28)) return OrbitHost();      // the kernel addresses a record by a 32-bit byte offset
   o.ok = true;
   return o;
 }
