@@ -628,8 +628,14 @@ gvi_status orbit_args(gvi_ctx* c, FactorSet& s, int full, OrbitArgs* out) {
   {   // the tile list as kernel arguments (OrbitDev): class ends and, for up to four chunks, the chunk bounds
     int32_t cum = 0;
     for (int sz = 7; sz >= 0; --sz) {
-      if (sz >= 1 && sz <= t.orb.smax) cum += (int32_t)((t.orb.count[sz] + 63) / 64);
+      if (sz >= 1 && sz <= t.orb.smax) cum += t.orb.cstride[sz] / 64;           // tiles of the class
       a.ob.cend[sz] = sz > t.orb.smax ? 0 : cum;
+    }
+    for (int sz = 0; sz < 8; ++sz) {
+      const bool in = sz >= 1 && sz <= t.orb.smax;
+      a.ob.cbase[sz] = in ? t.orb.cbase[sz] : 0;
+      a.ob.cgrp[sz] = in ? t.orb.cgrp[sz] : 1;
+      a.ob.cstride[sz] = in ? t.orb.cstride[sz] : 0;
     }
     a.ob.nb = 0;
     for (int i = 0; i < 5; ++i) a.ob.bnd[i] = 0;

@@ -53,6 +53,9 @@ struct OrbitDev {
   int32_t cend[8];
   int32_t bnd[5];
   int32_t nb;
+  // support-major classes (orbits.hpp): lane `l` of the class's tile `tl` owns the cgrp[s] orbits at entries
+  // cbase[s] + 64 tl + l + g cstride[s], g = 0 .. cgrp[s] - 1 (all of one support; cgrp = 1: one orbit per lane)
+  int32_t cbase[8], cgrp[8], cstride[8];
 };
 
 // the record of one orbit (one lane of a tile).  rpk: ten bits per support coordinate, R_i = packed-triangle index of
@@ -461,15 +464,196 @@ __device__ __forceinline__ void orbit_walk_split(const int lc, const uint64_t cp
   orbit_accumulate<S>(lc + 3, c, rpk, mg, wp, E0, Eij, Oi, accl, pre);
 }
 
+// The Gray walk of ONE orbit, the support's columns in registers (orbit_walk's HREG case as a function of its own): the
+// sign-weighted sums E0 = sum (q + k0), Oi = sum sigma_i l, Eij = sum sigma_i sigma_j (q + k0) over the half orbit.
+template <int M, int S, bool FULL, bool SIGNED>
+__device__ __forceinline__ void orbit_gray(const double (&hcol)[S][M], const double (&mg)[S], const double (&su0)[M], const double (&sg)[M],
+                                           const double k0, double& E0, double (&Eij)[S * (S - 1) / 2 + 1], double (&Oi)[S]) {
+  static_assert(S <= 3, "orbit_gray: one butterfly block");
+  constexpr int NH = 1 << (S - 1), LB = S - 1, BLK = NH;
+  constexpr bool WHT = FULL && S >= 2 && ORBIT_WHT;
+  int sig[S];
+#pragma unroll
+  for (int j = 0; j < S; ++j) sig[j] = j == S - 1 ? 1 : -1;
+  double v[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) v[r] = mg[S - 1] * hcol[S - 1][r];
+#pragma unroll
+  for (int j = 0; j < S - 1; ++j) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) v[r] = fma(-mg[j], hcol[j][r], v[r]);
+  }
+  double cpv[WHT ? BLK : 1], lv[WHT ? BLK : 1];
+  E0 = 0.0;
+#pragma unroll
+  for (int e = 0; e < S * (S - 1) / 2 + 1; ++e) Eij[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < S; ++j) Oi[j] = 0.0;
+#pragma unroll
+  for (int g = 0; g < NH; ++g) {
+    const int jn = g + 1 < NH ? __builtin_ctz(g + 1) : 0;
+    double q = 0.0, l = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+      q = SIGNED ? fma(sg[r] * v[r], v[r], q) : fma(v[r], v[r], q);
+      if (FULL) l = fma(su0[r], v[r], l);
+    }
+    const double cp = q + k0;
+    if constexpr (WHT) {
+      int b = 0;
+#pragma unroll
+      for (int j = 0; j < LB; ++j) b |= (sig[j] > 0 ? 1 : 0) << j;
+      cpv[b] = cp;
+      lv[b] = l;
+      if (g == NH - 1) {
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+#pragma unroll
+          for (int bb = 0; bb < BLK; ++bb) {
+            if (!(bb & (1 << j))) {
+              const double c0v = cpv[bb], c1v = cpv[bb | (1 << j)], l0v = lv[bb], l1v = lv[bb | (1 << j)];
+              cpv[bb] = c0v + c1v; cpv[bb | (1 << j)] = c1v - c0v;
+              lv[bb] = l0v + l1v; lv[bb | (1 << j)] = l1v - l0v;
+            }
+          }
+        }
+        E0 = cpv[0];
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          Oi[i] = i < LB ? lv[1 << i] : lv[0];              // (the last coordinate keeps its + sign)
+#pragma unroll
+          for (int j = i + 1; j < S; ++j) { Eij[e] = j < LB ? cpv[(1 << i) | (1 << j)] : cpv[1 << i]; ++e; }
+        }
+      }
+    } else {
+      E0 += cp;
+      if (FULL) {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          Oi[i] = sig[i] > 0 ? Oi[i] + l : Oi[i] - l;
+#pragma unroll
+          for (int j = i + 1; j < S; ++j) { Eij[e] = sig[i] * sig[j] > 0 ? Eij[e] + cp : Eij[e] - cp; ++e; }
+        }
+      }
+    }
+    if (g + 1 < NH) {
+      sig[jn] = -sig[jn];
+      const double t2 = (sig[jn] > 0 ? 2.0 : -2.0) * mg[jn];
+#pragma unroll
+      for (int r = 0; r < M; ++r) v[r] = fma(t2, hcol[jn][r], v[r]);
+    }
+  }
+}
+
+// weight and magnitudes of one orbit of a support-major lane
+template <int S>
+struct OrbitWm { double w; double mg[S]; };
+template <int S>
+__device__ __forceinline__ void orbit_load_wm(const OrbitDev& ob, const uint32_t boff, OrbitWm<S>& r) {
+  r.w = orbit_ld(ob.w, boff);
+#pragma unroll
+  for (int j = 0; j < S; ++j) r.mg[j] = orbit_ld(ob.mag + (size_t)j * ob.norb_p, boff);
+}
+
+// SUPPORT-MAJOR class (s <= 3; orbits.hpp): a lane walks the G orbits of its support with the support's columns of H in
+// registers, sums their scaled sign-weighted sums in registers and adds the result to the accumulators once -- G times
+// fewer LDS atomics and column reads than one orbit per lane.  The next orbit's weight and magnitudes are requested while
+// the current one is scaled into the sums.  Local tile tl of the class; t0, t1, tfirst wave-uniform.
+template <int M, int S, bool FULL, bool SIGNED>
+__device__ __forceinline__ void orbit_class_grouped(const OrbitDev& ob, const int lc, const int t0, const int t1, const int tfirst,
+                                                    const uint32_t lane8, const double* Hl, double* accl, const double (&su0)[M],
+                                                    const double (&sg)[M], const double k0, double& m0) {
+  static_assert(M * S <= 36, "support-major classes keep the support's columns in registers");
+  constexpr int NV = 2 * S + S * (S - 1) / 2;
+  const int G = ob.cgrp[S];
+  const uint32_t gstride8 = (uint32_t)ob.cstride[S] * 8u;
+  for (int t = t0; t < t1; ++t) {
+    const uint32_t boff0 = ((uint32_t)ob.cbase[S] + (uint32_t)(t - tfirst) * 64u) * 8u + lane8;
+    const uint64_t cpk = orbit_ld(ob.cpk, boff0), rpk = orbit_ld(ob.rpk, boff0);
+    OrbitWm<S> cur;
+    orbit_load_wm<S>(ob, boff0, cur);
+    int c[S];
+    double hcol[S][M];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      c[j] = (int)((cpk >> (8 * j)) & 255u);
+      const double* hp = Hl + c[j] * orbit_hstride(M);
+#pragma unroll
+      for (int r = 0; r < M; ++r) hcol[j][r] = hp[r];
+    }
+    double acc[FULL ? NV : 1];
+#pragma unroll
+    for (int q = 0; q < (FULL ? NV : 1); ++q) acc[q] = 0.0;
+    for (int g = 0; g < G; ++g) {
+      double mg[S];
+#pragma unroll
+      for (int j = 0; j < S; ++j) mg[j] = cur.mg[j];
+      const double w = cur.w;
+      double E0, Eij[S * (S - 1) / 2 + 1], Oi[S];
+      orbit_gray<M, S, FULL, SIGNED>(hcol, mg, su0, sg, k0, E0, Eij, Oi);
+      // the next orbit of the lane (the last one requests itself again: no branch)
+      const uint32_t bn = boff0 + (uint32_t)(g + 1 < G ? g + 1 : g) * gstride8;
+      __builtin_amdgcn_sched_barrier(0);
+      orbit_load_wm<S>(ob, bn, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      const double wp = w + w;
+      m0 = fma(wp, E0, m0);
+      if constexpr (FULL) {
+        const double w4 = wp + wp;
+        int n = 0, e = 0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          const double wm = wp * mg[i];
+          acc[n] = fma(w4 * mg[i], Oi[i], acc[n]); ++n;
+          acc[n] = fma(wm * mg[i], E0, acc[n]); ++n;
+#pragma unroll
+          for (int j = i + 1; j < S; ++j) { acc[n] = fma(wm * mg[j], Eij[e], acc[n]); ++n; ++e; }
+        }
+      }
+    }
+    if constexpr (FULL && S > GVI_EXP_NOATOM) {
+      const int sh = lc + 3;
+      char* const base = (char*)accl;
+      char* const base1 = base + (1u << sh);
+      unsigned A[S], B[S];
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        const unsigned R = ((unsigned)rpk >> (10 * i)) & 1023u;          // (S <= 3: the low word)
+        A[i] = R << sh;
+        B[i] = (unsigned)c[i] << sh;
+      }
+      int n = 0;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        lds_add_f64((double*)(base1 + B[i]), acc[n++]);
+        lds_add_f64((double*)(base + (A[i] + B[i])), acc[n++]);
+#pragma unroll
+        for (int j = i + 1; j < S; ++j) lds_add_f64((double*)(base + (A[i] + B[j])), acc[n++]);
+      }
+    } else if constexpr (FULL) {
+      double tsum = 0.0;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) tsum += acc[q];
+      m0 = fma(1e-300, tsum, m0);
+    }
+  }
+}
+
 // the tiles [t0, t1) of ONE support-size class, software-pipelined: the records of tile t + 1 are requested while tile t
 // still has its accumulator adds to issue, so that their round trip overlaps the adds and the next tile's column reads
+// largest support size stored support-major (host: build_orbits' group_smax must not exceed it)
+#ifndef ORBIT_GROUP_SMAX
+#define ORBIT_GROUP_SMAX 3
+#endif
 #ifndef ORBIT_PIPE_SMAX
 #define ORBIT_PIPE_SMAX 3
 #endif
 // t0, t1 are wave-uniform (SGPRs); lane8 = 8 * lane.  (Requesting the chunk's first tile ahead of orbit_wave's prologue was
 // tried: the record stays live through every class loop -- 14 registers, spills -- for no gain.)
 template <int M, int S, bool FULL, bool SIGNED>
-__device__ __forceinline__ void orbit_class(const OrbitDev& ob, const int lc, const int t0, const int t1, const uint32_t lane8,
+__device__ __forceinline__ void orbit_class(const OrbitDev& ob, const int lc, const int t0, const int t1, const int tfirst, const uint32_t lane8,
                                             const double* Hl, double* accl, const double (&su0)[M], const double (&sg)[M], const double k0,
                                             double& m0) {
   if (t0 >= t1) return;
@@ -477,15 +661,16 @@ __device__ __forceinline__ void orbit_class(const OrbitDev& ob, const int lc, co
   // leaves no 14 registers for the next tile's records
   constexpr bool PIPE = S <= ORBIT_PIPE_SMAX;
   OrbitRec<S> cur;
-  if constexpr (PIPE) orbit_load<S>(ob, (uint32_t)t0 * 512u + lane8, cur);
+  const uint32_t cb8 = ((uint32_t)ob.cbase[S] - (uint32_t)tfirst * 64u) * 8u + lane8;      // entry of (tile t, this lane) = cb8 + 512 t
+  if constexpr (PIPE) orbit_load<S>(ob, cb8 + (uint32_t)t0 * 512u, cur);
   for (int t = t0; t < t1; ++t) {
-    if constexpr (!PIPE) orbit_load<S>(ob, (uint32_t)t * 512u + lane8, cur);
+    if constexpr (!PIPE) orbit_load<S>(ob, cb8 + (uint32_t)t * 512u, cur);
     const int tn = t + 1 < t1 ? t + 1 : t;                      // (the last tile requests itself again: no branch)
     // the next tile's records go straight into cur: by the time pre() runs the walk has consumed the current ones
     auto pre = [&]() {
       if constexpr (PIPE) {
         __builtin_amdgcn_sched_barrier(0);
-        orbit_load<S>(ob, (uint32_t)tn * 512u + lane8, cur);
+        orbit_load<S>(ob, cb8 + (uint32_t)tn * 512u, cur);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -560,7 +745,11 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
 #define ORBIT_RUN_CLASS(S_)                                                                           \
   {                                                                                                   \
     const int e_ = te < ob.cend[S_] ? te : ob.cend[S_];                                                \
-    if (tcur < e_) { orbit_class<M, S_, FULL, SIGNED>(ob, lc, tcur, e_, lane8, Hl, accme, su0, sg, k0, m0); ORBIT_CLASS_STAMP(S_, e_ - tcur); tcur = e_; } \
+    if (tcur < e_) {                                                                                  \
+      if constexpr (S_ <= ORBIT_GROUP_SMAX && M * S_ <= 36) orbit_class_grouped<M, S_, FULL, SIGNED>(ob, lc, tcur, e_, ob.cend[S_ + 1], lane8, Hl, accme, su0, sg, k0, m0); \
+      else orbit_class<M, S_, FULL, SIGNED>(ob, lc, tcur, e_, ob.cend[S_ + 1], lane8, Hl, accme, su0, sg, k0, m0);            \
+      ORBIT_CLASS_STAMP(S_, e_ - tcur); tcur = e_;                                                     \
+    }                                                                                                 \
   }
   if constexpr (SMAX > 4) {
     ORBIT_RUN_CLASS(6)

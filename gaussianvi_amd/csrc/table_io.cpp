@@ -30,8 +30,18 @@ struct EntryHeader { double dim, deg; int32_t rows, cols; };
 bool read_header(File& io, EntryHeader& h) {
   return io.get(h.dim) && io.get(h.deg) && io.get(h.rows) && io.get(h.cols) && h.rows >= 0 && h.cols >= 0;
 }
+// a header whose claimed body cannot lie inside any file this reader accepts (2^40 bytes): refused before the product of
+// two corrupted 31-bit fields overflows (found by the UBSan build, tests/test_sanitizers.py)
+constexpr int64_t kMaxBodyBytes = (int64_t)1 << 40;
+bool body_bytes(const EntryHeader& h, int64_t& bytes) {
+  if ((int64_t)h.rows > kMaxBodyBytes / 8 / ((int64_t)h.cols > 0 ? (int64_t)h.cols : 1)) return false;
+  bytes = (int64_t)h.rows * h.cols * 8;
+  return true;
+}
 bool skip_body(File& io, const EntryHeader& h) {
-  if (fseek(io.f, (long)((int64_t)h.rows * h.cols * 8), SEEK_CUR)) return false;
+  int64_t bytes;
+  if (!body_bytes(h, bytes)) return false;
+  if (fseek(io.f, (long)bytes, SEEK_CUR)) return false;
   int32_t len;
   if (!io.get(len) || len < 0) return false;
   return fseek(io.f, (long)((int64_t)len * 8), SEEK_CUR) == 0;

@@ -38,8 +38,12 @@ static int check(int d, int p) {
   for (int t = 0; t < nt; ++t) {
     const int s = o.tile_s[t];
     if (t > 0 && o.tile_s[t] > o.tile_s[t - 1]) return fail("tile order", d, p);
-    for (int lane = 0; lane < 64; ++lane) {
-      const int64_t q = (int64_t)o.tile_first[t] + lane;
+    if (o.tile_g[t] < 1 || o.tile_g[t] != o.cgrp[s] || o.tile_gstride[t] != o.cstride[s]) return fail("tile group", d, p);
+    for (int lane = 0; lane < 64; ++lane)
+    for (int gi = 0; gi < o.tile_g[t]; ++gi) {
+      const int64_t q = (int64_t)o.tile_first[t] + lane + (int64_t)gi * o.tile_gstride[t];
+      if (gi > 0 && o.w[q] != 0.0 && (o.cpk[q] != o.cpk[q - (int64_t)gi * o.tile_gstride[t]] || o.rpk[q] != o.rpk[q - (int64_t)gi * o.tile_gstride[t]]))
+        return fail("a lane's orbits share one support", d, p);
       if (o.w[q] == 0.0) {                       // padding
         bool zero = true;
         for (int j = 0; j < o.smax; ++j) zero = zero && o.mag[(size_t)j * o.norb_p + q] == 0.0;
@@ -51,6 +55,8 @@ static int check(int d, int p) {
       for (int j = 0; j < s; ++j) {
         c[j] = (int)((o.cpk[q] >> (8 * j)) & 255u);
         if (c[j] >= d || (j > 0 && c[j] <= c[j - 1])) return fail("support", d, p);
+        const int R = (int)((o.rpk[q] >> (j < 3 ? 10 * j : 32 + 10 * (j - 3))) & 1023u);
+        if (R != 1 + d + c[j] * d - c[j] * (c[j] - 1) / 2 - c[j]) return fail("row base", d, p);
         if (!(o.mag[(size_t)j * o.norb_p + q] > 0.0)) return fail("magnitude", d, p);
       }
       for (int j = s; j < o.smax; ++j)
@@ -110,8 +116,9 @@ static int check(int d, int p) {
   double m0 = o.w0 * k0;
   for (int t = 0; t < nt; ++t) {
     const int S = o.tile_s[t];
-    for (int lane = 0; lane < 64; ++lane) {
-      const int64_t q = (int64_t)o.tile_first[t] + lane;
+    for (int lane = 0; lane < 64; ++lane)
+    for (int gi0 = 0; gi0 < o.tile_g[t]; ++gi0) {
+      const int64_t q = (int64_t)o.tile_first[t] + lane + (int64_t)gi0 * o.tile_gstride[t];
       int c[ORBIT_SMAX], sig[ORBIT_SMAX];
       double mg[ORBIT_SMAX];
       for (int j = 0; j < S; ++j) {
