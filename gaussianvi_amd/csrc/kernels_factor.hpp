@@ -385,14 +385,17 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     }
   }
   PREP_STAMP(2);
-  // X = L^-1 by forward substitution: lane c owns column c
-  double xcol[DT];
+  // X = L^-1 by forward substitution: lane c owns column c.  Column-oriented: x_i updates the right-hand sides of every
+  // later row at once, so the dependent chain is d (multiply + one FMA) instead of the d (d - 1) / 2 FMAs of the row-wise
+  // dot products -- the same FMAs in the same order per entry (bit-identical), 66 -> 24 instructions deep at d = 12
+  double xcol[DT], rhs[DT];
+#pragma unroll
+  for (int i = 0; i < d; ++i) rhs[i] = li == i ? 1.0 : 0.0;
 #pragma unroll
   for (int i = 0; i < d; ++i) {
-    double sacc = li == i ? 1.0 : 0.0;
+    xcol[i] = li <= i ? rhs[i] * inv[i] : 0.0;
 #pragma unroll
-    for (int q = 0; q < i; ++q) sacc = fma(-chol_readlane(row[q], i), xcol[q], sacc);
-    xcol[i] = li <= i ? sacc * inv[i] : 0.0;
+    for (int j = i + 1; j < d; ++j) rhs[j] = fma(-chol_readlane(row[i], j), xcol[i], rhs[j]);
   }
   PREP_STAMP(3);
   if (lane < d) {
