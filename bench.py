@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_PEAK = 78.6e12        # FLOP/s, AMD public spec sheet (vector = matrix fp64 on MI355X); not in the guide
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
+KSTATS_FILE = os.path.join("profiles", "r04_kernel_stats.csv")      # rocprofv3 --kernel-trace --stats of this command (c3)
 
 
 def git_blob_sha1(path):
@@ -289,11 +290,28 @@ def main():
         dist.broadcast(uid, 0)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) > 0.5:
-            try:
-                cx.dist_init_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
-            except Exception as e:
+            # ncclCommInitRank is collective: a rank that never returns from it would leave the job to the launcher's
+            # timeout.  Wall-clock guard: the call runs in a worker thread; if it has not returned after
+            # GVI_BENCH_INIT_TIMEOUT_S (default 120 s) the process ends with a non-zero code -- a fresh process is the only
+            # safe retry (never a re-exec, never an in-process retry of a half-initialised communicator).
+            import threading
+            box = {}
+
+            def _init():
+                try:
+                    cx.dist_init_rccl(rank, world, bytes(uid.cpu().numpy().tobytes()))
+                    box["ok"] = True
+                except Exception as e:                          # noqa: BLE001 (reported below)
+                    box["err"] = e
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("GVI_BENCH_INIT_TIMEOUT_S", "120")))
+            if th.is_alive():
+                print(f"[bench rank {rank}] gvi_dist_init_rccl (ncclCommInitRank) has not returned: giving up", file=sys.stderr, flush=True)
+                os._exit(3)
+            if "err" in box:
                 ok.zero_()
-                print(f"[bench rank {rank}] gvi_dist_init_rccl failed: {e}", file=sys.stderr, flush=True)
+                print(f"[bench rank {rank}] gvi_dist_init_rccl failed: {box['err']}", file=sys.stderr, flush=True)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) < 0.5:
             cx.dist_init_callback(rank, world, torch_allgather(local_rank))
@@ -447,6 +465,40 @@ def main():
                         pass
             ctx.profile_enable(0)
 
+    # ---- N > 1: the sharded result against the SAME steps unsharded on rank 0's GPU (the first run over RCCL / xGMI has
+    # to say by itself whether it computed the right thing): every rank repeats a fresh block of steps on the sharded
+    # context, rank 0 also on a one-GPU context of the whole chain; relative gaps of the final cost and mean, expected <= 1e-9
+    def parity_vs_single_gpu(cx_sharded, ch, nsteps, tables=None):
+        cx_sharded.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        rs = [cx_sharded.ngd_step(0.55, 10) for _ in range(nsteps)]
+        mu_s = cx_sharded.ngd_get_state()["mu"].copy()
+        out = None
+        if rank == 0:
+            t_ref = time.perf_counter()
+            ref, ref_ids = api.context_for_chain(ch, device=local_rank, tables=tables)
+            ref.ngd_set_mode(True, args.fuse_trial)
+            ref.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+            rr = [ref.ngd_step(0.55, 10) for _ in range(nsteps)]
+            mu_r = ref.ngd_get_state()["mu"]
+            st_ref = None
+            if not tables:                                   # stage times of the one-GPU iteration (strong_scaling_model)
+                ref.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+                ref.profile_stages(True, read=False)
+                for _ in range(min(16, args.restart_every)):
+                    ref.ngd_step(0.55, 10)
+                st_ref = {k: float(v[0]) for k, v in ref.profile_stages(False).items()}
+            ref.close()
+            out = {"steps": nsteps, "final_cost_sharded": rs[-1]["new_cost"], "final_cost_single_gpu": rr[-1]["new_cost"],
+                   "rel_gap_cost": abs(rs[-1]["new_cost"] - rr[-1]["new_cost"]) / abs(rr[-1]["new_cost"]),
+                   "rel_gap_mu": float(np.abs(mu_s - mu_r).max() / np.abs(mu_r).max()),
+                   "same_accept_decisions": [a["accepted"] for a in rs] == [b["accepted"] for b in rr] and
+                                            [a["ntrials"] for a in rs] == [b["ntrials"] for b in rr],
+                   "single_gpu_stage_us": st_ref, "expected": "<= 1e-9", "reference_s": round(time.perf_counter() - t_ref, 2)}
+        barrier()
+        return out
+
+    parity = parity_vs_single_gpu(ctx, chain, min(12, args.restart_every)) if world > 1 else None
+
     # ---- N > 1: BASELINE configs[4] (4096 factors, d = 24, p = 7; fp64) sharded over the same ranks, two iterations:
     # the workload whose factor pass (0.095 s on one GPU) dwarfs the replicated chain operations, i.e. where sharding has
     # work to split (strong scaling).  GVI_BENCH_C5_CONFIG selects a smaller d = 24 chain for rehearsals.
@@ -456,7 +508,26 @@ def main():
         t_build = time.perf_counter()
         chain5 = synthetic.make_chain(cfg5)
         local5 = shard_chain(chain5, rank, world)
-        ctx5, ids5 = api.context_for_chain(local5, device=local_rank)
+        # the (d, p) table of the prior set is generated ONCE, on rank 0 (70 s at (24,7)), and handed to the other ranks
+        # (broadcast + gvi_factors_add_table) instead of being generated by every rank
+        d5, p5 = int(chain5["specs"][0]["d"]), int(chain5["specs"][0]["p"])
+        N5 = api.spgh_count(d5, p5)
+        if rank == 0:
+            Z5, w5, _ = api.spgh_nodes(d5, p5)
+        else:
+            Z5, w5 = np.empty((N5, d5)), np.empty(N5)
+        t_table = time.perf_counter() - t_build
+        dev = "cpu" if rehearsal else "cuda"
+        for arr in (Z5, w5):
+            flat = arr.reshape(-1)
+            for lo in range(0, flat.size, 1 << 27):          # 1 GiB pieces
+                piece = torch.from_numpy(flat[lo:lo + (1 << 27)]).to(dev)
+                dist.broadcast(piece, 0)
+                if rank != 0:
+                    flat[lo:lo + (1 << 27)] = piece.cpu().numpy()
+                del piece
+        tables5 = {(d5, p5): (Z5, w5)}
+        ctx5, ids5 = api.context_for_chain(local5, device=local_rank, tables=tables5)
         ctx5.ngd_set_mode(True, 2)
         tr5 = init_transport(ctx5)
         ctx5.ngd_init(chain5["mu0"], chain5["D0"], chain5["U0"])
@@ -481,7 +552,9 @@ def main():
         nfac = torch.zeros(world, dtype=torch.float64, device="cuda")
         nfac[rank] = float(ctx5.sets[0][0])
         dist.all_reduce(nfac, op=dist.ReduceOp.SUM)
-        c5_block = {"config": cfg5, "workload": f"T={chain5['T']} n={chain5['n']}: {chain5['T'] - 1} prior factors d={ctx5.sets[0][1]} p={ctx5.sets[0][2]} "
+        parity5 = parity_vs_single_gpu(ctx5, chain5, 2, tables=tables5)
+        c5_block = {"config": cfg5, "parity_vs_single_gpu": parity5, "table_generation_s_rank0": round(t_table, 1),
+                    "table": f"({d5}, {p5}): {N5} points, generated on rank 0 and broadcast", "workload": f"T={chain5['T']} n={chain5['n']}: {chain5['T'] - 1} prior factors d={ctx5.sets[0][1]} p={ctx5.sets[0][2]} "
                                                   f"(N={ctx5.sets[0][3]}) + {chain5['T']} unary d={ctx5.sets[1][1]} factors, fp64, factor list sharded over {world} ranks",
                     "steps": 2, "ms_per_step": 1e3 * float(mx5[0]) / 2, "value": float(st5[1]) / float(mx5[0]), "unit": "psi-evals/s",
                     "accepted_steps": int(sum(r["accepted"] for r in log5)), "final_cost": log5[-1]["new_cost"],
@@ -489,6 +562,32 @@ def main():
                     "setup_s_rank0": round(t_build, 1),
                     "note": "BASELINE configs[4] in fp64 (fp32 refused: DESIGN section 4.4); one-GPU reference: bench.py --config c5"}
         ctx5.close()
+
+    # ---- BASELINE configs[2] as SURVEY 8(d) writes it (`c3lit`: the 1024 LTV priors and two end anchors, no unary set,
+    # cond(V) = 2.3e5): 20 driver-timed steps beside the default chain (which adds a unary factor per state)
+    c3_literal = None
+    if world == 1 and args.config == "c3":
+        lit = synthetic.make_chain("c3lit")
+        cl, _ = api.context_for_chain(lit, device=local_rank)
+        cl.ngd_set_mode(True, args.fuse_trial)
+        cl.ngd_init(lit["mu0"], lit["D0"], lit["U0"])
+        for _ in range(5):
+            cl.ngd_step(0.55, 10)
+        cl.ngd_init(lit["mu0"], lit["D0"], lit["U0"])
+        torch.cuda.synchronize()
+        cl.ngd_counters(reset=True)
+        tl = time.perf_counter()
+        llog = cl.ngd_run(20, 0.55, 10)
+        torch.cuda.synchronize()
+        tl = time.perf_counter() - tl
+        lf, lc = cl.ngd_counters()
+        evl = sum(K * N for (K, d, p, N) in cl.sets)
+        c3_literal = {"config": "c3lit", "steps": len(llog), "ms_per_step": 1e3 * tl / max(1, len(llog)),
+                      "trials_per_step": float(np.mean([r["ntrials"] for r in llog])), "accepted_steps": int(sum(r["accepted"] for r in llog)),
+                      "final_cost": llog[-1]["new_cost"], "psi_evals_per_s": (lf + lc) * evl / tl, "factor_sets": [list(map(int, x)) for x in cl.sets],
+                      "note": "the literal configs[2] chain (no unary factors; ill-conditioned, DESIGN section 6): 20 iterations from the "
+                              "initial state in one gvi_ngd_run call, backtracking included"}
+        cl.close()
 
     if rank == 0:
         Kd, dd_, pd_, Nd = ctx.sets[dom]
@@ -564,6 +663,19 @@ def main():
                                             "instruction, fp64 or integer -- the resource this kernel is bound by)"}
             except Exception:
                 traffic = None
+        # the dominant kernel's duration as rocprofv3 reports it (kernel-trace of this command, committed): the HIP-event
+        # bracket around a launch reads ~9 us more than the kernel runs.  frac is computed on the trace figure when the
+        # committed file is about the kernel that ran; both are in the line.
+        km_events = km
+        trace_src = None
+        kpath = os.path.join(ROOT, KSTATS_FILE)
+        if world == 1 and args.config == "c3" and os.path.exists(kpath):
+            import csv
+            for row in csv.reader(open(kpath)):
+                if row and kernel_name.split("<")[0] in row[0] and "AverageNs" not in row:
+                    km = float(row[3]) * 1e-9
+                    trace_src = f"{KSTATS_FILE} (git blob {git_blob_sha1(kpath)}): AverageNs of {row[1]} launches"
+                    break
         base_metric = "sigma-point psi-evals/sec + NGD iters/sec, 1024-factor d=12 p=5 chain"
         if args.config == "c3":
             metric = base_metric
@@ -580,9 +692,9 @@ def main():
             **({"rehearsal": "all ranks on cuda:0, gloo exchange: not a measurement"} if rehearsal else {}),
             **({"rccl_ranks": rccl_ranks} if rccl_ranks is not None else {}),
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: T={chain['T']} states of size n={chain['n']}; factor sets: {sets_desc}; one step = one "
-                                   f"device-resident NGD iteration (state re-initialised inside the timed region every {args.restart_every} steps)",
+            "config": {"workload": f"{args.config}: T={chain['T']} states, n={chain['n']}; 1 step = 1 device-resident NGD iteration; restart every {args.restart_every}",
                        "name": args.config, "factor_sets": [list(map(int, s)) for s in ctx.sets] if world == 1 else None,
+                       "factor_sets_columns": "[K factors, d, GH degree p, N sigma points]", "factor_set_kinds": sets_desc,
                        "sharding": (f"factors/{world} contiguous; per pass: all-gather of each rank's state records of [g|D|U] "
                                     f"({ctx.dist_info()['records_per_rank']} states per rank, folded in rank order) with the partial cost sum as one "
                                     f"more record (one all-gather per iteration), issued inside the library ({'gloo callback (rehearsal)' if rehearsal else transport})") if sharded else "none",
@@ -603,11 +715,12 @@ def main():
             "trials_per_step": float(np.mean([r["ntrials"] for r in log])),
             "final_cost": log[-1]["new_cost"],
             "reference_pass_order": ab,
+            "c3_literal": c3_literal,
             # event-timed stages of one iteration (gvi_profile_stages, 16 iterations outside the timed region): "chain" = trial
             # factorisation || gradient solve (kernels_chain.hpp, three launches), "factors" = the factor pass, "assemble"
             "iteration_breakdown_us": stages,
             "chain_us": stages["chain"]["mean_us"] if stages else None,
-            "moments_kernel": {"ms": km * 1e3, "psi_evals_per_s": evals_launch / km, "launch": launch_desc},
+            "moments_kernel": {"ms": km_events * 1e3, "psi_evals_per_s": evals_launch / km_events, "launch": launch_desc, "timed_by": "HIP events, this run"},
             # The dominant kernel streams only the quadrature table, which is L2-resident (HBM traffic ~0.5 % of the algorithmic
             # bytes), so the binding roof is the fp64 VALU pipe, not HBM; it issues NO MFMA instruction (fp64 MFMA and fp64 VALU
             # share one pipe on MI355X and deliver the same rate: profiles/r02_fp64_pipes.txt), so the label says what runs.
@@ -615,7 +728,8 @@ def main():
                          "achieved": exec_flop / km / 1e12, "peak": FP64_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": exec_flop / km / FP64_PEAK,
                          "traffic": traffic, "traffic_source": traffic_source, "valu_issue": valu_issue,
-                         "kernel": kernel_name, "kernel_ms": km * 1e3, "evals_per_launch": evals_launch,
+                         "kernel": kernel_name, "kernel_ms": km * 1e3, "kernel_ms_hip_events": km_events * 1e3,
+                         "kernel_ms_source": trace_src or "HIP events around the launch (this run)", "evals_per_launch": evals_launch,
                          "executed_fp64_ops_per_eval": ops_table,
                          "note": executed_note or ("achieved/frac = EXECUTED fp64 VALU instructions of the bracketed launch (every set in it), each "
                                                    "counted as one FMA (2 flop), / HIP-event time / 78.6 TF"
@@ -638,12 +752,17 @@ def main():
             out["transport"] = transport
             out.setdefault("rccl_ranks", None)                # (no RCCL group in a rehearsal)
             out["c5_strong"] = c5_block
-            # Expected ceiling of strong scaling (BASELINE configs[3]) from the one-GPU stage times of round 3
-            # (profiles/r03_*): the factor pass W shards, the chain operations + assemble R are replicated, the exchange X is added.
-            W, R, X = 0.043, 0.062, 0.030                     # ms; round-3 constants (profiles/r03_f_kernel_stats_c3.csv), not measured in this run
+            out["parity_vs_single_gpu"] = parity
+            # Expected ceiling of strong scaling (BASELINE configs[3]): t(N) = W / N + R + X with W = the factor pass (shards),
+            # R = chain operations + assemble (replicated) -- both event-timed in THIS run on rank 0's one-GPU reference context --
+            # and X = what is left of the measured sharded step (exchange, launches around it, the non-pipelined hand-over)
+            st1 = (parity or {}).get("single_gpu_stage_us") or {}
+            W = st1.get("factors", float("nan")) * 1e-3
+            R = (st1.get("chain", float("nan")) + st1.get("assemble", 0.0)) * 1e-3
+            X = out["ms_per_step"] - (W / world + R)
             out["strong_scaling_model"] = {"W_ms_sharded": W, "R_ms_replicated": R, "X_ms_exchange": X,
-                                           "expected_speedup_at_n": (W + R) / (W / world + R + X),
-                                           "constants": "round-3 one-GPU kernel times (profiles/r03_f_kernel_stats_c3.csv: factor pass 43 us; chain passes 18 + 22 + 8 us, stand-alone assemble 7.5 us and the host hand-over of the non-pipelined sharded iteration); not re-measured here",
+                                           "expected_speedup_at_n": (W + R) / (W / world + R + max(X, 0.0)),
+                                           "constants": "W, R: gvi_profile_stages on rank 0's unsharded context in this run; X = ms_per_step - (W / N + R)",
                                            "note": "t(N) = W / N + R + X; the ceiling as N grows is (W + R) / (R + X)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chain, args.cpu_seconds, dom if not chain_pattern else 0)

@@ -433,14 +433,19 @@ class Context:
         self._ck(self.lib.gvi_set_option(self.h, name.encode(), int(value)))
 
 
-def context_for_chain(chain, device=0, specs=None):
-    """Context with the chain of gaussianvi_amd.synthetic.make_chain loaded; returns (ctx, set ids)."""
+def context_for_chain(chain, device=0, specs=None, tables=None):
+    """Context with the chain of gaussianvi_amd.synthetic.make_chain loaded; returns (ctx, set ids).
+    tables: {(d, p): (Z, w)} -- the generator's own tables produced elsewhere (e.g. once on rank 0 and broadcast): a set
+    whose key is present takes that table through gvi_factors_add_table with "trust_table_degree" set (same routes as the
+    generated table, nothing is generated here)."""
     ctx = Context(device)
     ctx.chain_set(chain["T"], chain["n"])
     ids = []
+    if tables:
+        ctx.set_option("trust_table_degree", 1)
     for spec in (chain["specs"] if specs is None else specs):
         ids.append(ctx.factors_add(spec["d"], spec["p"], spec["start"], spec["kind"], spec["params"],
-                                   spec["temperature"]))
+                                   spec["temperature"], table=(tables or {}).get((spec["d"], spec["p"]))))
         if spec["kind"] in (PSI_HINGE_SDF_2D, PSI_HINGE_SDF_2D_BODY):
             ctx.factors_set_sdf2d(ids[-1], spec["sdf_origin"], spec["sdf_cell"], spec["sdf_field"])
         if spec["kind"] in (PSI_HINGE_SDF_3D, PSI_HINGE_SDF_3D_ARM):

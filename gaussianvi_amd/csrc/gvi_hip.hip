@@ -192,6 +192,11 @@ struct gvi_ctx {
   // sum-of-squares sets: per-pass products from the Cholesky factor of the marginal instead of its symmetric square root
   // (same moments -- the quadrature is exact there -- without the Jacobi sweeps); GVI_CHOL_SQRT=0 / option "chol_sqrt"
   bool chol_sqrt = true;
+  // option "trust_table_degree": a table handed to gvi_factors_add_table IS the Smolyak rule of the degree it is added
+  // under (e.g. the generator's own table, produced once and broadcast to the other ranks); it may then take every route
+  // the generated table takes (Cholesky factor for sum-of-squares psi).  Default 0: a caller's table keeps the symmetric
+  // root, as the reference maps the nodes.
+  bool trust_table_degree = false;
   int orbit_min_tiles = 6;            // GVI_ORBIT_MIN_TILES
   bool orbit_stack = true;            // two-set launch: block b takes item b of both sets (GVI_ORBIT_STACK=0: set 1 behind set 0)
   int orbit_copies = 8;               // private LDS copies of the accumulators (1, 2, 4, 8, 16; fewer when LDS is short)
@@ -1173,7 +1178,7 @@ static gvi_status factors_add_impl(gvi_ctx* ctx, int K, int d, int p, const int3
   // quadrature table: shared between sets with the same (d, p)
   if (tabZ) {
     auto t = std::make_shared<Table>();
-    GVICK(upload_table(ctx, *t, d, -1, tabN, tabZ, tabw));
+    GVICK(upload_table(ctx, *t, d, ctx->trust_table_degree ? p : -1, tabN, tabZ, tabw));
     s->table = t;
   }
   for (auto& t : ctx->tables) if (!s->table && t->d == d && t->p == p) s->table = t;
@@ -3199,6 +3204,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "assemble_on_load") ctx->asm_on_load = value != 0;
   else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chain_wave") chain_wave_enabled() = value != 0;
+  else if (n == "trust_table_degree") ctx->trust_table_degree = value != 0;
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") {
     // the threshold compares SQUARED off-diagonal mass with squared diagonal mass: anything looser than 1e-20 (1e-10 relative)

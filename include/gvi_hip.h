@@ -327,6 +327,9 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * setting of the scheduling switches; the switches that select another summation order or another (mathematically
  * equivalent) route agree to rounding: "split_flush" (d = 16 / 20 / 24 kernel; 0 = plain recursive sums), "mirror",
  * "orbit" / "orbit_waves" / "orbit_copies" (sign-orbit kernel, its chunking and its private accumulator copies),
+ * "trust_table_degree" (1: a table passed to gvi_factors_add_table is the Smolyak rule of the degree p it is added under --
+ * e.g. the generator's table, made once and handed to the other ranks -- and takes the routes of the generated table;
+ * default 0: a caller's table keeps the symmetric square root, as the reference maps the nodes),
  * "chol_sqrt" (1: sum-of-squares sets take S = chol(Sigma) instead of the symmetric root -- the quadrature is exact there),
  * "assemble_on_load" (1: on chain-structured graphs the ordered assemble of (g, V) is done by the first pass of the chain
  * operations that consume it instead of a launch of its own; same sums in the same order),
@@ -337,7 +340,7 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * chain_wave (default 1; process-wide, environment GVI_CHAIN_WAVE): chains of T <= 65 states of size n <= 2 run on the
  * lane-per-node kernel (one wave per chain operation) instead of the generic block-cyclic-reduction kernels.
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,
- * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline, chain_wave. */
+ * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline, chain_wave, trust_table_degree. */
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus

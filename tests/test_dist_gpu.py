@@ -185,5 +185,13 @@ def test_bench_two_rank_rehearsal_reproduces_the_single_gpu_cost():
     assert two["strong_scaling_model"]["expected_speedup_at_n"] > 0
     assert two["c5_strong"]["config"] == "c5small" and two["c5_strong"]["accepted_steps"] == two["c5_strong"]["steps"] == 2
     assert two["c5_strong"]["factors_per_rank"] == [16, 16]
+    # the N > 1 line validates itself: the sharded steps against the same steps unsharded on rank 0's GPU, for both workloads,
+    # and the model's W / R come from this run's own stage times
+    for blk in (two["parity_vs_single_gpu"], two["c5_strong"]["parity_vs_single_gpu"]):
+        assert blk["rel_gap_cost"] < 1e-9 and blk["rel_gap_mu"] < 1e-9 and blk["same_accept_decisions"], blk
+    assert two["parity_vs_single_gpu"]["single_gpu_stage_us"]["factors"] > 0
+    assert two["strong_scaling_model"]["W_ms_sharded"] > 0 and two["strong_scaling_model"]["R_ms_replicated"] > 0
+    assert "generated on rank 0 and broadcast" in two["c5_strong"]["table"]
+    assert one["c3_literal"]["steps"] == 20 and one["c3_literal"]["accepted_steps"] >= 1 and len(one["config"]["workload"]) < 120
     assert abs(two["final_cost"] - one["final_cost"]) < 1e-10 * abs(one["final_cost"])
     assert two["accepted_steps"] == one["accepted_steps"] == 12
