@@ -30,6 +30,7 @@ SIGNATURES = {
                         C.c_void_p, C.POINTER(C.c_int)],
     "gvi_factors_add_table": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
                               C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)],
+    "gvi_debug_cost_log": [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)],
     "gvi_factors_set_table": [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p],
     "gvi_factors_set_sdf2d": [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p],
     "gvi_table_file_list": [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

@@ -426,6 +426,17 @@ class Context:
         self._ck(self.lib.gvi_dist_info(self.h, C.byref(r), C.byref(w), C.byref(n)))
         return dict(rank=r.value, world=w.value, records_per_rank=n.value)
 
+    def debug_cost_log(self, entries=0, read=False):
+        """gvi_debug_cost_log: entries > 0 starts the device-side ring of published costs; read=True returns (ring, sequence)."""
+        seq = C.c_double()
+        if read:
+            buf = np.zeros(self._dbg_entries)
+            self._ck(self.lib.gvi_debug_cost_log(self.h, 0, _p(buf), C.byref(seq)))
+            return buf, seq.value
+        self._dbg_entries = entries if entries > 0 else 0
+        self._ck(self.lib.gvi_debug_cost_log(self.h, entries if entries > 0 else -1, None, C.byref(seq)))
+        return seq.value
+
     def set_variant(self, v):
         self._ck(self.lib.gvi_set_variant(self.h, v))
 

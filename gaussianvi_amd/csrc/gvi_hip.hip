@@ -274,6 +274,9 @@ struct gvi_ctx {
   std::vector<hipEvent_t> stage_pool;
   int spin_ms = 2;                    // wall-time bound of the host spin on the publish word (GVI_SPIN_MS)
   double* host_slot_dev = nullptr;
+  bool safe_publish = false;          // option "safe_publish": checked publish + release / acquire arrival counters (device_common.hpp)
+  DevMem dbg_log;                     // gvi_debug_cost_log: ring of the costs the epilogue tails published, indexed by sequence
+  int dbg_mask = 0;
 };
 
 namespace {
@@ -449,6 +452,11 @@ gvi_status upload_table(gvi_ctx* c, Table& t, int d, int p, int64_t N, const dou
     }
   }
   return GVI_OK;
+}
+
+// device address of the current publish slot (four doubles per ring entry); bit 0 tags the checked form (publish_to_host)
+double* pub_slot(const gvi_ctx* c) {
+  return (double*)((unsigned long long)(c->host_slot_dev + 4 * c->pub_ring) | (c->safe_publish ? 1ull : 0ull));
 }
 
 FactorSet* get_set(gvi_ctx* c, int id) {
@@ -1040,11 +1048,12 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_WARM_START")) c->warm_start = atoi(w) != 0;
   if (const char* w = getenv("GVI_FUSE_TRIAL")) c->fuse_trial = std::min(2, std::max(0, atoi(w)));
   if (const char* w = getenv("GVI_SPIN_MS")) c->spin_ms = std::max(0, atoi(w));
+  if (const char* w = getenv("GVI_SAFE_PUBLISH")) c->safe_publish = atoi(w) != 0;
   if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
-      hipHostMalloc((void**)&c->host_slot, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostMalloc((void**)&c->host_slot, 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
       hipHostGetDevicePointer((void**)&c->host_slot_dev, c->host_slot, 0) != hipSuccess)
     return fail(nullptr, GVI_ERR_HIP, "event / host-mapped slot allocation failed");
-  for (int q = 0; q < 8; ++q) c->host_slot[q] = 0.0;
+  for (int q = 0; q < 16; ++q) c->host_slot[q] = 0.0;
   *out = c.release();
   return GVI_OK;
 }
@@ -1062,6 +1071,10 @@ gvi_status gvi_ctx_destroy(gvi_ctx* ctx) {
   if (ctx->ev_grad) (void)hipEventDestroy(ctx->ev_grad);
   for (auto& e : ctx->ev_solve) if (e) (void)hipEventDestroy(e);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  if (ctx->dbg_mask) {                                          // the device-wide log pointer must not outlive its buffer
+    double* lg = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(gvi_dbg_log), &lg, sizeof(double*));
+  }
   if (ctx->host_slot) (void)hipHostFree(ctx->host_slot);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1742,6 +1755,7 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1
   tail.on = 0; tail.acc = nullptr; tail.half_logdet = nullptr; tail.host_out = nullptr; tail.seq = 0.0; tail.counter = nullptr;
   tail.pred = ctx->cur_pred; tail.pred_val = ctx->cur_pred_val;
   tail.accept = nullptr; tail.cost_dev = nullptr; tail.slot_cur = tail.slot_trial = 0; tail.c0_use_imm = 1; tail.c0_imm = 0.0;
+  tail.safe = ctx->safe_publish ? 1 : 0;
   if (publish_slot >= 0) {
     const size_t need = (size_t)128 * (2 + (size_t)L.koff[L.nsets] / EPI_GROUP);
     if (ctx->epi_counter.bytes < need) {
@@ -1751,7 +1765,7 @@ static gvi_status ngd_epilogue_all(gvi_ctx* ctx, int full, int publish_slot = -1
     }
     ctx->seq += 1.0;
     tail.on = 1; tail.acc = ctx->ngd.exch1.d(); tail.half_logdet = ctx->ngd.hld[publish_slot].d();
-    tail.host_out = ctx->host_slot_dev + 2 * ctx->pub_ring; tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
+    tail.host_out = pub_slot(ctx); tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
     if (ctx->pipe_tail) {
       tail.accept = ctx->pipe_dev.d() + ctx->pub_ring; tail.cost_dev = ctx->pipe_dev.d() + 2;   // accept word of THIS ring slot
       tail.slot_cur = 1 - publish_slot; tail.slot_trial = publish_slot;
@@ -1826,7 +1840,7 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
     HIPCK(ctx, hipMemsetAsync(g.exch1.p, 0, 8, ctx->stream));
     if (publish) {
       ctx->seq += 1.0;
-      hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), ctx->host_slot_dev + 2 * ctx->pub_ring, ctx->seq);
+      hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(), pub_slot(ctx), ctx->seq);
       HIPCK(ctx, hipGetLastError());
     }
     return GVI_OK;
@@ -1843,7 +1857,7 @@ static gvi_status ngd_cost_local(gvi_ctx* ctx, int i, bool publish = false) {
   for (auto& s : ctx->sets) nfac = std::max<int64_t>(nfac, s->K);
   const unsigned nblk = (unsigned)std::min<int64_t>(32, std::max<int64_t>(1, (nfac + 255) / 256));
   hipLaunchKernelGGL(cost_tail_kernel, dim3(nblk), dim3(256), 0, ctx->stream, make_epi_list(ctx, 0, nullptr), g.exch1.d(),
-                     g.hld[i].d(), publish ? ctx->host_slot_dev + 2 * ctx->pub_ring : nullptr, ctx->seq, (unsigned*)ctx->tail_counter.p);
+                     g.hld[i].d(), publish ? pub_slot(ctx) : nullptr, ctx->seq, (unsigned*)ctx->tail_counter.p);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -1852,7 +1866,7 @@ static gvi_status ngd_cost_publish(gvi_ctx* ctx, int i) {
   NgdState& g = ctx->ngd;
   ctx->seq += 1.0;
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, ctx->stream, g.exch1.d(), g.hld[i].d(),
-                     ctx->host_slot_dev + 2 * ctx->pub_ring, ctx->seq);
+                     pub_slot(ctx), ctx->seq);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -1877,9 +1891,21 @@ static gvi_status ngd_cost_wait(gvi_ctx* ctx, int i, double* out, double seq_exp
   // {value, sequence} is ONE 16-byte device store (publish_to_host) and is read here with ONE 16-byte load (movdqa: a single
   // access on every AVX-capable x86), so value and sequence always belong to the same publish -- no "new sequence, old value"
   // window between two 8-byte loads
-  const double* slot = ctx->host_slot + 2 * rg;
+  const double* slot = ctx->host_slot + 4 * rg;
   typedef double v2d __attribute__((vector_size(16), aligned(16)));
+  const bool safe = ctx->safe_publish;
   auto poll = [&](double* val) {
+    if (safe) {
+      // checked form [sequence | value | value | sequence]: taken only when both sequence words and both copies agree
+      const volatile double* vs = slot;
+      const double s0 = vs[0];
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      const double v1 = vs[1], v2 = vs[2];
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      const double s3 = vs[3];
+      *val = v1;
+      return s0 == want && s3 == want && std::memcmp(&v1, &v2, 8) == 0;
+    }
     const v2d both = *(const volatile v2d*)(const void*)slot;        // (volatile: re-read at every poll)
     *val = both[0];
     return both[1] == want;
@@ -2004,7 +2030,7 @@ static gvi_status dist_exchange0(gvi_ctx* ctx, int gb, bool with_cost = false, i
   hipLaunchKernelGGL(dist_fold_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ctx->T, ctx->n, d.world, d.maxlen, stride,
                      (const int32_t*)d.ranges.p, d.recv.d(), eg, eD, eU, with_cost ? ctx->ngd.exch1.d() : (double*)nullptr,
                      pub ? (const double*)ctx->ngd.hld[publish_slot].d() : (const double*)nullptr,
-                     pub ? ctx->host_slot_dev + 2 * ctx->pub_ring : (double*)nullptr, ctx->seq);
+                     pub ? pub_slot(ctx) : (double*)nullptr, ctx->seq);
   HIPCK(ctx, hipGetLastError());
   return GVI_OK;
 }
@@ -2248,6 +2274,7 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
   }
   EpiTail& tail = A.tail;
   tail.on = 0; tail.pred = ctx->cur_pred; tail.pred_val = ctx->cur_pred_val; tail.c0_use_imm = 1;
+  tail.safe = ctx->safe_publish ? 1 : 0;
   if (publish_slot >= 0) {
     const size_t need = (size_t)128 * (2 + (size_t)A.koff[A.nsets] / EPI_GROUP);
     if (ctx->epi_counter.bytes < need) {
@@ -2257,7 +2284,7 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
     }
     ctx->seq += 1.0;
     tail.on = 1; tail.acc = g.exch1.d(); tail.half_logdet = g.hld[publish_slot].d();
-    tail.host_out = ctx->host_slot_dev + 2 * ctx->pub_ring; tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
+    tail.host_out = pub_slot(ctx); tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
     if (ctx->pipe_tail) {
       tail.accept = ctx->pipe_dev.d() + ctx->pub_ring; tail.cost_dev = ctx->pipe_dev.d() + 2;
       tail.slot_cur = 1 - publish_slot; tail.slot_trial = publish_slot;
@@ -3205,6 +3232,11 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chain_wave") chain_wave_enabled() = value != 0;
   else if (n == "trust_table_degree") ctx->trust_table_degree = value != 0;
+  else if (n == "safe_publish") {
+    GVICK(sync(ctx));
+    ctx->safe_publish = value != 0;
+    for (int q = 0; q < 16; ++q) ctx->host_slot[q] = 0.0;       // the two forms lay the slot out differently
+  }
   else if (n == "chol_sqrt") { ctx->chol_sqrt = value != 0; for (auto& s : ctx->sets) s->use_chol = ctx->chol_sqrt; }
   else if (n == "jacobi_tol_exp") {
     // the threshold compares SQUARED off-diagonal mass with squared diagonal mass: anything looser than 1e-20 (1e-10 relative)
@@ -3225,6 +3257,30 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   return GVI_OK;
 }
 
+
+gvi_status gvi_debug_cost_log(gvi_ctx* ctx, int entries, double* out, double* seq_now) {
+  if (!ctx) return GVI_ERR_ARG;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  GVICK(sync(ctx));
+  if (entries > 0) {
+    if (entries & (entries - 1)) return fail(ctx, GVI_ERR_ARG, "entries must be a power of two");
+    HIPCK(ctx, ctx->dbg_log.ensure((size_t)entries * 8));
+    HIPCK(ctx, hipMemset(ctx->dbg_log.p, 0, (size_t)entries * 8));
+    ctx->dbg_mask = entries - 1;
+    double* lg = ctx->dbg_log.d();
+    HIPCK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(gvi_dbg_mask), &ctx->dbg_mask, sizeof(int)));
+    HIPCK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(gvi_dbg_log), &lg, sizeof(double*)));
+  } else if (entries == 0 && out) {
+    if (!ctx->dbg_mask) return fail(ctx, GVI_ERR_STATE, "cost log not enabled");
+    HIPCK(ctx, hipMemcpy(out, ctx->dbg_log.p, (size_t)(ctx->dbg_mask + 1) * 8, hipMemcpyDeviceToHost));
+  } else {
+    ctx->dbg_mask = 0;
+    double* lg = nullptr;
+    HIPCK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(gvi_dbg_log), &lg, sizeof(double*)));
+  }
+  if (seq_now) *seq_now = ctx->seq;
+  return GVI_OK;
+}
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
   if (!ctx || variant < 0 || variant > 6 || variant == 3 || variant == 4) return GVI_ERR_ARG;

@@ -2045,6 +2045,10 @@ struct EpiTail {
   int slot_cur, slot_trial;
   int c0_use_imm;
   double c0_imm;
+  // option "safe_publish": the arrival counters carry release / acquire order (agent scope) instead of the fence-free
+  // protocol (write-through store + vmcnt(0) + relaxed counters) -- an L2 write-back per arriving block, the price list of
+  // DESIGN 4.2 -- and the publish takes the checked four-word form (device_common.hpp)
+  int safe;
 };
 
 // The factor costs of every set, as the tail sums them
@@ -2073,11 +2077,15 @@ __device__ __forceinline__ void epi_tail_arrive(const CostList& cl, const EpiTai
     const unsigned in_grp = grp + 1 < ngrp ? (unsigned)EPI_GROUP : nblocks - grp * EPI_GROUP;
     unsigned* gc = tail.counter + 32u * (1u + grp);
     int l = 0;
-    if (__hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1) {
+    const bool lastg = tail.safe ? __hip_atomic_fetch_add(gc, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1
+                                 : __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_grp - 1;
+    if (lastg) {
       __hip_atomic_store(gc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
       // (a single group -- <= EPI_GROUP factors, BASELINE configs[1] -- needs no second level: one atomic round trip less
       // on the chain that ends in the publish)
-      l = ngrp == 1 ? 1 : (__hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1);
+      l = ngrp == 1 ? 1
+                    : (tail.safe ? __hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1
+                                 : __hip_atomic_fetch_add(tail.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1);
     }
     *last = l;
   }

@@ -318,6 +318,11 @@ gvi_status gvi_profile_stages(gvi_ctx* ctx, int on, float* mean_us, int* counts)
 /* Launch geometry of the set's last moments/cost launch: variant (0 closed form, 1 generic, 2 register, 3 split = four waves per factor, d = 16/20/24,
  * 5 register kernel fused with the chain's other set in one launch, 6 sign-orbit kernel), chunks. */
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk);
+/* Stress-test hook of the fence-free hand-over between the epilogue tail and the host (publish_to_host, option
+ * "safe_publish"): entries > 0 (a power of two) starts recording the cost every tail publishes at log[(int)sequence & (entries - 1)]
+ * on the DEVICE; entries == 0 with out != NULL copies that ring after a stream sync; entries < 0 stops recording.  *seq_now =
+ * sequence number of the last publish issued. */
+gvi_status gvi_debug_cost_log(gvi_ctx* ctx, int entries, double* out, double* seq_now);
 /* Kernel variant override for A/B runs: 0 = auto (sum-of-squares sets with m = 6 / 12 on a table that decomposes into sign
  * orbits take the sign-orbit kernel; otherwise 5 / 2 / 1 as instantiated), 1 = generic LDS kernel, 2 = register kernel
  * (psi operands in LDS), 5 = register kernel with psi operands in SGPRs, 6 = sign-orbit kernel where supported.  3 and 4
@@ -330,6 +335,8 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * "trust_table_degree" (1: a table passed to gvi_factors_add_table is the Smolyak rule of the degree p it is added under --
  * e.g. the generator's table, made once and handed to the other ranks -- and takes the routes of the generated table;
  * default 0: a caller's table keeps the symmetric square root, as the reference maps the nodes),
+ * "safe_publish" (1: the trial cost reaches the host in the checked four-word form and the arrival counters of the epilogue
+ * tail carry release / acquire order instead of the fence-free protocol; same numbers, slower: the A/B of DESIGN section 4.2),
  * "chol_sqrt" (1: sum-of-squares sets take S = chol(Sigma) instead of the symmetric root -- the quadrature is exact there),
  * "assemble_on_load" (1: on chain-structured graphs the ordered assemble of (g, V) is done by the first pass of the chain
  * operations that consume it instead of a launch of its own; same sums in the same order),
@@ -340,7 +347,7 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * chain_wave (default 1; process-wide, environment GVI_CHAIN_WAVE): chains of T <= 65 states of size n <= 2 run on the
  * lane-per-node kernel (one wave per chain operation) instead of the generic block-cyclic-reduction kernels.
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,
- * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline, chain_wave, trust_table_degree. */
+ * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline, chain_wave, trust_table_degree, safe_publish. */
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus

@@ -1457,3 +1457,45 @@ def test_c5_full_chain_two_iterations_closed_form_and_chain_round_trip():
     w = _closed_form_worst(spec["Phi"][pick], spec["Qinv"][pick], mk[pick], Sk[pick], Ephi[pick], Vdmu[pick], Vddmu[pick])
     assert max(w.values()) < 2e-7, w
     ctx.close()
+
+
+@pytest.mark.parametrize("safe,iterations", [(0, 20000), (1, 4000)])
+def test_handover_stress_published_costs_equal_the_device_log(safe, iterations):
+    """VERDICT r3 item 7 / ADVICE r2: the trial cost travels from the last block of the epilogue tail to the host through a
+    fence-free hand-over (write-through stores, relaxed agent-scope arrival counters, ONE 16-byte store into host-mapped
+    memory read with one 16-byte load).  Nothing in the HIP memory model promises that; a torn or stale read would silently
+    change an accept decision.  Stress: >= 20 000 PIPELINED iterations of BASELINE configs[1] (gvi_ngd_run blocks, with
+    aggressive step bases so that trials are rejected and iterations backtrack); the tail also leaves every published cost in a
+    device-side ring (gvi_debug_cost_log), read back after a stream sync: every cost the host acted on must be in that ring,
+    bit for bit and in order, and every accept decision must be the comparison of those doubles.  safe = 1: the same under
+    option "safe_publish" (checked four-word publish + release / acquire counters), fewer iterations -- it is the slow form;
+    its time per iteration is printed for DESIGN's A/B."""
+    import time
+    ch = make_chain("c2")
+    ctx, ids = api.context_for_chain(ch)
+    ctx.set_option("safe_publish", safe)
+    entries = 1 << 12
+    done, t_run, checked = 0, 0.0, 0
+    bases = (0.55, 0.55, 0.55, 1.9, 3.5)
+    blk = 0
+    while done < iterations:
+        base = bases[blk % len(bases)]
+        blk += 1
+        ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+        seq0 = ctx.debug_cost_log(entries)                   # (re)start the ring: zeroed, sequence number before the block
+        t0 = time.perf_counter()
+        log = ctx.ngd_run(28, base, 10)
+        t_run += time.perf_counter() - t0
+        ring, seq1 = ctx.debug_cost_log(read=True)
+        assert seq1 - seq0 < entries
+        device = [ring[int(q) & (entries - 1)] for q in range(int(seq0) + 1, int(seq1) + 1)]
+        # the host's costs (one per iteration: the accepted trial's, or the last rejected one's) as a subsequence of the device's
+        it = iter(device)
+        for r in log:
+            assert any(np.float64(r["new_cost"]).tobytes() == np.float64(c).tobytes() for c in it), (safe, base, done, r)
+            assert r["accepted"] == (r["new_cost"] < r["cost_iter"])
+            checked += 1
+        done += len(log)
+    ctx.close()
+    assert checked >= iterations
+    print(f"\nhand-over stress safe_publish={safe}: {done} iterations, {1e3 * t_run / done:.4f} ms per iteration inside gvi_ngd_run")
