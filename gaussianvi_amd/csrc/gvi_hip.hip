@@ -200,8 +200,8 @@ struct gvi_ctx {
   int orbit_min_tiles = 6;            // GVI_ORBIT_MIN_TILES
   bool orbit_stack = true;            // two-set launch: block b takes item b of both sets (GVI_ORBIT_STACK=0: set 1 behind set 0)
   int orbit_copies = 8;               // private LDS copies of the accumulators (1, 2, 4, 8, 16; fewer when LDS is short)
-  int cost_chunk_mult = 8;            // cost pass of the F-factor kernel: chunks per factor relative to the full pass
-  int scost_f = 2;                    // factors per wave of the cost kernel (2 or 4)
+  static constexpr int cost_chunk_mult = 8;   // cost pass of the F-factor kernel: chunks per factor relative to the full pass
+  static constexpr int scost_f = 2;           // factors per wave of the cost kernel (the four-factor form measured no better: removed)
   // run_moments in planning mode: the launch that WOULD be issued is recorded instead (pair fusion of two sets)
   struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; OrbitArgs oa; int smax = 0; bool all_pos = false; };
   Deferred* defer = nullptr;
@@ -602,8 +602,7 @@ bool dispatch_reg(const FactorSet& s, const MomArgs& a, dim3 grid, hipStream_t s
 }
 
 void dispatch_scost(gvi_ctx* c, const FactorSet& s, const MomArgs& a, int nchunk, hipStream_t st) {
-  if (c->scost_f == 4) launch_scost<4>(s, a, nchunk, st);
-  else launch_scost<2>(s, a, nchunk, st);
+  launch_scost<2>(s, a, nchunk, st);
 }
 
 // ---- sign-orbit kernel (kernels_orbit.hpp) ----
@@ -1022,30 +1021,17 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   c->device = device; c->dtype = dtype;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
     return fail(nullptr, GVI_ERR_HIP, "hipStreamCreate failed");
-  if (const char* w = getenv("GVI_TARGET_WAVES")) c->target_waves = std::max(1, atoi(w));
   if (const char* w = getenv("GVI_NO_SCOST")) c->no_scost = atoi(w) != 0;
   if (const char* w = getenv("GVI_ORBIT")) c->orbit = atoi(w) != 0;
   if (const char* w = getenv("GVI_FUSED")) c->fused = atoi(w) != 0;
   if (const char* w = getenv("GVI_ASM_ON_LOAD")) c->asm_on_load = atoi(w) != 0;
   if (const char* w = getenv("GVI_PIPELINE")) c->pipeline = atoi(w) != 0;
   if (const char* w = getenv("GVI_CHAIN_WAVE")) chain_wave_enabled() = atoi(w) != 0;     // (process-wide: A/B leg of kernels_chain_wave.hpp)
-  if (const char* w = getenv("GVI_CHOL_SQRT")) c->chol_sqrt = atoi(w) != 0;
-  if (const char* w = getenv("GVI_JACOBI_TOL_EXP")) c->jacobi_tol = std::pow(10.0, (double)std::min(-20, atoi(w)));
-  if (const char* w = getenv("GVI_ORBIT_WAVES")) c->orbit_waves = std::max(1, atoi(w));
-  if (const char* w = getenv("GVI_ORBIT_MIN_TILES")) c->orbit_min_tiles = std::max(1, atoi(w));
-  if (const char* w = getenv("GVI_ORBIT_STACK")) c->orbit_stack = atoi(w) != 0;
-  if (const char* w = getenv("GVI_ORBIT_COPIES")) c->orbit_copies = std::min(16, std::max(1, atoi(w)));
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
   if (const char* w = getenv("GVI_MIRROR")) c->mirror = atoi(w) != 0;
-  if (const char* w = getenv("GVI_SPLIT_FLUSH")) c->split_flush = std::max(0, atoi(w));
   if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
   if (const char* w = getenv("GVI_NO_FUSE_GATHER")) c->fuse_gather = atoi(w) == 0;
   if (const char* w = getenv("GVI_SIDE_SOLVE")) c->side_solve = atoi(w) != 0;
-  if (const char* w = getenv("GVI_DUAL_CHAIN")) c->dual_chain = atoi(w) != 0;
-  if (const char* w = getenv("GVI_SCOST_F")) c->scost_f = atoi(w) == 4 ? 4 : 2;
-  if (const char* w = getenv("GVI_COST_CHUNK_MULT")) c->cost_chunk_mult = std::max(1, atoi(w));
-  if (const char* w = getenv("GVI_SPECULATE")) c->speculate = atoi(w) != 0;
-  if (const char* w = getenv("GVI_WARM_START")) c->warm_start = atoi(w) != 0;
   if (const char* w = getenv("GVI_FUSE_TRIAL")) c->fuse_trial = std::min(2, std::max(0, atoi(w)));
   if (const char* w = getenv("GVI_SPIN_MS")) c->spin_ms = std::max(0, atoi(w));
   if (const char* w = getenv("GVI_SAFE_PUBLISH")) c->safe_publish = atoi(w) != 0;

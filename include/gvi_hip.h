@@ -328,7 +328,37 @@ gvi_status gvi_debug_cost_log(gvi_ctx* ctx, int entries, double* out, double* se
  * (psi operands in LDS), 5 = register kernel with psi operands in SGPRs, 6 = sign-orbit kernel where supported.  3 and 4
  * (round-1 A/B variants, removed) return GVI_ERR_ARG. */
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
-/* Runtime form of the A/B environment switches read at gvi_ctx_create.  Results are identical in every
+/* ---- A/B switches: the complete list ----
+ * Environment variables are read ONCE, at gvi_ctx_create (GVI_SPGH_EXTENDED at table generation, GVI_RCCL_PATH when
+ * librccl is loaded); everything else is a run-time option of gvi_set_option.  Every switch below is exercised by a test
+ * or by an A/B leg of tools/gpu_legs.sh; results are identical in every setting unless the last column says otherwise.
+ *
+ *   environment          option              default  what                                                   results
+ *   GVI_ORBIT            orbit               1        sign-orbit psi kernel (0: lane-per-point kernels)      agree to 1e-10
+ *   GVI_FUSED            fused               1        one-launch factor pass (0: prep -> psi -> epilogue)    bit-identical
+ *   GVI_ASM_ON_LOAD      assemble_on_load    1        assemble inside the chain's first pass                 bit-identical
+ *   GVI_PIPELINE         pipeline            1        gvi_ngd_run queues iteration i + 1 ahead of cost i     bit-identical
+ *   GVI_CHAIN_WAVE       chain_wave          1        lane-per-node chain kernel for T <= 65, n <= 2         bit-identical
+ *   GVI_FUSE_TRIAL       (gvi_ngd_set_mode)  2        0 reference pass order, 1 fused trial, 2 adaptive      identical iterates
+ *   GVI_SIDE_SOLVE       side_solve          1        gradient solve beside the trial factorisation          bit-identical
+ *   GVI_NO_PAIR          pair_fuse           0 / 1    both chain sets in one psi launch (lane-per-point)     bit-identical
+ *   GVI_NO_FUSE_GATHER   fuse_gather         0 / 1    gather inside the prep launch                          bit-identical
+ *   GVI_NO_SCOST         no_scost            0        cost pass on the full kernel instead of the cost one   bit-identical
+ *   GVI_SREG_PIPE        sreg_pipe           1        hand-pipelined loads of the lane-per-point kernel      bit-identical
+ *   GVI_MIRROR           mirror              1        +- pairing of the lane-per-point kernel                agree to 1e-11
+ *   GVI_SAFE_PUBLISH     safe_publish        0        checked publish + release / acquire arrival counters   bit-identical (slower)
+ *   GVI_SPIN_MS          --                  2        wall-time bound of the host's spin on the publish word --
+ *   GVI_SPGH_EXTENDED    --                  auto     long-double merge of the Smolyak weights (0 / 1 force)  weights
+ *   GVI_RCCL_PATH        --                  --       the only librccl candidate gvi_dist_* tries            --
+ *   --                   chol_sqrt           1        Cholesky factor for sum-of-squares psi                 agree to 1e-10
+ *   --                   trust_table_degree  0        gvi_factors_add_table: the table is the rule of degree p  --
+ *   --                   jacobi_tol_exp      -34      stopping threshold of the symmetric-root solve         rounding
+ *   --                   split_flush, target_waves, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, dual_chain,
+ *                        warm_start: launch geometry / summation order of individual kernels (tests/test_gpu_parity.py A/Bs)
+ * Build-time only: GVI_BUILD_DEFINES=GVI_FUSED_TIMING (phase stamps; GVI_FUSED_DBG=8 prints them), GVI_ORBIT_SPLIT12,
+ * GVI_EXP_* (timing experiments with WRONG results, tools/build_variant.py).
+ *
+ * Runtime form of the A/B environment switches read at gvi_ctx_create.  Results are identical in every
  * setting of the scheduling switches; the switches that select another summation order or another (mathematically
  * equivalent) route agree to rounding: "split_flush" (d = 16 / 20 / 24 kernel; 0 = plain recursive sums), "mirror",
  * "orbit" / "orbit_waves" / "orbit_copies" (sign-orbit kernel, its chunking and its private accumulator copies),
