@@ -25,6 +25,7 @@
 #include "kernels_factor.hpp"
 #include "kernels_orbit.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_orbit_psi.hpp"
 #include "orbits.hpp"
 #include "spgh.hpp"
 
@@ -87,6 +88,8 @@ struct FactorSet {
   bool use_reg = false;
   bool use_split = false;
   bool use_orbit = false;
+  bool use_opsi = false;              // sign-orbit kernel for the non-polynomial psi kinds (kernels_orbit_psi.hpp)
+  int arm_ndof = 0;
   bool fused_pair = false;            // last resident launch went out fused with the other set
   bool closed_form = false;           // NGDFactorizedLinear route (no sigma points)
   bool chain_structured = false;      // start[k] == k (factor k on state k / states k, k + 1): assemble-on-load needs no CSR
@@ -125,7 +128,7 @@ struct FactorSet {
     // to look at the sigma points themselves (force_sym: gvi_expand / gvi_moments_from_psi) or runs the JKO map
     f.chol = (use_chol && !force_sym && (kind == KIND_QUAD_PRIOR || kind == KIND_FIXED_PRIOR) && table->p >= 3 &&
               (d == 2 || d == 4 || d == 6 || d == 8 || d == 12)) ? 1 : 0;
-    f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz; f.arm = arm.p ? arm.d() : nullptr;
+    f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_inv_cell = 1.0 / sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz; f.arm = arm.p ? arm.d() : nullptr;
     return f;
   }
 };
@@ -191,6 +194,7 @@ struct gvi_ctx {
   double jacobi_tol = 1e-34;
   // sum-of-squares sets: per-pass products from the Cholesky factor of the marginal instead of its symmetric square root
   // (same moments -- the quadrature is exact there -- without the Jacobi sweeps); GVI_CHOL_SQRT=0 / option "chol_sqrt"
+  bool prefer_opsi = false;           // gvi_set_variant(7)
   bool chol_sqrt = true;
   // option "trust_table_degree": a table handed to gvi_factors_add_table IS the Smolyak rule of the degree it is added
   // under (e.g. the generator's own table, produced once and broadcast to the other ranks); it may then take every route
@@ -609,7 +613,7 @@ void dispatch_scost(gvi_ctx* c, const FactorSet& s, const MomArgs& a, int nchunk
 bool orbit_supported(const gvi_ctx* c, const FactorSet& s) {
   if (!c->orbit || !(c->variant == 0 || c->variant == 6)) return false;
   if (s.kind != KIND_QUAD_PRIOR && s.kind != KIND_FIXED_PRIOR) return false;
-  if (!(s.m == 2 || s.m == 6 || s.m == 12) || s.d > 32) return false;
+  if (!(s.m == 2 || s.m == 6 || s.m == 12 || (s.m == 14 && s.table->orb.smax <= 4)) || s.d > 32) return false;   // m = 14: the d = 28 priors of the arm graph
   if (s.m == 2 && s.table->orb.smax > 4) return false;          // m = 2 is instantiated for degree <= 5 only
   const OrbitHost& o = s.table->orb;
   return o.ok && o.smax >= 1 && o.smax <= ORBIT_SMAX && !o.tile_s.empty();
@@ -674,6 +678,7 @@ void launch_orbit(const OrbitArgs& a, int m, int smax, bool full, bool all_pos, 
   const dim3 grid((a.K + 3) / 4, a.nchunk);
   const size_t lds = (size_t)4 * orbit_lds_doubles(a.d, m, a.copies) * 8;
   if (m == 2) launch_orbit_t<2, 4, 4>(a, full, all_pos, grid, lds, st);
+  else if (m == 14) launch_orbit_t<14, 4, 2>(a, full, all_pos, grid, lds, st);
   else if (m == 6 && smax <= 4) launch_orbit_t<6, 4, 4>(a, full, all_pos, grid, lds, st);
   else if (m == 6) launch_orbit_t<6, 6, 2>(a, full, all_pos, grid, lds, st);
   else if (smax <= 4) launch_orbit_t<12, 4, 3>(a, full, all_pos, grid, lds, st);
@@ -771,11 +776,61 @@ gvi_status run_prep(gvi_ctx* c, FactorSet& s, const double* mu, const double* Si
   return GVI_OK;
 }
 
+// ---- sign-orbit kernel for the non-polynomial psi kinds (kernels_orbit_psi.hpp) ----
+// Selected by gvi_set_variant(7) only.  Measured (profiles/r04_*): with a non-polynomial psi the evaluations themselves
+// dominate and a lane that walks an orbit evaluates its 2^s points ONE AFTER THE OTHER -- planar hinge factors (d = 4, p = 7):
+// 30.8 us against 19.0 us of the lane-per-point register kernel; the arm graph's 129 factors x 421 points: 120 us slower per
+// pass than the generic kernel, which keeps 54 k points in flight.  It stays as the A/B leg and as the parity cross-check
+// (three independent kernels for these kinds); the arm graph's 0.27 ms launch was its d = 28 PRIOR set on the generic kernel,
+// which now takes the m = 14 instance of the sign-orbit kernel.
+bool orbit_psi_supported(const gvi_ctx* c, const FactorSet& s, bool reg) {
+  if (!c->orbit) return false;
+  (void)reg;
+  if (!(c->variant == 0 && c->prefer_opsi)) return false;
+  if (!(s.kind == KIND_RANGE_1D || s.kind == KIND_HINGE_SDF_2D || s.kind == KIND_HINGE_SDF_2D_BODY || s.kind == KIND_HINGE_SDF_3D ||
+        s.kind == KIND_HINGE_SDF_3D_ARM)) return false;
+  const OrbitHost& o = s.table->orb;
+  if (!(o.ok && o.smax >= 1 && o.smax <= 4 && !o.tile_s.empty()) || s.d > 32) return false;
+  if (s.kind == KIND_HINGE_SDF_3D_ARM && (s.arm_ndof < 1 || s.arm_ndof > orbit_psi_rows(KIND_HINGE_SDF_3D_ARM))) return false;
+  return orbit_psi_rows(s.kind) <= s.d;
+}
+
+template <int KIND>
+gvi_status launch_orbit_psi_t(gvi_ctx* c, const OrbitPsiArgs& a, bool full, dim3 grid, size_t lds, hipStream_t st) {
+  if (full) {
+    if (lds > 64 * 1024) GVICK(allow_lds(c, (const void*)moments_orbit_psi_kernel<KIND, true>, (int)lds));
+    hipLaunchKernelGGL((moments_orbit_psi_kernel<KIND, true>), grid, dim3(256), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((moments_orbit_psi_kernel<KIND, false>), grid, dim3(256), lds, st, a);
+  }
+  return GVI_OK;
+}
+
+gvi_status launch_orbit_psi(gvi_ctx* c, FactorSet& s, const double* mu, int full, hipStream_t st) {
+  OrbitArgs oa;
+  GVICK(orbit_args(c, s, full, &oa));                       // table pointers, class layout, chunk bounds
+  OrbitPsiArgs a;
+  a.f = s.dev(); a.mu = mu; a.partial = s.partial.d(); a.nchunk = s.nchunk;
+  a.pred = c->cur_pred; a.pred_val = c->cur_pred_val; a.ob = oa.ob;
+  const int NR = orbit_psi_rows(s.kind);
+  a.copies = 1;
+  while (a.copies * 2 <= c->orbit_copies && (size_t)4 * orbit_psi_lds_doubles(s.d, NR, a.copies * 2, true) * 8 <= 64 * 1024) a.copies *= 2;
+  const size_t lds = (size_t)4 * orbit_psi_lds_doubles(s.d, NR, a.copies, full != 0) * 8;
+  const dim3 grid((s.K + 3) / 4, s.nchunk);
+  switch (s.kind) {
+    case KIND_RANGE_1D: return launch_orbit_psi_t<KIND_RANGE_1D>(c, a, full != 0, grid, lds, st);
+    case KIND_HINGE_SDF_2D: return launch_orbit_psi_t<KIND_HINGE_SDF_2D>(c, a, full != 0, grid, lds, st);
+    case KIND_HINGE_SDF_2D_BODY: return launch_orbit_psi_t<KIND_HINGE_SDF_2D_BODY>(c, a, full != 0, grid, lds, st);
+    case KIND_HINGE_SDF_3D: return launch_orbit_psi_t<KIND_HINGE_SDF_3D>(c, a, full != 0, grid, lds, st);
+    default: return launch_orbit_psi_t<KIND_HINGE_SDF_3D_ARM>(c, a, full != 0, grid, lds, st);
+  }
+}
+
 // moments (full=1) or cost (full=0) pass for one set; prep must have run for (mu, Sigma).
 gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double* psi_ext, int full,
                        hipStream_t st = nullptr) {
   if (!st) st = c->stream;
-  if (s.K == 0) { s.nchunk = 1; s.chunk = s.table->Np; s.use_reg = s.use_split = s.use_orbit = false; return GVI_OK; }   // empty shard
+  if (s.K == 0) { s.nchunk = 1; s.chunk = s.table->Np; s.use_reg = s.use_split = s.use_orbit = s.use_opsi = false; return GVI_OK; }   // empty shard
   if (s.kind == KIND_HINGE_SDF_3D_ARM && !psi_ext && !s.arm.p)
     return fail(c, GVI_ERR_STATE, "HINGE_SDF_3D_ARM set without an arm model: call gvi_factors_set_arm");
   if (s.kind >= KIND_HINGE_SDF_2D && !psi_ext && s.sdf_rows == 0)
@@ -785,9 +840,10 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
     return fail(c, GVI_ERR_UNSUPPORTED, "register kernel not instantiated for this (kind, d)");
   const bool closed = s.closed_form && !psi_ext;
   const bool orbit = !closed && !psi_ext && orbit_supported(c, s);
-  const bool split = !closed && !orbit && !reg && !psi_ext && c->variant != 1 && split_supported(s);
+  const bool opsi = !closed && !orbit && !psi_ext && orbit_psi_supported(c, s, reg);
+  const bool split = !closed && !orbit && !opsi && !reg && !psi_ext && c->variant != 1 && split_supported(s);
   if (closed) { reg = false; s.chunk = s.table->Np; s.nchunk = 1; }
-  else if (orbit) {
+  else if (orbit || opsi) {
     reg = false;
     const int64_t tiles = (int64_t)s.table->orb.tile_s.size();
     // chunks: enough waves to fill the chip, but at least orbit_min_tiles tiles per wave -- a wave's prologue (H into LDS,
@@ -815,6 +871,7 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   s.use_reg = reg;
   s.use_split = split;
   s.use_orbit = orbit;
+  s.use_opsi = opsi;
   const size_t need = (size_t)s.K * s.nchunk * npairs(s.d) * 8;
   HIPCK(c, s.partial.ensure(need));
   MomArgs a;
@@ -846,6 +903,8 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
       return GVI_OK;
     }
     launch_orbit(oa, s.m, s.table->orb.smax, full != 0, s.all_pos, st);
+  } else if (opsi) {
+    GVICK(launch_orbit_psi(c, s, mu, full, st));
   } else if (split) {
     const dim3 grid(s.K, s.nchunk);
     const int R = (s.m + 3) / 4;
@@ -1357,6 +1416,7 @@ gvi_status gvi_factors_set_arm(gvi_ctx* ctx, int set_id, int ndof, const double*
     if (frames[q] < 0 || frames[q] >= ndof || (q && frames[q] < frames[q - 1]))
       return fail(ctx, GVI_ERR_ARG, "sphere frames must be non-decreasing and < ndof");
   std::vector<double> pk;
+  s->arm_ndof = ndof;
   pk.push_back(ndof); pk.push_back(nspheres);
   pk.insert(pk.end(), a, a + ndof); pk.insert(pk.end(), alpha, alpha + ndof);
   pk.insert(pk.end(), d, d + ndof); pk.insert(pk.end(), theta_bias, theta_bias + ndof);
@@ -3192,7 +3252,7 @@ gvi_status gvi_profile_stages(gvi_ctx* ctx, int on, float* mean_us, int* counts)
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk) {
   FactorSet* s = get_set(ctx, set_id);
   if (!s) return GVI_ERR_ARG;
-  if (variant) *variant = s->closed_form ? 0 : (s->use_orbit ? 6 : (s->fused_pair ? 5 : (s->use_reg ? 2 : (s->use_split ? 3 : 1))));
+  if (variant) *variant = s->closed_form ? 0 : (s->use_opsi ? 7 : s->use_orbit ? 6 : (s->fused_pair ? 5 : (s->use_reg ? 2 : (s->use_split ? 3 : 1))));
   if (nchunk) *nchunk = s->nchunk;
   if (chunk) *chunk = s->chunk;
   return GVI_OK;
@@ -3269,8 +3329,10 @@ gvi_status gvi_debug_cost_log(gvi_ctx* ctx, int entries, double* out, double* se
 }
 
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 6 || variant == 3 || variant == 4) return GVI_ERR_ARG;
-  ctx->variant = variant;
+  if (!ctx || variant < 0 || variant > 7 || variant == 3 || variant == 4) return GVI_ERR_ARG;
+  // 7 = auto, but the non-polynomial psi kinds take the sign-orbit kernel also where a register kernel exists
+  ctx->prefer_opsi = variant == 7;
+  ctx->variant = variant == 7 ? 0 : variant;
   return GVI_OK;
 }
 

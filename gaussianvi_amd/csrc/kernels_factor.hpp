@@ -77,6 +77,7 @@ struct FactorDev {
   const double* sdf;        // HINGE_SDF_2D: column-major rows x cols signed-distance grid
   int sdf_rows, sdf_cols, sdf_nz;
   double sdf_ox, sdf_oy, sdf_oz, sdf_cell;
+  double sdf_inv_cell;                // 1 / sdf_cell: the look-ups multiply (an fp64 division is ~12 VALU instructions; two per 2-D look-up were 25 of the hinge kernel's 79)
   const double* arm;        // HINGE_SDF_3D_ARM: [ndof, ns, a[ndof], alpha[ndof], d[ndof], bias[ndof], frame[ns], centre[ns][3], radius[ns]]
   double jko_h;             // > 0: the third spectral output is the JKO map 1 / (l/2 + h + sqrt(l (l + 4h))/2) instead of 1/l
   double jtol;              // Jacobi stops when off^2 <= jtol * diag^2 (sums of squares)
@@ -644,7 +645,7 @@ __device__ inline double sdf2d_lookup(const FactorDev& f, double px, double py) 
   const double xmax = f.sdf_ox + (f.sdf_cols - 1.0) * f.sdf_cell, ymax = f.sdf_oy + (f.sdf_rows - 1.0) * f.sdf_cell;
   const double xin = px < f.sdf_ox ? f.sdf_ox : (px > xmax ? xmax : px);
   const double yin = py < f.sdf_oy ? f.sdf_oy : (py > ymax ? ymax : py);
-  const double col = (xin - f.sdf_ox) / f.sdf_cell, row = (yin - f.sdf_oy) / f.sdf_cell;
+  const double col = (xin - f.sdf_ox) * f.sdf_inv_cell, row = (yin - f.sdf_oy) * f.sdf_inv_cell;
   const double lr = floor(row), lc = floor(col), hr = lr + 1.0, hc = lc + 1.0;
   const int lri = (int)lr, lci = (int)lc;
   const int hri = lri + 1 < f.sdf_rows ? lri + 1 : f.sdf_rows - 1;    // weight is 0 there; keeps the read in bounds
@@ -662,7 +663,7 @@ __device__ inline double sdf3d_lookup(const FactorDev& f, double px, double py, 
   const double xin = px < f.sdf_ox ? f.sdf_ox : (px > xmax ? xmax : px);
   const double yin = py < f.sdf_oy ? f.sdf_oy : (py > ymax ? ymax : py);
   const double zin = pz < f.sdf_oz ? f.sdf_oz : (pz > zmax ? zmax : pz);
-  const double col = (xin - f.sdf_ox) / f.sdf_cell, row = (yin - f.sdf_oy) / f.sdf_cell, zz = (zin - f.sdf_oz) / f.sdf_cell;
+  const double col = (xin - f.sdf_ox) * f.sdf_inv_cell, row = (yin - f.sdf_oy) * f.sdf_inv_cell, zz = (zin - f.sdf_oz) * f.sdf_inv_cell;
   const double lr = floor(row), lc = floor(col), lz = floor(zz), hr = lr + 1.0, hc = lc + 1.0, hz = lz + 1.0;
   const int lri = (int)lr, lci = (int)lc, lzi = (int)lz;
   const int hri = lri + 1 < f.sdf_rows ? lri + 1 : f.sdf_rows - 1;

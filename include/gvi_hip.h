@@ -316,7 +316,7 @@ gvi_status gvi_profile_last(gvi_ctx* ctx, int set_id, int what /*0 moments kerne
  * call; the records are then cleared and the mode set to `on`.  A pair costs ~14 us of queue gaps: keep it out of timed runs. */
 gvi_status gvi_profile_stages(gvi_ctx* ctx, int on, float* mean_us, int* counts);
 /* Launch geometry of the set's last moments/cost launch: variant (0 closed form, 1 generic, 2 register, 3 split = four waves per factor, d = 16/20/24,
- * 5 register kernel fused with the chain's other set in one launch, 6 sign-orbit kernel), chunks. */
+ * 5 register kernel fused with the chain's other set in one launch, 6 sign-orbit kernel, 7 sign-orbit kernel for a non-polynomial psi), chunks. */
 gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nchunk, int64_t* chunk);
 /* Stress-test hook of the fence-free hand-over between the epilogue tail and the host (publish_to_host, option
  * "safe_publish"): entries > 0 (a power of two) starts recording the cost every tail publishes at log[(int)sequence & (entries - 1)]
@@ -325,7 +325,9 @@ gvi_status gvi_profile_geometry(gvi_ctx* ctx, int set_id, int* variant, int* nch
 gvi_status gvi_debug_cost_log(gvi_ctx* ctx, int entries, double* out, double* seq_now);
 /* Kernel variant override for A/B runs: 0 = auto (sum-of-squares sets with m = 6 / 12 on a table that decomposes into sign
  * orbits take the sign-orbit kernel; otherwise 5 / 2 / 1 as instantiated), 1 = generic LDS kernel, 2 = register kernel
- * (psi operands in LDS), 5 = register kernel with psi operands in SGPRs, 6 = sign-orbit kernel where supported.  3 and 4
+ * (psi operands in LDS), 5 = register kernel with psi operands in SGPRs, 6 = sign-orbit kernel where supported, 7 = auto, with
+ * the non-polynomial psi kinds (hinge-on-SDF, range) on the sign-orbit kernel also where a register kernel is instantiated
+ * (an A/B leg and parity cross-check: for these kinds the lane-per-point kernels are faster).  3 and 4
  * (round-1 A/B variants, removed) return GVI_ERR_ARG. */
 gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
 /* ---- A/B switches: the complete list ----

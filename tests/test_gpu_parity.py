@@ -162,8 +162,8 @@ def test_moments_range_1d_nonlinear(variant):
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-@pytest.mark.parametrize("d,p", [(2, 4), (4, 4), (6, 3), (8, 3)])
+@pytest.mark.parametrize("variant", [1, 2, 7])
+@pytest.mark.parametrize("d,p", [(2, 4), (4, 4), (6, 3), (8, 3), (4, 7)])
 def test_moments_hinge_sdf2d_vs_oracle(d, p, variant):
     """Hinge-on-signed-distance psi of the planar point robot (helpers/CudaOperation.h:61-103,491-508):
     means inside, on the rim of and far from the obstacles, one of them outside the grid (clamped)."""
@@ -176,11 +176,12 @@ def test_moments_hinge_sdf2d_vs_oracle(d, p, variant):
     with pytest.raises(RuntimeError):
         ctx.moments(sid, np.zeros((K, d)), np.stack([np.eye(d)] * K))        # no grid yet
     ctx.factors_set_sdf2d(sid, origin, cell, field)
-    ctx.set_variant(variant if d <= 6 else 0)              # d = 8 has no register instantiation: generic kernel
+    # d = 8 has no register instantiation: generic kernel; 7 = the sign-orbit kernel for a non-polynomial psi (kernels_orbit_psi.hpp)
+    ctx.set_variant(variant if (d <= 6 or variant != 2) else 0)
     mu, Sigma = syn.random_marginals(rng, K, d, 0.2)
     mu[:, :2] = [(0.0, 1.5), (0.1, 0.2), (-1.0, -1.2), (3.0, 3.0), (6.5, 0.0), (-0.3, 2.9)]
     Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
-    assert ctx.profile_geometry(sid)["variant"] == (variant if d <= 6 else 1)
+    assert ctx.profile_geometry(sid)["variant"] == (variant if (d <= 6 or variant != 2) else 1)
     Z, w = o.nwspgr(d, p)
     r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_hinge_sdf2d(params, origin, cell, field), np.ones(K))
     assert np.abs(r["E_phi"]).max() > 0.05              # Smolyak weights are signed: no positivity on a kinked psi
@@ -267,7 +268,7 @@ def test_mixed_linear_nonlinear_graph_without_quadrature_for_priors():
     ctx.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 7])
 @pytest.mark.parametrize("kind,d,p", [("body", 3, 4), ("body", 6, 3), ("body", 4, 3), ("sdf3d", 3, 4), ("sdf3d", 6, 3), ("sdf3d", 5, 3)])
 def test_moments_hinge_body_and_3d_vs_oracle(kind, d, p, variant):
     """Planar quadrotor body (5 check points, slope 5; helpers/CudaOperation.h:565-606) and the 3-D point robot on a
@@ -294,11 +295,11 @@ def test_moments_hinge_body_and_3d_vs_oracle(kind, d, p, variant):
         psi = o.psi_batch_hinge_sdf3d(params, origin, cell, field)
         poses = [(0.0, 1.3, 0.3), (0.1, 0.2, 0.1), (-0.5, -1.0, 0.2), (3.0, 2.0, 1.5), (5.5, 0.0, -3.0)]
     reg = d in (3, 6)
-    ctx.set_variant(variant if reg else 0)
+    ctx.set_variant(variant if (reg or variant != 2) else 0)     # no register instance at d = 4, 5: auto = the generic kernel
     mu, Sigma = syn.random_marginals(rng, K, d, 0.2)
     mu[:, :3] = poses
     Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
-    assert ctx.profile_geometry(sid)["variant"] == (variant if reg else 1)
+    assert ctx.profile_geometry(sid)["variant"] == (variant if (reg or variant != 2) else 1)
     Z, w = o.nwspgr(d, p)
     r = o.batched_moments(Z, w, mu, Sigma, psi, np.ones(K))
     assert np.abs(r["E_phi"]).max() > 0.05
@@ -327,7 +328,7 @@ def test_obstacle_chains_vs_oracle(name):
     ctx.close()
 
 
-@pytest.mark.parametrize("d,p", [(7, 2), (14, 2)])
+@pytest.mark.parametrize("d,p", [(7, 2), (14, 2), (14, 3)])
 def test_moments_arm_obstacle_vs_oracle(d, p):
     """7-DOF arm (DH forward kinematics, collision spheres on the frames, 3-D trilinear field; the reference's fourth
     obstacle workload, helpers/CudaOperation.h:325-399, 686-771).  The reference builds its DH matrices from
@@ -348,13 +349,21 @@ def test_moments_arm_obstacle_vs_oracle(d, p):
     ctx.factors_set_arm(sid, arm)
     mu, Sigma = syn.random_marginals(rng, K, d, 0.05)
     mu[:, :7] = rng.uniform(-1.2, 1.2, (K, 7))
-    Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
-    assert ctx.profile_geometry(sid)["variant"] == 1
     Z, w = o.nwspgr(d, p)
     r = o.batched_moments(Z, w, mu, Sigma, o.psi_batch_hinge_sdf3d_arm(params, arm, origin, cell, field), np.ones(K))
     assert np.abs(r["E_phi"]).max() > 0.01
-    assert rel(Ephi, r["E_phi"]) < 1e-8 and rel(Vdmu, r["Vdmu"]) < 1e-8 and rel(Vddmu, r["Vddmu"]) < 1e-7
-    assert rel(ctx.costs(sid, mu, Sigma), r["cost"]) < 1e-8
+    # 7: the sign-orbit kernel for a non-polynomial psi (joint angles in registers, kernels_orbit_psi.hpp); auto: the generic
+    # kernel (d = 14 has no register instance) -- both against the oracle and against each other
+    got = {}
+    for variant, expect in ((7, 7), (0, 1)):
+        ctx.set_variant(variant)
+        Ephi, Vdmu, Vddmu = ctx.moments(sid, mu, Sigma)
+        assert ctx.profile_geometry(sid)["variant"] == expect
+        assert rel(Ephi, r["E_phi"]) < 1e-8 and rel(Vdmu, r["Vdmu"]) < 1e-8 and rel(Vddmu, r["Vddmu"]) < 1e-7
+        assert rel(ctx.costs(sid, mu, Sigma), r["cost"]) < 1e-8
+        got[variant] = (Ephi, Vdmu, Vddmu)
+    for x, y in zip(got[7], got[0]):
+        assert rel(x, y) < 1e-10
     ctx.close()
 
 
