@@ -207,7 +207,9 @@ struct gvi_ctx {
   static constexpr int cost_chunk_mult = 8;   // cost pass of the F-factor kernel: chunks per factor relative to the full pass
   static constexpr int scost_f = 2;           // factors per wave of the cost kernel (the four-factor form measured no better: removed)
   // run_moments in planning mode: the launch that WOULD be issued is recorded instead (pair fusion of two sets)
-  struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; OrbitArgs oa; int smax = 0; bool all_pos = false; };
+  // capture_any: kind 3 = "a lane-per-point launch of this set would go out with these arguments and this grid" (whichever
+  // register kernel): the three-set launch of the planning graph (moments_planar3_kernel)
+  struct Deferred { int kind = -1; MomArgs a; dim3 grid; int d = 0, m = 0; OrbitArgs oa; int smax = 0; bool all_pos = false; bool capture_any = false; };
   Deferred* defer = nullptr;
   int update_rule = 0;                // 0 natural gradient (NGD-GH), 1 proximal / JKO (ProxGVI-GH)
   bool pair_fuse = true;              // GVI_NO_PAIR=1: one launch per set
@@ -917,6 +919,10 @@ gvi_status run_moments(gvi_ctx* c, FactorSet& s, const double* mu, const double*
   } else if (reg) {
     dim3 grid((s.K + 3) / 4, s.nchunk);
     bool done = false;
+    if (c->defer && c->defer->capture_any) {
+      c->defer->kind = 3; c->defer->a = a; c->defer->grid = grid; c->defer->d = s.d; c->defer->m = s.m;
+      return GVI_OK;
+    }
     // auto: psi operands from SGPRs where instantiated (fastest for both passes); otherwise the operand-
     // resident kernel for the cost pass and the LDS-operand kernel for the full pass
     if ((c->variant == 5 || c->variant == 0) && !full && scost_supported(s) && !c->no_scost) {
@@ -2234,6 +2240,49 @@ static gvi_status ngd_moments_launch(gvi_ctx* ctx, int slot, int full) {
       if (d0.kind < 0 && d1.kind < 0) { s0.fused_pair = s1.fused_pair = false; return GVI_OK; }   // both already launched
       if (d0.kind >= 0 && d1.kind < 0) { s0.fused_pair = false; return run_moments(ctx, s0, s0.mu_k[slot].d(), nullptr, full); }
       if (d1.kind >= 0 && d0.kind < 0) { s1.fused_pair = false; return run_moments(ctx, s1, s1.mu_k[slot].d(), nullptr, full); }
+    }
+  }
+  // the planning graph: d = 8 priors + d = 4 hinge-on-SDF obstacle factors + d = 4 anchors, all three on lane-per-point
+  // register kernels -> ONE launch (moments_planar3_kernel); any other shape: one launch per set
+  if (ctx->pair_fuse && ctx->sets.size() == 3 && !ctx->profile_all && ctx->variant == 0 && !ctx->prefer_opsi) {
+    FactorSet& s0 = *ctx->sets[0];
+    FactorSet& s1 = *ctx->sets[1];
+    FactorSet& s2 = *ctx->sets[2];
+    const bool shape = s0.kind == KIND_QUAD_PRIOR && s0.d == 8 && s0.m == 4 && s1.kind == KIND_HINGE_SDF_2D && s1.d == 4 &&
+                       s2.kind == KIND_FIXED_PRIOR && s2.d == 4 && !s0.closed_form && !s2.closed_form && s0.K > 0 && s1.K > 0 && s2.K > 0;
+    if (shape) {
+      gvi_ctx::Deferred dq[3];
+      FactorSet* ss[3] = {&s0, &s1, &s2};
+      gvi_status st = GVI_OK;
+      for (int q = 0; q < 3 && st == GVI_OK; ++q) {
+        dq[q].capture_any = true;
+        ctx->defer = &dq[q];
+        st = run_moments(ctx, *ss[q], ss[q]->mu_k[slot].d(), nullptr, full);
+      }
+      ctx->defer = nullptr;
+      GVICK(st);
+      if (dq[0].kind == 3 && dq[1].kind == 3 && dq[2].kind == 3) {
+        const int nb0 = (int)(dq[0].grid.x * dq[0].grid.y), nb1 = (int)(dq[1].grid.x * dq[1].grid.y), nb2 = (int)(dq[2].grid.x * dq[2].grid.y);
+        const bool prof = ctx->profile && full && (ctx->profile_count++ % ctx->profile_every) == 0;
+        if (prof) {                                          // the bracket is booked on the obstacle set (the dominant one)
+          for (int e = 0; e < 2; ++e)
+            if (!s1.ev[0][e]) HIPCK(ctx, hipEventCreate(&s1.ev[0][e]));
+          HIPCK(ctx, hipEventRecord(s1.ev[0][0], ctx->stream));
+        }
+        if (full)
+          hipLaunchKernelGGL((moments_planar3_kernel<true>), dim3(nb0 + nb1 + nb2), dim3(256), 0, ctx->stream, dq[0].a, dq[1].a, dq[2].a,
+                             (int)dq[0].grid.x, nb0, (int)dq[1].grid.x, nb1, (int)dq[2].grid.x, (ctx->sreg_pipe && s0.table->Zq.p) ? 1 : 0);
+        else
+          hipLaunchKernelGGL((moments_planar3_kernel<false>), dim3(nb0 + nb1 + nb2), dim3(256), 0, ctx->stream, dq[0].a, dq[1].a, dq[2].a,
+                             (int)dq[0].grid.x, nb0, (int)dq[1].grid.x, nb1, (int)dq[2].grid.x, 0);
+        HIPCK(ctx, hipGetLastError());
+        if (prof) { HIPCK(ctx, hipEventRecord(s1.ev[0][1], ctx->stream)); s1.ev_set[0] = true; }
+        for (auto* q : ss) q->fused_pair = false;
+        return GVI_OK;
+      }
+      for (int q = 0; q < 3; ++q)                            // some set took another route: whatever was captured goes out on its own
+        if (dq[q].kind >= 0) { ss[q]->fused_pair = false; GVICK(run_moments(ctx, *ss[q], ss[q]->mu_k[slot].d(), nullptr, full)); }
+      return GVI_OK;
     }
   }
   for (auto& s : ctx->sets) { s->fused_pair = false; GVICK(run_moments(ctx, *s, s->mu_k[slot].d(), nullptr, full)); }

@@ -996,15 +996,16 @@ struct PsiHingeSdf {
 };
 template <int D> using PsiHingeSdf2D = PsiHingeSdf<D, KIND_HINGE_SDF_2D>;
 
+// (bx, by): the block's position in the (ceil(K / 4), nchunk) grid of the set -- the launch's own blockIdx, or a virtual one
+// when several sets share a launch (moments_planar3_kernel).  hs_: [4][Psi::LDS], red_: [4][16][65] doubles of LDS.
 template <int D, typename Psi, bool FULL>
-__global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
-  if (pred_skip(a.pred, a.pred_val)) return;
+__device__ __forceinline__ void reg_body(const MomArgs& a, const int bx, const int by, double* hs_, double* red_) {
   constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
   constexpr int NB = (NP + 15) / 16;
-  __shared__ double hs[4][Psi::LDS];
-  __shared__ double red[4][16][65];
+  double (*hs)[Psi::LDS] = (double (*)[Psi::LDS])hs_;
+  double (*red)[16][65] = (double (*)[16][65])red_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + wave;
+  const int k = bx * 4 + wave;
   const bool active = k < a.f.K;
   if (active) Psi::load(a, k, hs[wave], lane);
   __syncthreads();
@@ -1012,7 +1013,7 @@ __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
 #pragma unroll
   for (int j = 0; j < NP; ++j) acc[j] = 0.0;
   const int64_t Np = a.f.Np;
-  const int64_t i0 = (int64_t)blockIdx.y * a.chunk;
+  const int64_t i0 = (int64_t)by * a.chunk;
   const int64_t i1 = (i0 + a.chunk < Np) ? i0 + a.chunk : Np;
   const double* __restrict__ Zt = a.f.Zt;
   const double* __restrict__ w = a.f.w;
@@ -1036,7 +1037,7 @@ __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
       }
     }
   }
-  double* out = a.partial + ((size_t)(active ? k : 0) * a.nchunk + blockIdx.y) * NP;
+  double* out = a.partial + ((size_t)(active ? k : 0) * a.nchunk + by) * NP;
 #pragma unroll
   for (int bb = 0; bb < NB; ++bb) {
 #pragma unroll
@@ -1052,6 +1053,14 @@ __global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
     if (active && lane < 16 && bb * 16 + lane < NP) out[bb * 16 + lane] = s;
     __syncthreads();
   }
+}
+
+template <int D, typename Psi, bool FULL>
+__global__ __launch_bounds__(256) void moments_reg_kernel(MomArgs a) {
+  if (pred_skip(a.pred, a.pred_val)) return;
+  __shared__ double hs[4 * Psi::LDS];
+  __shared__ double red[4 * 16 * 65];
+  reg_body<D, Psi, FULL>(a, (int)blockIdx.x, (int)blockIdx.y, hs, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1676,6 +1685,32 @@ __global__ __launch_bounds__(256, 2) void moments_sreg_pair_kernel(MomArgs a0, M
     if (b < nb0) sreg_body<D0, M0, FULL>(a0, b % nbx0, b / nbx0, us, red);
     else sreg_body<D1, M1, FULL>(a1, (b - nb0) % nbx1, (b - nb0) / nbx1, us, red);
   }
+}
+
+// The planning graph of the reference's own GPU workload (helpers/CudaOperation.cu:74-119: minimum-acceleration priors d = 8,
+// hinge-on-SDF obstacle factors d = 4, two fixed-prior anchors d = 4) as ONE moments launch: the three sets are independent,
+// three launches were three dependent kernel boundaries (5.3 + 18.8 + 4.5 us, profiles/r03_f_kernel_stats_planar1k.csv)
+// around one 18.8 us kernel.  Blocks [0, nb1) = the obstacle set (the heavy one first), [nb1, nb1 + nb0) = the priors, the rest
+// the anchors; every block runs its set's body unchanged (bit-identical to the three launches).
+template <bool FULL>
+__global__ __launch_bounds__(256, 2) void moments_planar3_kernel(MomArgs a0, MomArgs a1, MomArgs a2, int nbx0, int nb0, int nbx1, int nb1, int nbx2,
+                                                                  int pipe) {
+  if (pred_skip(a0.pred, a0.pred_val)) return;
+  using PsiH = PsiHingeSdf<4, KIND_HINGE_SDF_2D>;
+  using PsiA = PsiQuad<4, 4>;
+  constexpr int HS = PsiH::LDS > PsiA::LDS ? (PsiH::LDS > 2 * 4 ? PsiH::LDS : 2 * 4) : (PsiA::LDS > 2 * 4 ? PsiA::LDS : 2 * 4);
+  __shared__ double hs[4 * HS];
+  __shared__ double red[4 * 16 * 65];
+  const int b = (int)blockIdx.x;
+  if (b < nb1) reg_body<4, PsiH, FULL>(a1, b % nbx1, b / nbx1, hs, red);
+  else if (b < nb1 + nb0) {
+    // (the body the set's own launch would run: the hand-pipelined one for the full pass when the tile-major table is there)
+    if constexpr (FULL) {
+      if (pipe) sreg_pipe_dispatch<8, 4>(a0, (b - nb1) % nbx0, (b - nb1) / nbx0, hs, red);
+      else sreg_body<8, 4, true>(a0, (b - nb1) % nbx0, (b - nb1) / nbx0, hs, red);
+    } else sreg_body<8, 4, false>(a0, (b - nb1) % nbx0, (b - nb1) / nbx0, hs, red);
+  }
+  else reg_body<4, PsiA, FULL>(a2, (b - nb1 - nb0) % nbx2, (b - nb1 - nb0) / nbx2, hs, red);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1508,3 +1508,25 @@ def test_handover_stress_published_costs_equal_the_device_log(safe, iterations):
     ctx.close()
     assert checked >= iterations
     print(f"\nhand-over stress safe_publish={safe}: {done} iterations, {1e3 * t_run / done:.4f} ms per iteration inside gvi_ngd_run")
+
+
+def test_planning_graph_three_set_launch_is_bit_identical_to_one_launch_per_set(monkeypatch):
+    """The planning graph (d = 8 priors, d = 4 hinge-on-SDF obstacle factors, two d = 4 anchors: the reference's own GPU
+    workload, helpers/CudaOperation.cu:74-119) issues its three moments launches as ONE (moments_planar3_kernel, every block
+    running its set's body unchanged).  Same costs, same accept decisions, same state, bit for bit, as one launch per set
+    (GVI_NO_PAIR=1) -- full passes and the cost-only passes of backtracking iterations."""
+    ch = make_chain("planar")
+    runs = []
+    for no_pair in ("0", "1"):
+        monkeypatch.setenv("GVI_NO_PAIR", no_pair)
+        ctx, ids = api.context_for_chain(ch)
+        for mode in ((1, 2), (1, 0)):                         # adaptive fused trial, then the reference's pass order (cost passes)
+            ctx.ngd_set_mode(*mode)
+            ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+            log = [ctx.ngd_step(s, 10) for s in (0.55, 0.55, 3.5, 0.55)]
+            runs.append((no_pair, mode, log, ctx.ngd_get_state()))
+        ctx.close()
+    half = len(runs) // 2
+    for (_, mode, log_a, st_a), (_, _, log_b, st_b) in zip(runs[:half], runs[half:]):
+        assert log_a == log_b, mode
+        assert all(np.array_equal(st_a[k], st_b[k]) for k in st_a), mode

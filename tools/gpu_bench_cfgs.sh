@@ -2,7 +2,7 @@
 # bench.py for a list of configs (arguments); JSON lines under gpurun_out/$R
 set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}"
-R="${R:-r03}"
+R="${R:-r04}"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT="gpurun_out/$R"
 mkdir -p "$OUT"

@@ -3,7 +3,7 @@
 # 2-rank rehearsal.  Output under gpurun_out/$R/final (R defaults to r03).
 set -o pipefail
 ROOT="${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT not set}"
-R="${R:-r03}"
+R="${R:-r04}"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 O="gpurun_out/$R/final"
 mkdir -p "$O"
