@@ -372,10 +372,6 @@ def main():
             blk = ctx.ngd_run(min(args.steps - done, args.restart_every - pos, 64), 0.55, 10)
             block_ms.append(1e3 * (time.perf_counter() - tb) / max(1, len(blk)))
             log.extend(blk); done += len(blk); pos += len(blk)
-            try:
-                kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch of the block
-            except api.GviError:
-                pass
     else:
         for i in range(args.steps):
             if pos == args.restart_every:
@@ -391,6 +387,18 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
     n_full, n_cost = ctx.ngd_counters()
+    if single and not args.per_step_calls:
+        # event time of the bracketed dominant launch: sampled OUTSIDE the timed region (reading an event pair is a host-side
+        # synchronisation of ~30 us; inside a 20-step region it was 4 % of the line)
+        for _ in range(1 if big else 8):
+            if pos == args.restart_every:
+                restart(); pos = 0
+            blk = ctx.ngd_run(min(1 if big else 8, args.restart_every - pos), 0.55, 10)
+            pos += len(blk)
+            try:
+                kern_ms.append(ctx.profile_last(ids[0], 0))
+            except api.GviError:
+                pass
 
     # A/B leg (not part of `value`): the reference's pass order -- a cost-only pass per trial and a separate
     # gradient pass per iteration (gvi_ngd_set_mode fuse_trial = 0); same iterates, one more psi pass per iteration

@@ -126,8 +126,7 @@ struct FactorSet {
     // Cholesky factor instead of the symmetric root: sum-of-squares psi on a generated table of degree >= 3 (exact
     // quadrature -- kernels_factor.hpp, prep_chol_body), the instantiated dimensions, and not when the caller is going
     // to look at the sigma points themselves (force_sym: gvi_expand / gvi_moments_from_psi) or runs the JKO map
-    f.chol = (use_chol && !force_sym && (kind == KIND_QUAD_PRIOR || kind == KIND_FIXED_PRIOR) && table->p >= 3 &&
-              (d == 2 || d == 4 || d == 6 || d == 8 || d == 12)) ? 1 : 0;
+    f.chol = (use_chol && !force_sym && (kind == KIND_QUAD_PRIOR || kind == KIND_FIXED_PRIOR) && table->p >= 3 && d <= 32) ? 1 : 0;
     f.sdf = sdf.d(); f.sdf_rows = sdf_rows; f.sdf_cols = sdf_cols; f.sdf_ox = sdf_ox; f.sdf_oy = sdf_oy; f.sdf_cell = sdf_cell; f.sdf_inv_cell = 1.0 / sdf_cell; f.sdf_nz = sdf_nz; f.sdf_oz = sdf_oz; f.arm = arm.p ? arm.d() : nullptr;
     return f;
   }

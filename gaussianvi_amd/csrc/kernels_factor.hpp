@@ -477,6 +477,80 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
   PREP_STAMP(5);
 }
 
+// The Cholesky route for every other dimension (d <= 32): L, X = L^-1 in LDS, any d at run time.  The register form above
+// exists for the chain shapes; a d = 28 prior set (the arm graph, gp/minimum_acc_prior.h with 14-dimensional states) fell to
+// the symmetric-root Jacobi solve -- 0.6 ms per prep launch, 74 % of that graph's iteration.  One wave per factor:
+// right-looking factorisation with the trailing update spread over the lanes (EPLP elements each), forward substitution with
+// lane = column, then the same outputs as prep_chol_body's non-lean form (S = L, S^-T, Sigma^-1 = X^T X, H = A L, u0).
+template <int EPLP>
+__device__ inline void prep_chol_lds_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin, double* Zs) {
+  const int d = f.d, dd = d * d, lane = threadIdx.x & 63;
+  double* Ll = sm;             // [d][d] row-major, zeros above the diagonal
+  double* Xl = Ll + dd;        // [d][d] X = L^-1 (row-major, lower triangular)
+  const double* Sg = Sigma + (size_t)kin * dd;
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    Ll[e] = j <= i ? Sg[i * d + j] : 0.0;        // lower triangle, like SelfAdjointEigenSolver
+    Xl[e] = 0.0;
+  }
+  wave_lds_sync();
+  for (int j = 0; j < d; ++j) {
+    const double pj = Ll[j * d + j];
+    double r = __builtin_amdgcn_rsq(pj);          // NaN for a negative pivot, as the register form
+    r = r * fma(-0.5 * pj * r, r, 1.5);
+    r = r * fma(-0.5 * pj * r, r, 1.5);
+    wave_lds_sync();                              // (every lane has read the pivot before column j is rescaled)
+    if (lane >= j && lane < d) Ll[lane * d + j] = lane == j ? pj * r : Ll[lane * d + j] * r;
+    if (lane == j) Xl[j * d + j] = r;             // 1 / L_jj parked on X's diagonal
+    wave_lds_sync();
+    for (int e = lane; e < dd; e += 64) {         // trailing update of the lower triangle: L_ic -= L_ij L_cj, j < c <= i
+      const int i = e / d, c = e % d;
+      if (c > j && c <= i) Ll[e] = fma(-Ll[i * d + j], Ll[c * d + j], Ll[e]);
+    }
+    wave_lds_sync();
+  }
+  // X = L^-1 by forward substitution, lane c = column c: x_i = (delta_ic - sum_{c <= q < i} L_iq x_q) / L_ii
+  if (lane < d) {
+    const int c = lane;
+    for (int i = c; i < d; ++i) {
+      double acc = i == c ? 1.0 : 0.0;
+      for (int q = c; q < i; ++q) acc = fma(-Ll[i * d + q], Xl[q * d + c], acc);
+      const double inv = i == c ? Xl[c * d + c] : Xl[i * d + i];       // (the diagonal still holds 1 / L_ii until row i is written)
+      Xl[i * d + c] = acc * inv;
+    }
+  }
+  wave_lds_sync();
+  for (int e = lane; e < dd; e += 64) {
+    const int i = e / d, j = e % d;
+    double lam = 0.0;
+    const int lo = i > j ? i : j;
+    for (int c = lo; c < d; ++c) lam = fma(Xl[c * d + i], Xl[c * d + j], lam);      // Sigma^-1 = X^T X (X lower triangular)
+    f.S[(size_t)k * dd + e] = Ll[e];
+    f.Sinv[(size_t)k * dd + e] = Xl[j * d + i];                                      // S^-T = X^T
+    f.Lam[(size_t)k * dd + e] = lam;
+    if (Zs) Zs[e] = Xl[j * d + i];
+  }
+  if (f.m > 0) {
+    const int m = f.m;
+    const double* Ak = f.A + (size_t)k * m * d;
+    for (int e = lane; e < m * d; e += 64) {
+      const int r = e / d, a = e % d;
+      double h = 0.0;
+      for (int c = a; c < d; ++c) h = fma(Ak[r * d + c], Ll[c * d + a], h);           // (L lower triangular: rows c >= a)
+      f.H[(size_t)k * m * d + a * m + r] = h;
+      if (f.Hq) {
+        const int R = (m + 3) / 4;
+        f.Hq[(((size_t)k * 4 + r / R) * d + a) * R + r % R] = h;
+      }
+    }
+    if (lane < m) {
+      double u = f.b[(size_t)k * m + lane];
+      for (int c = 0; c < d; ++c) u = fma(Ak[lane * d + c], mu[(size_t)kin * d + c], u);
+      f.u0[(size_t)k * m + lane] = u;
+    }
+  }
+}
+
 // the chain shapes of BASELINE.json get unrolled instances
 // true when prep_body_d takes the Cholesky route for this set (and can leave [S^-T | Sigma^-1] in LDS)
 __device__ __forceinline__ bool prep_is_chol(const FactorDev& f) {
@@ -492,6 +566,7 @@ __device__ inline void prep_body_d(const FactorDev& f, const double* mu, const d
       case 6: prep_chol_body<6>(f, mu, Sigma, k, sm, kin, Zs); return;
       case 8: prep_chol_body<8>(f, mu, Sigma, k, sm, kin, Zs); return;
       case 12: prep_chol_body<12>(f, mu, Sigma, k, sm, kin, Zs); return;
+      default: prep_chol_lds_body<EPLP>(f, mu, Sigma, k, sm, kin, Zs); return;
     }
   }
   if (EPLP == 1 && f.d == 2) prep_body<EPLP, 2>(f, mu, Sigma, k, sm, kin);
