@@ -66,4 +66,87 @@ __device__ __forceinline__ LazyPred pred_issue(const double* pred, double val) {
 }
 __device__ __forceinline__ bool pred_fail(const LazyPred& p) { return p.has && p.v != p.want; }
 
+// One scalar load from each of the first LINES 64-byte lines of the kernel's argument block, in ONE batch with one wait.
+// A launch's arguments were written by the host a moment ago, so a line's first read on an XCD goes to memory (0.7 us,
+// timing build of factor_fused_kernel; with the arguments in host memory, HIP_FORCE_DEV_KERNARG=0, a C3 iteration of four
+// launches takes 11 us longer), and the compiler fetches a field where it is first needed, behind the branch before it:
+// the prologue of the fused kernel was six such round trips one after the other.  After this pass they hit the scalar cache.
+// (Spelled out as one asm block: left to the compiler the same loads are issued in batches of eight with a wait each, and
+// loads split over several asm blocks would leave registers with a load in flight that the allocator believes to be free.)
+// LINES = ceil(sizeof(arguments) / 64), a specialisation per kernel that uses it.
+template <int LINES> __device__ __forceinline__ void kernarg_warm();
+template <> __device__ __forceinline__ void kernarg_warm<7>() {
+#ifndef GVI_NO_KERNARG_WARM      // (A/B build)
+  unsigned w[7];
+  asm volatile(
+               "s_load_dword %0, %7, 0x0\n"
+               "s_load_dword %1, %7, 0x40\n"
+               "s_load_dword %2, %7, 0x80\n"
+               "s_load_dword %3, %7, 0xc0\n"
+               "s_load_dword %4, %7, 0x100\n"
+               "s_load_dword %5, %7, 0x140\n"
+               "s_load_dword %6, %7, 0x180\n"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(w[0]), "=&s"(w[1]), "=&s"(w[2]), "=&s"(w[3]), "=&s"(w[4]), "=&s"(w[5]), "=&s"(w[6])
+               : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+#endif
+}
+template <> __device__ __forceinline__ void kernarg_warm<13>() {
+#ifndef GVI_NO_KERNARG_WARM      // (A/B build)
+  unsigned w[13];
+  asm volatile(
+               "s_load_dword %0, %13, 0x0\n"
+               "s_load_dword %1, %13, 0x40\n"
+               "s_load_dword %2, %13, 0x80\n"
+               "s_load_dword %3, %13, 0xc0\n"
+               "s_load_dword %4, %13, 0x100\n"
+               "s_load_dword %5, %13, 0x140\n"
+               "s_load_dword %6, %13, 0x180\n"
+               "s_load_dword %7, %13, 0x1c0\n"
+               "s_load_dword %8, %13, 0x200\n"
+               "s_load_dword %9, %13, 0x240\n"
+               "s_load_dword %10, %13, 0x280\n"
+               "s_load_dword %11, %13, 0x2c0\n"
+               "s_load_dword %12, %13, 0x300\n"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(w[0]), "=&s"(w[1]), "=&s"(w[2]), "=&s"(w[3]), "=&s"(w[4]), "=&s"(w[5]), "=&s"(w[6]), "=&s"(w[7]), "=&s"(w[8]), "=&s"(w[9]), "=&s"(w[10]), "=&s"(w[11]), "=&s"(w[12])
+               : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+#endif
+}
+template <> __device__ __forceinline__ void kernarg_warm<26>() {
+#ifndef GVI_NO_KERNARG_WARM      // (A/B build)
+  unsigned w[26];
+  asm volatile(
+               "s_load_dword %0, %26, 0x0\n"
+               "s_load_dword %1, %26, 0x40\n"
+               "s_load_dword %2, %26, 0x80\n"
+               "s_load_dword %3, %26, 0xc0\n"
+               "s_load_dword %4, %26, 0x100\n"
+               "s_load_dword %5, %26, 0x140\n"
+               "s_load_dword %6, %26, 0x180\n"
+               "s_load_dword %7, %26, 0x1c0\n"
+               "s_load_dword %8, %26, 0x200\n"
+               "s_load_dword %9, %26, 0x240\n"
+               "s_load_dword %10, %26, 0x280\n"
+               "s_load_dword %11, %26, 0x2c0\n"
+               "s_load_dword %12, %26, 0x300\n"
+               "s_load_dword %13, %26, 0x340\n"
+               "s_load_dword %14, %26, 0x380\n"
+               "s_load_dword %15, %26, 0x3c0\n"
+               "s_load_dword %16, %26, 0x400\n"
+               "s_load_dword %17, %26, 0x440\n"
+               "s_load_dword %18, %26, 0x480\n"
+               "s_load_dword %19, %26, 0x4c0\n"
+               "s_load_dword %20, %26, 0x500\n"
+               "s_load_dword %21, %26, 0x540\n"
+               "s_load_dword %22, %26, 0x580\n"
+               "s_load_dword %23, %26, 0x5c0\n"
+               "s_load_dword %24, %26, 0x600\n"
+               "s_load_dword %25, %26, 0x640\n"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(w[0]), "=&s"(w[1]), "=&s"(w[2]), "=&s"(w[3]), "=&s"(w[4]), "=&s"(w[5]), "=&s"(w[6]), "=&s"(w[7]), "=&s"(w[8]), "=&s"(w[9]), "=&s"(w[10]), "=&s"(w[11]), "=&s"(w[12]), "=&s"(w[13]), "=&s"(w[14]), "=&s"(w[15]), "=&s"(w[16]), "=&s"(w[17]), "=&s"(w[18]), "=&s"(w[19]), "=&s"(w[20]), "=&s"(w[21]), "=&s"(w[22]), "=&s"(w[23]), "=&s"(w[24]), "=&s"(w[25])
+               : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+#endif
+}
+
 }  // namespace gvi

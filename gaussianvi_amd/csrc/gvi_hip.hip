@@ -742,9 +742,13 @@ gvi_status launch_fused_t(gvi_ctx* c, const FusedArgs& A, unsigned grid, size_t 
           fprintf(stderr, "[walk stamps] block %4d wave %d item %d: shader cycles prologue %llu | s=1 %llu (%llu tiles) | s=2 %llu (%llu) | s=3 %llu (%llu) | s=4 %llu (%llu) | reduction %llu\n",
                   blk * 146, w, it, ws[0], ws[1], ws[7], ws[2], ws[8], ws[3], ws[9], ws[4], ws[10], ws[5]);
         }
-    fprintf(stderr, "[prep stamps] block 0 wave 0, us after the block's start: [Sigma row loaded | Cholesky | L^-1 | LDS + Lam + stores | H, u0]:");
-    for (int i = 0; i < 6; ++i) fprintf(stderr, " %.2f", (double)(long long)(h[256 + i] - h[0]) * 0.01);
-    fprintf(stderr, "\n");
+    for (int w = 0; w < 4; ++w) {
+      fprintf(stderr, "[prep stamps] block 0 wave %d, us after the wave's start: prologue [arguments warm | first scalars | barrier] %.2f %.2f %.2f; gather [entry | loads back | stores issued] %.2f %.2f %.2f; products [Sigma row loaded | Cholesky | L^-1 | LDS | Lam + stores | H, u0]:",
+              w, (double)(long long)(h[256 + 16 * w + 11] - h[8 * w]) * 0.01, (double)(long long)(h[256 + 16 * w + 12] - h[8 * w]) * 0.01,
+              (double)(long long)(h[256 + 16 * w + 13] - h[8 * w]) * 0.01, (double)(long long)(h[256 + 16 * w + 8] - h[8 * w]) * 0.01, (double)(long long)(h[256 + 16 * w + 9] - h[8 * w]) * 0.01, (double)(long long)(h[256 + 16 * w + 10] - h[8 * w]) * 0.01);
+      for (int i = 0; i < 6; ++i) fprintf(stderr, " %.2f", (double)(long long)(h[256 + 16 * w + i] - h[8 * w]) * 0.01);
+      fprintf(stderr, "\n");
+    }
     unsigned long long t0 = ~0ull;
     for (int blk = 0; blk < 8; ++blk) if (h[blk * 32] && h[blk * 32] < t0) t0 = h[blk * 32];
     for (int blk = 0; blk < 8; ++blk)

@@ -965,6 +965,9 @@ __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid,
 template <int N, bool TOP>
 __global__ __launch_bounds__(chain_threads(N)) void chain_forward_kernel(ChainArgs a0, ChainArgs a1, int nb0, AsmList AL) {
   extern __shared__ double sm[];
+  constexpr int KA_LINES = (2 * sizeof(ChainArgs) + 8 + sizeof(AsmList) + 63) / 64;
+  static_assert(KA_LINES == 13, "kernarg_warm: one specialisation per argument block size");
+  kernarg_warm<KA_LINES>();
   if ((int)blockIdx.x < nb0) chain::forward_body<false, true, false, TOP, N>(a0, AL, (int)blockIdx.x, sm);    // (predicate: inside)
   else chain::forward_body<true, false, true, TOP, N>(a1, AL, (int)blockIdx.x - nb0, sm);
 }
@@ -972,6 +975,9 @@ __global__ __launch_bounds__(chain_threads(N)) void chain_forward_kernel(ChainAr
 template <int N>
 __global__ __launch_bounds__(chain_threads(N)) void chain_backward_kernel(ChainArgs a0, ChainArgs a1, int nb0) {
   extern __shared__ double sm[];
+  constexpr int KA_LINES = (2 * sizeof(ChainArgs) + 4 + 63) / 64;
+  static_assert(KA_LINES == 7, "kernarg_warm: one specialisation per argument block size");
+  kernarg_warm<KA_LINES>();
   if ((int)blockIdx.x < nb0) chain::backward_body<true, false, N>(a0, (int)blockIdx.x, sm);      // (predicate: inside)
   else chain::backward_body<false, true, N>(a1, (int)blockIdx.x - nb0, sm);
 }

@@ -328,7 +328,7 @@ __device__ __forceinline__ double chol_readlane(double v, int src) {
 // buffer; the kernel parks the pointer here)
 #ifdef GVI_FUSED_TIMING
 __device__ unsigned long long* gvi_prep_stamps;
-#define PREP_STAMP(i) do { if (gvi_prep_stamps && blockIdx.x == 0 && threadIdx.x == 0) gvi_prep_stamps[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PREP_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && gvi_prep_stamps) gvi_prep_stamps[(i) + 16 * (threadIdx.x >> 6)] = t_; } while (0)
 #else
 #define PREP_STAMP(i) do { } while (0)
 #endif
@@ -337,9 +337,11 @@ __device__ unsigned long long* gvi_prep_stamps;
 // Hs / u0s (LDS, optional; factor_fused_kernel's lean form): the psi operands H (column c at Hs + c hstride) and u0 stay in LDS
 // for the walk of the same launch and NOTHING of the per-pass products goes to memory (no S / S^-T / Sigma^-1 / H / u0
 // stores, Sigma^-1 is not formed: the caller's epilogue re-forms what it needs from Zs)
+// l_ready (LDS, optional; lean form only): ANOTHER wave of the block forms H = A L and u0 = b + A mu for this item
+// (prep_chol_hu0) -- this wave then skips the rows of A altogether and raises *l_ready once L is in its LDS area
 template <int DT>
 __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin, double* Zs = nullptr,
-                                      double* Hs = nullptr, double* u0s = nullptr, const int hstride = 0) {
+                                      double* Hs = nullptr, double* u0s = nullptr, const int hstride = 0, int* l_ready = nullptr) {
   const bool lean = Hs != nullptr;
   constexpr int d = DT, dd = DT * DT;
   const int lane = threadIdx.x & 63;      // one wave per factor (the fused kernel runs several per block)
@@ -352,7 +354,7 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
   // latencies: ~10 us per factor before this, profiles/r03 fused-pass stamps).  Element e = lane (+ 64) of H reads row e / d.
   constexpr int HPL = 2;                                       // H elements per lane: m d <= 128 for the Cholesky shapes (m <= d / 2 ... d)
   const int mm = f.m;
-  const bool pre = mm > 0 && mm * d <= 64 * HPL;
+  const bool pre = mm > 0 && mm * d <= 64 * HPL && !l_ready;
   double arow[HPL][DT], brow = 0.0;
   if (pre) {
     const double* Ak = f.A + (size_t)k * mm * d;
@@ -418,6 +420,7 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     }
   }
   wave_lds_sync();
+  if (l_ready && lane == 0) __hip_atomic_store(l_ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave execute in order: L is there)
   if (lean) {
     for (int e = lane; e < dd; e += 64) Zs[e] = Xl[(e % d) * d + e / d];            // S^-T = X^T
   } else {
@@ -433,7 +436,7 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     }
   }
   PREP_STAMP(4);
-  if (f.m > 0) {
+  if (f.m > 0 && !l_ready) {
     const int m = f.m;
     const double* Ak = f.A + (size_t)k * m * d;
     if (pre) {                                           // operands already in registers (same products, same order)
@@ -477,6 +480,57 @@ __device__ inline void prep_chol_body(const FactorDev& f, const double* mu, cons
     }
   }
   PREP_STAMP(5);
+}
+
+// The psi operands H = A L and u0 = b + A mu of an item whose Cholesky factor ANOTHER wave of the block is forming
+// (factor_fused_kernel: two of a block's four waves are idle in the products phase).  u0 does not depend on the factorisation
+// and is formed at once; the rows of A are requested at once too; H waits for *l_ready (raised by prep_chol_body once L is in
+// that wave's LDS area Ll).  Same products in the same order as prep_chol_body's own H / u0: bit-identical.
+// mul: the item's mean (LDS or global, [d] at index 0); own: this wave's LDS area (>= m d + d doubles); 0 < m d <= 128 (caller).
+template <int DT>
+__device__ inline void prep_chol_hu0(const FactorDev& f, const double* mul, const int k, double* own, const double* Ll, int* l_ready,
+                                     double* Hs, double* u0s, const int hstride) {
+  constexpr int d = DT, HPL = 2;
+  const int lane = threadIdx.x & 63, m = f.m;
+  const double* Ak = f.A + (size_t)k * m * d;
+  double arow[HPL][DT], brow = 0.0;
+#pragma unroll
+  for (int q = 0; q < HPL; ++q) {
+    const int e = lane + 64 * q;
+    const int r = e < m * d ? e / d : 0;
+#pragma unroll
+    for (int c = 0; c < d; ++c) arow[q][c] = Ak[r * d + c];
+  }
+  if (lane < m) brow = f.b[(size_t)k * m + lane];
+  double* Al = own;            // [m][d]
+#pragma unroll
+  for (int q = 0; q < HPL; ++q) {
+    const int e = lane + 64 * q;
+    if (e < m * d && e % d == 0) {
+#pragma unroll
+      for (int c = 0; c < d; ++c) Al[e + c] = arow[q][c];
+    }
+  }
+  wave_lds_sync();
+  if (lane < m) {
+    double u = brow;
+#pragma unroll
+    for (int c = 0; c < d; ++c) u += Al[lane * d + c] * mul[c];
+    u0s[lane] = u;
+  }
+  while (__hip_atomic_load(l_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < HPL; ++q) {
+    const int e = lane + 64 * q;
+    if (e < m * d) {
+      const int r = e / d, a = e % d;
+      double h = 0.0;
+#pragma unroll
+      for (int c = 0; c < d; ++c) h += arow[q][c] * Ll[c * d + a];
+      Hs[a * hstride + r] = h;
+    }
+  }
 }
 
 // The Cholesky route for every other dimension (d <= 32): L, X = L^-1 in LDS, any d at run time.  The register form above

@@ -28,6 +28,9 @@
 namespace gvi {
 
 constexpr int FUSED_MAX_ITEMS = 4;
+#ifndef GVI_FUSED_HELPERS
+#define GVI_FUSED_HELPERS 1     // 0: every item's wave forms its own H and u0 (A/B build)
+#endif
 
 struct FusedSet {
   FactorDev f;
@@ -92,6 +95,7 @@ template <int DT>
 __device__ __forceinline__ bool fused_gather(const FusedArgs& A, const FusedSet& S, const int k, const int lane, double* Sl, double* ml,
                                              const LazyPred& lpred) {
   constexpr int dd = DT * DT, NI = (dd + 63) / 64;
+  PREP_STAMP(8);
   const int n = A.n, nn = n * n;
   const int s = S.start ? S.start[k] : k;
   double v[NI];
@@ -110,6 +114,10 @@ __device__ __forceinline__ bool fused_gather(const FusedArgs& A, const FusedSet&
     const size_t j = (size_t)s * n + lane;
     m = A.gdmu ? A.gmu[j] + A.gstep * A.gdmu[j] : A.gmu[j];
   }
+#ifdef GVI_FUSED_TIMING
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  PREP_STAMP(9);
   if (pred_fail(lpred)) return true;             // the launch's predicate (block-uniform), in front of the first store
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
@@ -117,6 +125,7 @@ __device__ __forceinline__ bool fused_gather(const FusedArgs& A, const FusedSet&
     if (e < dd) { Sl[e] = v[i]; S.Sigma_k[(size_t)k * dd + e] = v[i]; }
   }
   if (lane < DT) { ml[lane] = m; S.mu_k[(size_t)k * DT + lane] = m; }
+  PREP_STAMP(10);
   return false;
 }
 
@@ -128,7 +137,8 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
   extern __shared__ double sm[];
   // -DGVI_FUSED_TIMING + GVI_FUSED_DBG=8: 100 MHz stamps of wave 0 of every 146th block at the phase boundaries
 #ifdef GVI_FUSED_TIMING
-#define FUSED_STAMP(i) do { if (stamps && (threadIdx.x & 63) == 0 && (blockIdx.x % 146) == 0) stamps[(blockIdx.x / 146) * 32 + (threadIdx.x >> 6) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define FUSED_STAMP(i) do { const unsigned long long t_ = (i) == 0 ? t_start : __builtin_amdgcn_s_memrealtime(); if (stamps && (threadIdx.x & 63) == 0 && (blockIdx.x % 146) == 0) stamps[(blockIdx.x / 146) * 32 + (threadIdx.x >> 6) * 8 + (i)] = t_; } while (0)
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();     // (before the first argument is fetched)
 #else
 #define FUSED_STAMP(i) do { } while (0)
 #endif
@@ -141,11 +151,23 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
     stamps[320 + (blockIdx.x / 146) * 4 + (threadIdx.x >> 6)] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
                                                                    ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #endif
+  // The scalars of the prologue, requested in ONE batch: left to the compiler every branch below fetched its own kernel
+  // arguments behind the branch before it -- six dependent round trips of the scalar cache, 1.7 us from the wave's start to
+  // its first load of data (stamps of the timing build)
+  const double* const pred_p = A.tail.pred;
+  const int nblk_ = A.nblk, K0 = A.s[0].f.K, K1_ = A.s[1].f.K, nsets_ = A.nsets;
+  // ... behind one pass over every line of the (1.6 KB) argument block (kernarg_warm)
+  constexpr int KA_LINES = (sizeof(FusedArgs) + 3 * 8 + 63) / 64;
+  static_assert(KA_LINES == 26, "kernarg_warm: one specialisation per argument block size");
+  kernarg_warm<KA_LINES>();
+  PREP_STAMP(11);
+  asm volatile("" :: "s"(pred_p), "s"(nblk_), "s"(K0), "s"(K1_), "s"(nsets_));
+  PREP_STAMP(12);
   // the launch's predicate (pipelined iterations): requested here, waited for in front of the first store to memory
-  const LazyPred lpred = pred_issue(A.tail.pred, A.tail.pred_val);
+  const LazyPred lpred = pred_issue(pred_p, A.tail.pred_val);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = (int)blockIdx.x;
-  if (b >= A.nblk) {                                          // chain-level trial mean (gather mode only)
+  if (b >= nblk_) {                                           // chain-level trial mean (gather mode only)
     const int64_t j = (int64_t)(b - A.nblk) * 256 + threadIdx.x;
     const double v = j < A.nmu ? A.gmu[j] + A.gstep * A.gdmu[j] : 0.0;
     if (pred_fail(lpred)) return;
@@ -153,9 +175,10 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
     return;
   }
   // items of this block: set 0's b, b + nblk, ...; then set 1's
-  const int K0 = A.s[0].f.K, K1 = A.nsets > 1 ? A.s[1].f.K : 0;
-  const int c0 = K0 > b ? (K0 - b + A.nblk - 1) / A.nblk : 0;
-  const int c1 = K1 > b ? (K1 - b + A.nblk - 1) / A.nblk : 0;
+  const int K1 = nsets_ > 1 ? K1_ : 0;
+  int c0 = 0, c1 = 0;                                          // (counted, not divided: at most FUSED_MAX_ITEMS of them)
+#pragma unroll
+  for (int j = 0; j < FUSED_MAX_ITEMS; ++j) { c0 += b + j * nblk_ < K0; c1 += b + j * nblk_ < K1; }
   const int nitems = c0 + c1;                                  // <= FUSED_MAX_ITEMS (host)
   // Which wave takes which item in phases 1 and 3.  Those phases are dependent chains of one wave per item (d = 12: 1500
   // instructions, three times the d = 6 item) and a block has two idle waves in them, so what matters is which SIMD an item's
@@ -166,10 +189,12 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
   // a bijection whenever the block's four waves sit on four SIMDs (checked; else item i stays on wave i), and the results
   // do not depend on it.
   __shared__ int hw_simd[4];
+  __shared__ int l_ready[FUSED_MAX_ITEMS];     // products phase: item i's Cholesky factor is in its wave's LDS area (prep_chol_hu0)
   const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);      // HW_ID.simd_id
   const int slot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.wave_id
-  if ((threadIdx.x & 63) == 0) hw_simd[wave] = simd | (slot << 4);
+  if ((threadIdx.x & 63) == 0) { hw_simd[wave] = simd | (slot << 4); l_ready[wave] = 0; }
   __syncthreads();
+  PREP_STAMP(13);
   const int h0 = hw_simd[0], h1 = hw_simd[1], h2 = hw_simd[2], h3 = hw_simd[3];
   const bool spread = ((1 << (h0 & 3)) | (1 << (h1 & 3)) | (1 << (h2 & 3)) | (1 << (h3 & 3))) == 15;
   const int iw = __builtin_amdgcn_readfirstlane(spread ? (simd - (h0 >> 4)) & 3 : wave);
@@ -178,7 +203,13 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
   const size_t zs = fused_keep_doubles(dmax, M), ps = (size_t)4 * npairs(dmax);
   const size_t oH = (size_t)dmax * dmax, oU = oH + (size_t)dmax * orbit_hstride(M);
   double* Pbase = Zbase + (size_t)maxitems * zs;               // [items][4][npairs(dmax)]
-  // ---- phase 1: wave i forms the products of item i ----
+  // ---- phase 1: wave i forms the products of item i; the block's idle waves (4 - nitems of them) form H and u0 of items
+  // 0 .. 3 - nitems beside it (prep_chol_hu0): the item's own chain is then gather -> Cholesky -> L^-1 ----
+  const int nhelp = GVI_FUSED_HELPERS ? min(4 - nitems, nitems) : 0;      // items [0, nhelp) have a helper: the wave with iw = nitems + item
+  const auto helped = [&](const int it) {                      // (the shapes whose rows of A fit two registers a lane: all the fused route takes)
+    const FactorDev& f = A.s[it < c0 ? 0 : 1].f;
+    return it < nhelp && f.m > 0 && f.m * f.d <= 128;
+  };
   if (iw < nitems) {
     const int si = iw < c0 ? 0 : 1;
     const int k = b + (iw < c0 ? iw : iw - c0) * A.nblk;
@@ -187,17 +218,49 @@ __global__ __launch_bounds__(256, WAVES) void factor_fused_kernel(FusedArgs A, i
     const int d = f.d, dd = d * d, lane = threadIdx.x & 63;
     double* area = sm + (size_t)wave * region;
     double* Zs = Zbase + (size_t)iw * zs;
+    int* flag = helped(iw) ? &l_ready[iw] : nullptr;
     if (!A.gather) {
-      if (si == 0) prep_chol_body<D0>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
-      else prep_chol_body<D1>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
+      if (si == 0) prep_chol_body<D0>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M), flag);
+      else prep_chol_body<D1>(f, S.mu, S.Sigma, k, area, k, Zs, Zs + oH, Zs + oU, orbit_hstride(M), flag);
     } else {
       const int dp = d + (d & 1);
       double* Sl = area + 4 * dd + 2 * dp + 3 * d + (dp + 1) / 2 + 1;   // behind prep_body's own LDS
       double* ml = Sl + dd;
       if (si == 0 ? fused_gather<D0>(A, S, k, lane, Sl, ml, lpred) : fused_gather<D1>(A, S, k, lane, Sl, ml, lpred)) return;
       wave_lds_sync();
-      if (si == 0) prep_chol_body<D0>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
-      else prep_chol_body<D1>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M));
+      if (si == 0) prep_chol_body<D0>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M), flag);
+      else prep_chol_body<D1>(f, ml, Sl, k, area, 0, Zs, Zs + oH, Zs + oU, orbit_hstride(M), flag);
+    }
+  } else if (helped(iw - nitems)) {
+    const int it = iw - nitems;                               // the item this wave helps
+    const int si = it < c0 ? 0 : 1;
+    const int k = b + (it < c0 ? it : it - c0) * A.nblk;
+    const FusedSet& S = A.s[si];
+    const int d = S.f.d, lane = threadIdx.x & 63;
+    // the wave that runs item `it` (the inverse of the SIMD map above), whose LDS area holds L
+    int wi = it;
+    if (spread) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int hw = w == 0 ? h0 : (w == 1 ? h1 : (w == 2 ? h2 : h3));
+        if ((((hw & 3) - (h0 >> 4)) & 3) == it) wi = w;
+      }
+    }
+    double* own = sm + (size_t)wave * region;
+    double* Zs = Zbase + (size_t)it * zs;
+    // the item's mean, as its own wave gathers it (same expression: bit-identical u0)
+    double* mh = own + (size_t)S.f.m * d;
+    if (lane < d) {
+      double mval;
+      if (A.gather) {
+        const size_t j = (size_t)(S.start ? S.start[k] : k) * A.n + lane;
+        mval = A.gdmu ? A.gmu[j] + A.gstep * A.gdmu[j] : A.gmu[j];
+      } else mval = S.mu[(size_t)k * d + lane];
+      mh[lane] = mval;
+    }
+    if (!pred_fail(lpred)) {
+      if (si == 0) prep_chol_hu0<D0>(S.f, mh, k, own, sm + (size_t)wi * region, &l_ready[it], Zs + oH, Zs + oU, orbit_hstride(M));
+      else prep_chol_hu0<D1>(S.f, mh, k, own, sm + (size_t)wi * region, &l_ready[it], Zs + oH, Zs + oU, orbit_hstride(M));
     }
   }
   FUSED_STAMP(1);

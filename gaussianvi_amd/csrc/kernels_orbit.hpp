@@ -771,7 +771,10 @@ __device__ __forceinline__ void orbit_wave(const OrbitArgs& a, const int k, cons
     // below is eight DEPENDENT LDS round trips per entry: 4400 cycles of a wave's 30 000 at (12,5), walk stamps)
     if (C == 8) {
       for (int e = 1 + lane; e < NP; e += 64) {
-        const int rot = (lane >> 2) & 7;
+        int rot = (lane >> 2) & 7;
+        // (opaque: the eight rotated addresses are otherwise hoisted out of the fused pass's item loop and kept -- spilled --
+        // across the whole walk: 32 of its 56 bytes of scratch per lane)
+        asm volatile("" : "+v"(rot));
         double c8[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) c8[q] = accl[e * 8 + ((q + rot) & 7)];
