@@ -61,21 +61,58 @@ inline hipError_t chain_allow_lds() {
   if ((e = hipFuncSetAttribute((const void*)chain_forward_kernel<N, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)chain_forward_kernel<N, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute((const void*)chain_backward_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute((const void*)chain_top_back_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lim)) != hipSuccess) return e;
   if (dev >= 0 && dev < 64) done[dev] = true;
   return hipSuccess;
 }
 
+// The hand-over words of a merged top + backward launch (kernels_chain.hpp::chain_top_back_kernel): two device words (one per
+// operation) and a sequence number the caller advances with every chain_launch.  words == nullptr: separate launches.
+struct ChainSync { unsigned* words = nullptr; unsigned seq = 0; };
+
 // on0: factorisation a0 (log-det; + selected inverse when a0.need_back); on1: pivoted solve a1.  Both: side by side in the
 // same launches.  Returns hipErrorInvalidValue when a pass does not fit LDS.
 template <int N>
-inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st, const AsmList& AL) {
+inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st, const AsmList& AL,
+                                 const ChainSync& sync) {
   hipError_t e = chain_allow_lds<N>();
   if (e != hipSuccess) return e;
   auto set = [](ChainArgs& a, const ChainPass& ps) {
     a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.first = ps.first; a.par = ps.par; a.lp_off = ps.lp_off;
   };
+  a0.sync = a1.sync = nullptr; a0.sync_seq = a1.sync_seq = 0;
+  const bool back0 = on0 && a0.need_back;
+  const int npass = (int)pl.passes.size();
+  // the top pass carries the backward workgroups of the last segmented pass when there is one and its LDS fits
+  bool merged = false;
+  if (sync.words && npass >= 2 && (back0 || on1)) {
+    const ChainPass& pt = pl.passes[npass - 1];
+    const ChainPass& pc = pl.passes[npass - 2];
+    size_t lds = 0;
+    if (on0) lds = std::max(lds, chain::fwd_lds_doubles<true, false, true, N>(pt.S));
+    if (on1) lds = std::max(lds, chain::fwd_lds_doubles<false, true, true, N>(pt.S));
+    if (back0) lds = std::max(lds, chain::bwd_lds_doubles<true, N>(pc.S));
+    if (on1) lds = std::max(lds, chain::bwd_lds_doubles<false, N>(pc.S));
+    merged = lds * 8 <= 160 * 1024;
+  }
   for (const ChainPass& ps : pl.passes) {
     set(a0, ps); set(a1, ps);
+    if (ps.top && merged) {
+      const ChainPass& pc = pl.passes[npass - 2];
+      size_t lds = 0;
+      if (on0) lds = std::max(lds, chain::fwd_lds_doubles<true, false, true, N>(ps.S));
+      if (on1) lds = std::max(lds, chain::fwd_lds_doubles<false, true, true, N>(ps.S));
+      if (back0) lds = std::max(lds, chain::bwd_lds_doubles<true, N>(pc.S));
+      if (on1) lds = std::max(lds, chain::bwd_lds_doubles<false, N>(pc.S));
+      lds *= 8;
+      a0.sync = sync.words; a1.sync = sync.words + 1; a0.sync_seq = a1.sync_seq = sync.seq;
+      const int nb0 = on0 ? 1 : 0, nbt = nb0 + (on1 ? 1 : 0);
+      const int nb0c = back0 ? pc.blocks : 0, nbc = nb0c + (on1 ? pc.blocks : 0);
+      const ChainPassDev cp{pc.level0, pc.m, pc.S, pc.first, pc.par, pc.lp_off};
+      hipLaunchKernelGGL((chain_top_back_kernel<N>), dim3(nbt + nbc), dim3(pl.threads), lds, st, a0, a1, nb0, AL, cp, nbt, nb0c);
+      a0.sync = a1.sync = nullptr;
+      continue;
+    }
     size_t lds = 0;
     if (ps.top) {
       if (on0) lds = std::max(lds, chain::fwd_lds_doubles<true, false, true, N>(ps.S));
@@ -90,9 +127,8 @@ inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1
     if (ps.top) hipLaunchKernelGGL((chain_forward_kernel<N, true>), dim3(nb), dim3(pl.threads), lds, st, a0, a1, nb0, AL);
     else hipLaunchKernelGGL((chain_forward_kernel<N, false>), dim3(nb), dim3(pl.threads), lds, st, a0, a1, nb0, AL);
   }
-  const bool back0 = on0 && a0.need_back;
   if (back0 || on1) {
-    for (int i = (int)pl.passes.size() - 2; i >= 0; --i) {
+    for (int i = npass - 2 - (merged ? 1 : 0); i >= 0; --i) {
       const ChainPass& ps = pl.passes[i];
       set(a0, ps); set(a1, ps);
       size_t lds = 0;
@@ -114,7 +150,7 @@ inline bool chain_wave_applies(int T, int n) { return chain_wave_enabled() && n 
 
 // n: the caller's block size (a0.n / a1.n are set here).  AL: the factor sets of an assemble-on-load (a0.asm_on / a1.asm_on), else null
 inline hipError_t chain_launch(int n, const ChainPlan& pl, ChainArgs a0, ChainArgs a1, bool on0, bool on1, hipStream_t st,
-                               const AsmList* AL = nullptr) {
+                               const AsmList* AL = nullptr, const ChainSync& sync = ChainSync{}) {
   a0.n = a1.n = n;
   AsmList none{};
   const AsmList& L = AL ? *AL : none;
@@ -126,14 +162,14 @@ inline hipError_t chain_launch(int n, const ChainPlan& pl, ChainArgs a0, ChainAr
     return hipGetLastError();
   }
   switch (chain_padded(n)) {
-    case 1: return chain_launch_t<1>(pl, a0, a1, on0, on1, st, L);
-    case 2: return chain_launch_t<2>(pl, a0, a1, on0, on1, st, L);
-    case 3: return chain_launch_t<3>(pl, a0, a1, on0, on1, st, L);
-    case 4: return chain_launch_t<4>(pl, a0, a1, on0, on1, st, L);
-    case 6: return chain_launch_t<6>(pl, a0, a1, on0, on1, st, L);
-    case 8: return chain_launch_t<8>(pl, a0, a1, on0, on1, st, L);
-    case 12: return chain_launch_t<12>(pl, a0, a1, on0, on1, st, L);
-    case 16: return chain_launch_t<16>(pl, a0, a1, on0, on1, st, L);
+    case 1: return chain_launch_t<1>(pl, a0, a1, on0, on1, st, L, sync);
+    case 2: return chain_launch_t<2>(pl, a0, a1, on0, on1, st, L, sync);
+    case 3: return chain_launch_t<3>(pl, a0, a1, on0, on1, st, L, sync);
+    case 4: return chain_launch_t<4>(pl, a0, a1, on0, on1, st, L, sync);
+    case 6: return chain_launch_t<6>(pl, a0, a1, on0, on1, st, L, sync);
+    case 8: return chain_launch_t<8>(pl, a0, a1, on0, on1, st, L, sync);
+    case 12: return chain_launch_t<12>(pl, a0, a1, on0, on1, st, L, sync);
+    case 16: return chain_launch_t<16>(pl, a0, a1, on0, on1, st, L, sync);
   }
   return hipErrorInvalidValue;
 }

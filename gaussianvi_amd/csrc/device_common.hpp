@@ -113,6 +113,29 @@ template <> __device__ __forceinline__ void kernarg_warm<13>() {
                : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
 #endif
 }
+template <> __device__ __forceinline__ void kernarg_warm<14>() {
+#ifndef GVI_NO_KERNARG_WARM      // (A/B build)
+  unsigned w[14];
+  asm volatile(
+               "s_load_dword %0, %14, 0x0\n"
+               "s_load_dword %1, %14, 0x40\n"
+               "s_load_dword %2, %14, 0x80\n"
+               "s_load_dword %3, %14, 0xc0\n"
+               "s_load_dword %4, %14, 0x100\n"
+               "s_load_dword %5, %14, 0x140\n"
+               "s_load_dword %6, %14, 0x180\n"
+               "s_load_dword %7, %14, 0x1c0\n"
+               "s_load_dword %8, %14, 0x200\n"
+               "s_load_dword %9, %14, 0x240\n"
+               "s_load_dword %10, %14, 0x280\n"
+               "s_load_dword %11, %14, 0x2c0\n"
+               "s_load_dword %12, %14, 0x300\n"
+               "s_load_dword %13, %14, 0x340\n"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(w[0]), "=&s"(w[1]), "=&s"(w[2]), "=&s"(w[3]), "=&s"(w[4]), "=&s"(w[5]), "=&s"(w[6]), "=&s"(w[7]), "=&s"(w[8]), "=&s"(w[9]), "=&s"(w[10]), "=&s"(w[11]), "=&s"(w[12]), "=&s"(w[13])
+               : "s"(__builtin_amdgcn_kernarg_segment_ptr()));
+#endif
+}
 template <> __device__ __forceinline__ void kernarg_warm<26>() {
 #ifndef GVI_NO_KERNARG_WARM      // (A/B build)
   unsigned w[26];

@@ -230,6 +230,10 @@ struct gvi_ctx {
   bool asm_on_load = true;
   bool asm_pending[2] = {false, false};
   DevMem Wbuf2, Ibuf2;                // second BCR workspace (the two chains are in flight together)
+  // merged top + backward launch of the chain (chain_launch.hpp::ChainSync): a ring of word pairs, one pair per launch
+  DevMem chain_sync;
+  unsigned chain_seq = 0;
+  bool chain_merge = true;
   DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
   DevMem epi_counter;                 // two-level arrival counters of epilogue_all_kernel's tail
   // trial precision formed inside the first pass of the next factorisation (see ChainArgs::mix*)
@@ -1016,7 +1020,18 @@ ChainArgs make_chain_args(gvi_ctx* c, const ChainWs& w, const double* D, const d
 gvi_status run_chain(gvi_ctx* c, const ChainArgs& a0, const ChainArgs& a1, bool on0, bool on1, const AsmList* AL = nullptr) {
   hipStream_t st = c->chain_stream ? c->chain_stream : c->stream;
   StageScope scope(c, STAGE_CHAIN);
-  const hipError_t e = chain_launch(c->n, chain_plan(c->T, c->n), a0, a1, on0, on1, st, AL);
+  ChainSync sy;
+  if (c->chain_merge) {
+    constexpr unsigned RING = 64;
+    if (!c->chain_sync.p) {
+      HIPCK(c, c->chain_sync.ensure(RING * 2 * sizeof(unsigned)));
+      HIPCK(c, hipMemset(c->chain_sync.p, 0, RING * 2 * sizeof(unsigned)));       // (once per context)
+    }
+    if (++c->chain_seq == 0) ++c->chain_seq;       // 0 is the cleared state of a word
+    sy.seq = c->chain_seq;
+    sy.words = (unsigned*)c->chain_sync.p + 2 * (sy.seq % RING);
+  }
+  const hipError_t e = chain_launch(c->n, chain_plan(c->T, c->n), a0, a1, on0, on1, st, AL, sy);
   if (e == hipErrorInvalidValue) return fail(c, GVI_ERR_UNSUPPORTED, "chain kernels: block size / LDS budget");
   HIPCK(c, e);
   return GVI_OK;
@@ -1095,6 +1110,7 @@ gvi_status gvi_ctx_create(int device, int dtype, gvi_ctx** out) {
   if (const char* w = getenv("GVI_ASM_ON_LOAD")) c->asm_on_load = atoi(w) != 0;
   if (const char* w = getenv("GVI_PIPELINE")) c->pipeline = atoi(w) != 0;
   if (const char* w = getenv("GVI_CHAIN_WAVE")) chain_wave_enabled() = atoi(w) != 0;     // (process-wide: A/B leg of kernels_chain_wave.hpp)
+  if (const char* w = getenv("GVI_CHAIN_MERGE")) c->chain_merge = atoi(w) != 0;
   if (const char* w = getenv("GVI_SREG_PIPE")) c->sreg_pipe = atoi(w) != 0;
   if (const char* w = getenv("GVI_MIRROR")) c->mirror = atoi(w) != 0;
   if (const char* w = getenv("GVI_NO_PAIR")) c->pair_fuse = atoi(w) == 0;
@@ -3329,6 +3345,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "assemble_on_load") ctx->asm_on_load = value != 0;
   else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chain_wave") chain_wave_enabled() = value != 0;
+  else if (n == "chain_merge") ctx->chain_merge = value != 0;
   else if (n == "trust_table_degree") ctx->trust_table_degree = value != 0;
   else if (n == "safe_publish") {
     GVICK(sync(ctx));

@@ -95,7 +95,14 @@ struct ChainArgs {
   double* asmG;
   const double* pred;    // predicated launch (device_common.hpp, pred_skip) or null
   double pred_val;
+  // top pass + first backward pass in ONE launch (chain_top_back_kernel): the top pass's workgroup stores sync_seq to *sync
+  // (release, agent scope) behind its last store; the backward workgroups wait for it in front of their first load of what
+  // the top pass wrote (chain_wait).  null: separate launches
+  unsigned* sync;
+  unsigned sync_seq;
 };
+// what changes from pass to pass (chain_launch.hpp::ChainPass), for the second pass of a merged launch
+struct ChainPassDev { int level0, m, S, first, par, lp_off; };
 
 // Chain-structured factor sets for the assemble-on-load: factor k of a binary set (d = 2n) couples states k, k + 1, factor
 // k of a unary set (d = n) sits on state k -- start[k] = k, so no CSR indirection (three INDEPENDENT loads per element
@@ -210,6 +217,12 @@ __device__ __forceinline__ void st_row(double* p, const double (&v)[N]) {
 
 __device__ __forceinline__ void lds_add(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// a result other workgroups of the SAME launch read (wt): written through at agent scope
+__device__ __forceinline__ void st_out(double* p, const double v, const bool wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
 }
 
 __device__ __forceinline__ double readlane64(double v, int src) {
@@ -434,7 +447,9 @@ __device__ __forceinline__ void marginal_node(double* sm, const int lane, const 
                                               const int oSaa, const int oSbb, const int oX, const int oY, const int oSee,
                                               const int oSL, const int oSLt, const int oSR, const int oSRt, double* gSee, double* gSL,
                                               double* gSR, double* gUa, double* gUe, const int n,
-                                              [[maybe_unused]] const bool stamp = false) {
+                                              [[maybe_unused]] const bool stamp = false, const bool wt = false) {
+  // wt: Sig[e,e] and the workspace copies of Sig[e,a] / Sig[e,b] are read by OTHER workgroups of this launch (merged top +
+  // backward launch): stored write-through at agent scope
   constexpr int nn = N * N, R = (nn + 63) / 64;
   double slv[R], srv[R];
   CHAIN_STAMP(stamp);
@@ -468,7 +483,7 @@ __device__ __forceinline__ void marginal_node(double* sm, const int lane, const 
       sm[oSL + el] = -sl;
       sm[oSLt + c * N + r] = -sl;
       if (has_b) { sm[oSR + el] = -sr; sm[oSRt + c * N + r] = -sr; }
-      if (gSL) { gSL[el] = -sl; if (has_b) gSR[el] = -sr; }
+      if (gSL) { st_out(gSL + el, -sl, wt); if (has_b) st_out(gSR + el, -sr, wt); }
       if (gUa && r < n && c < n) { gUa[c * n + r] = -sl; if (has_b) gUe[r * n + c] = -sr; }      // Sig[a,e] = Sig[e,a]^T ; Sig[e,b]
     }
   }
@@ -494,7 +509,7 @@ __device__ __forceinline__ void marginal_node(double* sm, const int lane, const 
     }
     if (on) {
       sm[oSee + el] = see;
-      if (r < n && c < n) gSee[r * n + c] = see;
+      if (r < n && c < n) st_out(gSee + r * n + c, see, wt);
     }
   }
   CHAIN_STAMP(stamp);
@@ -512,8 +527,43 @@ __host__ __device__ constexpr size_t fwd_lds_doubles(int S) {
 template <bool HAS_E, int N>
 __host__ __device__ constexpr size_t bwd_lds_doubles(int S) {
   constexpr int nn = N * N;
-  return HAS_E ? (size_t)5 * (S + 1) * nn + (size_t)3 * S * nn            // Sg, SL, SLt, SR, SRt ; E, GA, GB
-               : (size_t)(S + 1) * N + (size_t)S * N + (size_t)2 * S * nn;   // x, v, GA, GB
+  return (HAS_E ? (size_t)5 * (S + 1) * nn + (size_t)3 * S * nn            // Sg, SL, SLt, SR, SRt ; E, GA, GB
+                : (size_t)(S + 1) * N + (size_t)S * N + (size_t)2 * S * nn)   // x, v, GA, GB
+         + 2;                                                              // chain_wait's word
+}
+
+// ---- hand-over inside a launch (chain_top_back_kernel) ----
+// No fences: a release at agent scope writes the XCD's whole L2 back and an acquire invalidates it -- with both the merged
+// launch took exactly as long as the two launches it replaces (chain_bench, T = 1025, n = 6: 47.6 vs 47.4 us).  Instead the
+// producer stores what the consumers read WRITE-THROUGH at agent scope (st_out), every thread waits for its stores at the
+// barrier (vmcnt(0): the workgroup-scope release of __syncthreads), and thread 0 stores the word; the consumers read those
+// values -- and only those -- with agent-scope loads (chain_ld) behind the word.  Same protocol as the epilogue's tail
+// (kernels_factor.hpp, epi_tail).
+__device__ __forceinline__ void chain_signal(unsigned* sync, const unsigned seq) {
+  if (!sync) return;
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(sync, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Consumer: thread 0 polls (the producer's workgroups have the launch's lowest indices: they are resident before any waiting
+// one, and a waiting workgroup holds nothing the producer needs).  The wait is bounded (~0.5 s of polls), after which the
+// caller poisons what it would have read -- NaN results, a rejected step, never a hung device.  Returns false on the
+// time-out (block-uniform).
+__device__ __forceinline__ bool chain_wait(const unsigned* sync, const unsigned seq, int* lds_word) {
+  if (!sync) return true;
+  if (threadIdx.x == 0) {
+    int ok = 0;
+    for (int i = 0; i < (1 << 22); ++i) {
+      if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) { ok = 1; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *lds_word = ok;
+  }
+  __syncthreads();                                     // (no load of a consumer is issued before thread 0 has seen the word)
+  return *lds_word != 0;
+}
+// a value the top pass of the same launch wrote: read at agent scope (never from a stale line of this XCD's L2)
+__device__ __forceinline__ double chain_ld(const double* p, const bool fresh) {
+  return fresh ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
 
 // ---- passes A / B: one workgroup per segment ----
@@ -759,7 +809,8 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
     }
     // ---- backward recursion for the nodes of this pass ----
     if constexpr (HAS_Y) {                              // solve: x_e = v - GA x_a - GB x_b
-      if (tid < N) { const double v = sm[ovl + tid]; sm[oxl + tid] = v; if (tid < a.n) a.x[tid] = v; }
+      const bool wt = a.sync != nullptr;                // (merged launch: the backward workgroups beside us read x of our nodes)
+      if (tid < N) { const double v = sm[ovl + tid]; sm[oxl + tid] = v; if (tid < a.n) st_out(a.x + tid, v, wt); }
       lds_barrier();
       for (int lam = a.m - 1; lam >= 0; --lam) {
         const int h2 = 1 << lam;
@@ -780,10 +831,11 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
             for (int k = 0; k < N; ++k) xe = fma(-ga[k], xv[k], xe);
           }
           sm[oxl + j * N + r] = xe;
-          if (r < a.n) a.x[(size_t)x * a.n + r] = xe;
+          if (r < a.n) st_out(a.x + (size_t)x * a.n + r, xe, wt);
         }
         lds_barrier();
       }
+      chain_signal(a.sync, a.sync_seq);
     } else if (HAS_E) {
       if (!a.need_back) return;
       const int oSg = oDl, oSL = oRl, oSLt = oCt, oSR = oNU;   // the forward arrays are dead
@@ -792,7 +844,7 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
         const double v = sm[oEl + el];
         const int xe = ext_el<N>(a.n, el);
         sm[oSg + el] = v;
-        if (xe >= 0) a.SigD[xe] = v;
+        if (xe >= 0) st_out(a.SigD + xe, v, a.sync != nullptr);
       }
       lds_barrier();
       CHAIN_STAMP(true);
@@ -813,11 +865,12 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
                            oSg + j * nn, oSL + j * nn, oSLt + j * nn, oSR + j * nn, oSRt + j * nn, a.SigD + (size_t)x * (a.n * a.n),
                            ws_mat<N>(a, W_SL) + gx, ws_mat<N>(a, W_SR) + gx,
                            lvl0 ? a.SigU + (size_t)(x0 + ja * st) * (a.n * a.n) : nullptr,
-                           lvl0 ? a.SigU + (size_t)x * (a.n * a.n) : nullptr, a.n, true);
+                           lvl0 ? a.SigU + (size_t)x * (a.n * a.n) : nullptr, a.n, true, a.sync != nullptr);
         }
         lds_barrier();
         CHAIN_STAMP(true);
       }
+      chain_signal(a.sync, a.sync_seq);
     }
   }
 }
@@ -850,8 +903,16 @@ __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid,
       const int j = e / N, r = e % N, x = x0 + j * st;
       if (j > 0) sm[ovl + e] = ws_vec<N>(a, V_V)[(size_t)x * N + r];
     }
-    if (tid < N) sm[oxl + tid] = tid < a.n ? a.x[(size_t)x0 * a.n + tid] : 0.0;
-    if (ext_right && tid >= 64 && tid < 64 + N) sm[oxl + S * N + tid - 64] = tid - 64 < a.n ? a.x[(size_t)xn * a.n + tid - 64] : 0.0;
+    const bool fresh = a.sync != nullptr;               // merged launch: x of the boundary nodes comes from the top pass beside us
+    bool poison = false;
+    if (fresh) {
+      if (pred_fail(lpred)) return;                    // (the top pass's workgroup returns on the same predicate: nothing to wait for)
+      poison = !chain_wait(a.sync, a.sync_seq, (int*)(sm + oGB + S * nn));
+    }
+    const double nanv = __builtin_nan("");
+    if (tid < N) sm[oxl + tid] = poison ? nanv : (tid < a.n ? chain_ld(a.x + (size_t)x0 * a.n + tid, fresh) : 0.0);
+    if (ext_right && tid >= 64 && tid < 64 + N)
+      sm[oxl + S * N + tid - 64] = poison ? nanv : (tid - 64 < a.n ? chain_ld(a.x + (size_t)xn * a.n + tid - 64, fresh) : 0.0);
     if (pred_fail(lpred)) return;                      // (block-uniform; only LDS has been written)
     __syncthreads();
     for (int lam = a.m - 1; lam >= 0; --lam) {
@@ -915,14 +976,22 @@ __device__ __forceinline__ void backward_body(const ChainArgs& a, const int bid,
         }
       }
     }
+    const bool fresh = a.sync != nullptr;               // merged launch: Sig of the boundary nodes comes from the top pass beside us
+    bool poison = false;
+    if (fresh) {
+      if (pred_fail(lpred)) return;                    // (the top pass's workgroup returns on the same predicate: nothing to wait for)
+      poison = !chain_wait(a.sync, a.sync_seq, (int*)(sm + oGB + S * nn));
+    }
     for (int el = tid; el < nn; el += nthr) {
       const int r = el / N, c = el % N;
       const int xe = ext_el<N>(a.n, el);
       const double pad = r == c ? 1.0 : 0.0;
-      sm[oSg + el] = xe >= 0 ? a.SigD[(size_t)x0 * (a.n * a.n) + xe] : pad;
+      const double nanv = __builtin_nan("");
+      sm[oSg + el] = poison ? nanv : (xe >= 0 ? chain_ld(a.SigD + (size_t)x0 * (a.n * a.n) + xe, fresh) : pad);
       if (ext_right) {
-        sm[oSg + S * nn + el] = xe >= 0 ? a.SigD[(size_t)xn * (a.n * a.n) + xe] : pad;
-        const double v = x0_odd ? ws_mat<N>(a, W_SR)[(size_t)x0 * nn + el] : ws_mat<N>(a, W_SL)[(size_t)xn * nn + c * N + r];
+        sm[oSg + S * nn + el] = poison ? nanv : (xe >= 0 ? chain_ld(a.SigD + (size_t)xn * (a.n * a.n) + xe, fresh) : pad);
+        const double v = x0_odd ? chain_ld(ws_mat<N>(a, W_SR) + (size_t)x0 * nn + el, fresh)
+                                : chain_ld(ws_mat<N>(a, W_SL) + (size_t)xn * nn + c * N + r, fresh);
         sm[oSR + el] = v;                                    // Sig[x0, xn] [r][c]
         sm[oSRt + c * N + r] = v;
       }
@@ -980,6 +1049,31 @@ __global__ __launch_bounds__(chain_threads(N)) void chain_backward_kernel(ChainA
   kernarg_warm<KA_LINES>();
   if ((int)blockIdx.x < nb0) chain::backward_body<true, false, N>(a0, (int)blockIdx.x, sm);      // (predicate: inside)
   else chain::backward_body<false, true, N>(a1, (int)blockIdx.x - nb0, sm);
+}
+
+// The top pass and the backward recursion of the last segmented pass in ONE launch: blocks [0, nbt) are the top pass (as in
+// chain_forward_kernel<N, true>), the blocks behind them pass C's (as in chain_backward_kernel) with the pass parameters cp.
+// The backward workgroups load their segment's factors (written by the launch before) while the top pass runs, and wait for
+// its word (a0.sync / a1.sync) only in front of the boundary values: a kernel boundary and pass C's load phase leave the
+// critical path for one hand-over.
+template <int N>
+__global__ __launch_bounds__(chain_threads(N)) void chain_top_back_kernel(ChainArgs a0, ChainArgs a1, int nb0, AsmList AL, ChainPassDev cp,
+                                                                           int nbt, int nb0c) {
+  extern __shared__ double sm[];
+  constexpr int KA_LINES = (2 * sizeof(ChainArgs) + 8 + sizeof(AsmList) + sizeof(ChainPassDev) + 8 + 63) / 64;
+  static_assert(KA_LINES == 14, "kernarg_warm: one specialisation per argument block size");
+  kernarg_warm<KA_LINES>();
+  const int b = (int)blockIdx.x;
+  if (b < nbt) {
+    if (b < nb0) chain::forward_body<false, true, false, true, N>(a0, AL, b, sm);
+    else chain::forward_body<true, false, true, true, N>(a1, AL, b - nb0, sm);
+    return;
+  }
+  const int bc = b - nbt;
+  ChainArgs c = bc < nb0c ? a0 : a1;
+  c.level0 = cp.level0; c.m = cp.m; c.S = cp.S; c.first = cp.first; c.par = cp.par; c.lp_off = cp.lp_off;
+  if (bc < nb0c) chain::backward_body<true, false, N>(c, bc, sm);
+  else chain::backward_body<false, true, N>(c, bc - nb0c, sm);
 }
 
 }  // namespace gvi

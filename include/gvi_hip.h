@@ -341,6 +341,8 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  *   GVI_ASM_ON_LOAD      assemble_on_load    1        assemble inside the chain's first pass                 bit-identical
  *   GVI_PIPELINE         pipeline            1        gvi_ngd_run queues iteration i + 1 ahead of cost i     bit-identical
  *   GVI_CHAIN_WAVE       chain_wave          1        lane-per-node chain kernel for T <= 65, n <= 2         bit-identical
+ *   GVI_CHAIN_MERGE      chain_merge         1        top pass + first backward pass of the chain in one     bit-identical
+ *                                                     launch (0: one launch per pass)
  *   GVI_FUSE_TRIAL       (gvi_ngd_set_mode)  2        0 reference pass order, 1 fused trial, 2 adaptive      identical iterates
  *   GVI_SIDE_SOLVE       side_solve          1        gradient solve beside the trial factorisation          bit-identical
  *   GVI_NO_PAIR          pair_fuse           0 / 1    both chain sets in one psi launch (lane-per-point)     bit-identical
@@ -378,8 +380,12 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * above -20 return GVI_ERR_ARG -- the environment form GVI_JACOBI_TOL_EXP clamps to -20 instead).
  * chain_wave (default 1; process-wide, environment GVI_CHAIN_WAVE): chains of T <= 65 states of size n <= 2 run on the
  * lane-per-node kernel (one wave per chain operation) instead of the generic block-cyclic-reduction kernels.
+ * chain_merge (default 1; environment GVI_CHAIN_MERGE): a chain of more than one pass runs its top pass and the backward
+ * recursion of the last segmented pass in ONE launch (the backward workgroups wait for a device word the top pass's workgroup
+ * releases); 0: one launch per pass.
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,
- * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline, chain_wave, trust_table_degree, safe_publish. */
+ * orbit, fused, assemble_on_load, orbit_waves, orbit_min_tiles, orbit_stack, orbit_copies, chol_sqrt, jacobi_tol_exp, pipeline, chain_wave, chain_merge,
+ * trust_table_degree, safe_publish. */
 gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus

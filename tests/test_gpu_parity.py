@@ -1211,6 +1211,62 @@ def test_lane_per_node_chain_kernel_matches_the_generic_chain_kernels(name):
         assert rel(sa[k], sb[k]) < 1e-10, k
 
 
+@pytest.mark.parametrize("name", ["c3", "c5small"])
+def test_merged_top_and_backward_launch_is_bit_identical_to_one_launch_per_pass(name):
+    """chain_top_back_kernel (the top pass and the backward recursion of the last segmented pass in one launch; the backward
+    workgroups wait for a device word of the top pass's workgroup) against one launch per pass: the same arithmetic on the same
+    values, so chain operators and NGD iterates must agree bit for bit.  c3: T = 1025, n = 6 (two forward passes);
+    c5small: n = 12 (three or more forward passes: the merged launch carries only the LAST segmented pass's recursion)."""
+    ch = make_chain(name)
+    ctx, ids = api.context_for_chain(ch)
+    try:
+        res = []
+        for merge in (1, 0):
+            ctx.set_option("chain_merge", merge)
+            fac = (np.array([ctx.bt_logdet(ch["D0"], ch["U0"])]),) + tuple(ctx.bt_marginals(ch["D0"], ch["U0"]))
+            rhs = np.random.default_rng(3).normal(size=(ch["T"], ch["n"]))
+            x = ctx.bt_solve(ch["D0"], ch["U0"], rhs)
+            ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+            log = ctx.ngd_run(4, 0.55, 10)
+            res.append((fac, x, log, ctx.ngd_get_state()))
+    finally:
+        ctx.close()
+    (fa, xa, la, sa), (fb, xb, lb, sb) = res
+    for u, v in zip(fa, fb):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+    assert np.array_equal(xa, xb)
+    assert la == lb
+    for k in sb:
+        assert np.array_equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("T,n", [(1025, 12), (300, 8), (1057, 6), (40000, 6), (34, 6)])
+def test_merged_chain_launch_operators_on_multi_pass_plans(T, n):
+    """The chain operators alone on plans of two to four forward passes (T = 1025, n = 12: four), on a chain whose last
+    segment is a single node (1057 = 33 * 32 + 1), on one with more backward workgroups than the chip has CUs (T = 40000: the
+    waiting workgroups are dispatched behind the top pass's, which never waits) and on the shortest two-pass chain: merged
+    and separate launches agree bit for bit, and the solve's residual is small."""
+    rng = np.random.default_rng(T + n)
+    D, U = _spd_chain(T, n, rng)
+    rhs = rng.normal(size=(T, n))
+    ctx = api.Context(0)
+    ctx.chain_set(T, n)
+    out = []
+    for merge in (1, 0, 1):
+        ctx.set_option("chain_merge", merge)
+        out.append((ctx.bt_logdet(D, U),) + tuple(ctx.bt_marginals(D, U)) + (ctx.bt_solve(D, U, rhs),))
+    ctx.close()
+    for a, b in ((out[0], out[1]), (out[2], out[1])):
+        assert a[0] == b[0]
+        for u, v in zip(a[1:], b[1:]):
+            assert np.array_equal(u, v)
+    x = out[0][3]
+    Ax = np.einsum("tij,tj->ti", D, x)
+    Ax[:-1] += np.einsum("tij,tj->ti", U, x[1:])
+    Ax[1:] += np.einsum("tji,tj->ti", U, x[:-1])
+    assert np.abs(Ax - rhs).max() < 1e-9 * max(1.0, np.abs(D).max()) * max(1.0, np.abs(x).max())
+
+
 def test_asymmetric_user_table_keeps_the_unpaired_kernel():
     """gvi_factors_set_table with a table that is NOT mirror-symmetric (one weight perturbed): the +-pairing must not be
     used; results follow the oracle on that very table."""

@@ -99,6 +99,20 @@ static std::vector<OldPass> old_plan(int T, int n, int* threads) {
   *threads = n <= 8 ? 1024 : 512;
   return p;
 }
+// CHAIN_MERGE=1: the top pass and the first backward pass in one launch (chain_launch.hpp::ChainSync)
+static unsigned* g_sync_words = nullptr;
+static unsigned g_sync_seq = 0;
+static gvi::ChainSync next_sync() {
+  gvi::ChainSync sy;
+  const char* e = getenv("CHAIN_MERGE");
+  if (!e || atoi(e) == 0) return sy;
+  if (!g_sync_words) { (void)hipMalloc(&g_sync_words, 64 * 2 * sizeof(unsigned)); (void)hipMemset(g_sync_words, 0, 64 * 2 * sizeof(unsigned)); }
+  if (++g_sync_seq == 0) ++g_sync_seq;
+  sy.seq = g_sync_seq;
+  sy.words = g_sync_words + 2 * (sy.seq % 64);
+  return sy;
+}
+
 template <int N>
 static void old_launch(int T, SegArgs a0, SegArgs a1, hipStream_t st) {
   static bool attr = false;
@@ -190,12 +204,12 @@ static int run(int T, int n, int reps, bool with_old) {
 
   int fail = 0;
   clear_out();
-  CK(chain_launch(n, pl, a0, a1, true, true, st));
+  CK(chain_launch(n, pl, a0, a1, true, true, st, nullptr, next_sync()));
   fail |= check("new");
   // single operations through the same kernels
   clear_out();
-  CK(chain_launch(n, pl, a0, a1, true, false, st));
-  CK(chain_launch(n, pl, a0, a1, false, true, st));
+  CK(chain_launch(n, pl, a0, a1, true, false, st, nullptr, next_sync()));
+  CK(chain_launch(n, pl, a0, a1, false, true, st, nullptr, next_sync()));
   fail |= check("new/1");
 
   SegArgs o0{}, o1{};
@@ -211,11 +225,11 @@ static int run(int T, int n, int reps, bool with_old) {
   // run-to-run bit identity of the new kernels
   {
     std::vector<double> A(btD + btU), B(btD + btU);
-    CK(chain_launch(n, pl, a0, a1, true, true, st)); CK(hipStreamSynchronize(st));
+    CK(chain_launch(n, pl, a0, a1, true, true, st, nullptr, next_sync())); CK(hipStreamSynchronize(st));
     CK(hipMemcpy(A.data(), dSig, (btD + btU) * 8, hipMemcpyDeviceToHost));
     int diff = 0;
     for (int it = 0; it < 5; ++it) {
-      CK(chain_launch(n, pl, a0, a1, true, true, st)); CK(hipStreamSynchronize(st));
+      CK(chain_launch(n, pl, a0, a1, true, true, st, nullptr, next_sync())); CK(hipStreamSynchronize(st));
       CK(hipMemcpy(B.data(), dSig, (btD + btU) * 8, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < A.size(); ++i) diff += A[i] != B[i];
     }
@@ -229,7 +243,7 @@ static int run(int T, int n, int reps, bool with_old) {
     // barrier after each level, root, ..., backward: per node [phase 1 | sync | phase 2], barrier)
     int zero = 0;
     CK(hipMemcpyToSymbol(HIP_SYMBOL(gvi_chain_nstamp), &zero, sizeof(int)));
-    CK(chain_launch(n, pl, a0, a1, true, false, st));
+    CK(chain_launch(n, pl, a0, a1, true, false, st, nullptr, next_sync()));
     CK(hipStreamSynchronize(st));
     int ns = 0;
     std::vector<unsigned long long> stp(256);
@@ -254,9 +268,9 @@ static int run(int T, int n, int reps, bool with_old) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-28s %8.2f us per call\n", name, 1e3 * ms / reps);
   };
-  time_it("new: factor || solve", [&]() { CK(chain_launch(n, pl, a0, a1, true, true, st)); });
-  time_it("new: factor only", [&]() { CK(chain_launch(n, pl, a0, a1, true, false, st)); });
-  time_it("new: solve only", [&]() { CK(chain_launch(n, pl, a0, a1, false, true, st)); });
+  time_it("new: factor || solve", [&]() { CK(chain_launch(n, pl, a0, a1, true, true, st, nullptr, next_sync())); });
+  time_it("new: factor only", [&]() { CK(chain_launch(n, pl, a0, a1, true, false, st, nullptr, next_sync())); });
+  time_it("new: solve only", [&]() { CK(chain_launch(n, pl, a0, a1, false, true, st, nullptr, next_sync())); });
   if constexpr (N > 0) { if (with_old) time_it("old: factor || solve", [&]() { old_launch<N>(T, o0, o1, st); }); }
   {
     // the same launches with a predicate that does not hold: every block returns at its first instruction -- what the launch
@@ -266,7 +280,7 @@ static int run(int T, int n, int reps, bool with_old) {
     CK(hipMemset(dpred, 0, 8));
     ChainArgs s0 = a0, s1 = a1;
     s0.pred = s1.pred = dpred; s0.pred_val = s1.pred_val = 1.0;
-    time_it("skipped (predicate): both", [&]() { CK(chain_launch(n, pl, s0, s1, true, true, st)); });
+    time_it("skipped (predicate): both", [&]() { CK(chain_launch(n, pl, s0, s1, true, true, st, nullptr, next_sync())); });
     CK(hipFree(dpred));
   }
   return fail;
