@@ -25,6 +25,7 @@
 #include "kernels_factor.hpp"
 #include "kernels_orbit.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_block.hpp"
 #include "kernels_orbit_psi.hpp"
 #include "orbits.hpp"
 #include "spgh.hpp"
@@ -2423,12 +2424,117 @@ static gvi_status ngd_fused_full(gvi_ctx* ctx, int slot, int publish_slot) {
   return GVI_OK;
 }
 
+// ---- the planning graph's full pass as ONE launch (kernels_block.hpp) ----
+// The shape of moments_planar3_kernel (priors d = 8 / hinge on the SDF d = 4 / anchors d = 4, all on their lane-per-point
+// kernels), at most four chunks per factor (a workgroup's four waves take them), products
+// of this state not resident yet.  *done = false: not this shape -- the caller takes the three launches.
+static gvi_status ngd_block3_full(gvi_ctx* ctx, int slot, int publish_slot, bool* done) {
+  *done = false;
+  if (!ctx->fused || !ctx->pair_fuse || ctx->profile_all || ctx->sets.size() != 3 || ctx->variant != 0 || ctx->prefer_opsi) return GVI_OK;
+  if (ctx->update_rule != GVI_RULE_NGD) return GVI_OK;     // the JKO map reads the sets' Sigma^-1 after the pass
+  FactorSet* ss[3] = {ctx->sets[0].get(), ctx->sets[1].get(), ctx->sets[2].get()};
+  FactorSet &s0 = *ss[0], &s1 = *ss[1], &s2 = *ss[2];
+  const bool shape = s0.kind == KIND_QUAD_PRIOR && s0.d == 8 && s0.m == 4 && s1.kind == KIND_HINGE_SDF_2D && s1.d == 4 &&
+                     s2.kind == KIND_FIXED_PRIOR && s2.d == 4 && !s0.closed_form && !s2.closed_form && s0.K > 0 && s1.K > 0 && s2.K > 0;
+  if (!shape) return GVI_OK;
+  for (auto* q : ss)
+    if (q->prep_slot == slot) return GVI_OK;                 // products already resident: the plain route skips the prep
+  if (!s0.dev().chol || s1.dev().chol || !s2.dev().chol) return GVI_OK;     // the products the kernel is compiled for (kernels_block.hpp)
+  NgdState& g = ctx->ngd;
+  // the sets' moments launches exactly as they would go out on their own (chunking, table pointers, partial buffers)
+  gvi_ctx::Deferred dq[3];
+  gvi_status st = GVI_OK;
+  for (int q = 0; q < 3 && st == GVI_OK; ++q) {
+    dq[q].capture_any = true;
+    ctx->defer = &dq[q];
+    st = run_moments(ctx, *ss[q], ss[q]->mu_k[slot].d(), nullptr, 1);
+  }
+  ctx->defer = nullptr;
+  GVICK(st);
+  bool ok = true;
+  for (int q = 0; q < 3; ++q) ok = ok && dq[q].kind == 3 && dq[q].grid.y <= 4 && (int)dq[q].grid.y == dq[q].a.nchunk;
+  if (!ok) {                                   // some set took another route: whatever was captured is re-planned by the caller
+    for (int q = 0; q < 3; ++q)
+      if (dq[q].kind < 0) return fail(ctx, GVI_ERR_STATE, "planning-graph pass: a set launched while its siblings were captured");
+    return GVI_OK;
+  }
+  ++ctx->n_full_pass;
+  Block3Args A{};
+  A.nitems = s0.K + s1.K + s2.K;
+  A.pipe = (ctx->sreg_pipe && s0.table->Zq.p) ? 1 : 0;
+  for (int q = 0; q < 3; ++q) {
+    FactorSet& s = *ss[q];
+    BlockSet& B = A.s[q];
+    B.a = dq[q].a;
+    if (ctx->warm_start) {                 // warm-started Jacobi of the symmetric-root sets, as ngd_prep_all
+      if (s.Vws.bytes == 0) { HIPCK(ctx, s.Vws.ensure((size_t)s.K * s.d * s.d * 8)); s.warm_count = 0; }
+      B.a.f.Vws = s.Vws.d();
+      B.a.f.warm = (s.warm_count % 32) != 0;
+      s.warm_count++;
+    }
+    B.start = (const int32_t*)s.dstart.p;
+    B.mu_k = s.mu_k[slot].d(); B.Sigma_k = s.Sigma_k[slot].d();
+    B.Ephi = s.Ephi.d(); B.cost = s.cost.d(); B.Vdmu = s.Vdmu.d(); B.Vddmu = s.Vddmu.d();
+    s.prep_slot = slot;                        // the products go to memory as prep_all_kernel leaves them
+    s.fused_pair = false;
+  }
+  unsigned extra = 0;
+  if (g.gpend[slot].on) {
+    const size_t T = ctx->T, nn = nn_(ctx);
+    A.gather = 1; A.n = ctx->n;
+    A.gmu = g.gpend[slot].dmu ? g.gpend[slot].mu_from : g.mu[slot].d();
+    A.gdmu = g.gpend[slot].dmu; A.gstep = g.gpend[slot].step;
+    A.SigD = g.Sig[slot].d(); A.SigU = g.Sig[slot].d() + T * nn;
+    A.mu_out = g.mu[slot].d(); A.nmu = (int64_t)T * ctx->n;
+    if (A.gdmu) extra = (unsigned)((A.nmu + 255) / 256);
+    g.gpend[slot].on = false;
+  }
+  EpiTail& tail = A.tail;
+  tail.on = 0; tail.pred = ctx->cur_pred; tail.pred_val = ctx->cur_pred_val; tail.c0_use_imm = 1;
+  tail.safe = ctx->safe_publish ? 1 : 0;
+  if (publish_slot >= 0) {
+    const size_t need = (size_t)128 * (2 + (size_t)A.nitems / EPI_GROUP);
+    if (ctx->epi_counter.bytes < need) {
+      HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCK(ctx, ctx->epi_counter.ensure(need));
+      HIPCK(ctx, hipMemsetAsync(ctx->epi_counter.p, 0, need, ctx->stream));
+    }
+    ctx->seq += 1.0;
+    tail.on = 1; tail.acc = g.exch1.d(); tail.half_logdet = g.hld[publish_slot].d();
+    tail.host_out = pub_slot(ctx); tail.seq = ctx->seq; tail.counter = (unsigned*)ctx->epi_counter.p;
+    if (ctx->pipe_tail) {
+      tail.accept = ctx->pipe_dev.d() + ctx->pub_ring; tail.cost_dev = ctx->pipe_dev.d() + 2;
+      tail.slot_cur = 1 - publish_slot; tail.slot_trial = publish_slot;
+      tail.c0_use_imm = ctx->pipe_c0_imm ? 1 : 0; tail.c0_imm = ctx->pipe_c0;
+    }
+  }
+  A.cl.nsets = 3;
+  for (int q = 0; q < 3; ++q) { A.cl.cost[q] = ss[q]->cost.d(); A.cl.K[q] = ss[q]->K; }
+  const bool prof = ctx->profile && (ctx->profile_count++ % ctx->profile_every) == 0;
+  if (prof) {                                  // the bracket is booked on the obstacle set (the dominant one)
+    for (int e = 0; e < 2; ++e)
+      if (!s1.ev[0][e]) HIPCK(ctx, hipEventCreate(&s1.ev[0][e]));
+    HIPCK(ctx, hipEventRecord(s1.ev[0][0], ctx->stream));
+  }
+  const unsigned nblk = (unsigned)(block3_blocks(s0.K, A.s[0].a.nchunk) + block3_blocks(s1.K, A.s[1].a.nchunk) + block3_blocks(s2.K, A.s[2].a.nchunk));
+  hipLaunchKernelGGL(factor_block3_kernel, dim3(nblk + extra), dim3(256), 4 * block3_lds_doubles() * 8, ctx->stream, A);
+  HIPCK(ctx, hipGetLastError());
+  if (prof) { HIPCK(ctx, hipEventRecord(s1.ev[0][1], ctx->stream)); s1.ev_set[0] = true; }
+  *done = true;
+  return GVI_OK;
+}
+
 static gvi_status ngd_moments_full(gvi_ctx* ctx, int slot, int publish_slot = -1) {
   if ((int)ctx->sets.size() > MAX_SETS) return fail(ctx, GVI_ERR_UNSUPPORTED, "more than 8 factor sets");
   for (auto& s : ctx->sets)
     if (s->kind == KIND_HOST_CALLBACK) return fail(ctx, GVI_ERR_UNSUPPORTED, "resident NGD needs device psi kinds");
   StageScope scope(ctx, STAGE_FACTORS);
   if (fused_ok(ctx, slot)) return ngd_fused_full(ctx, slot, publish_slot);
+  {
+    bool done = false;
+    GVICK(ngd_block3_full(ctx, slot, publish_slot, &done));
+    if (done) return GVI_OK;
+  }
   GVICK(ngd_prep_all(ctx, slot));
   GVICK(ngd_moments_launch(ctx, slot, 1));
   return ngd_epilogue_all(ctx, 1, publish_slot);

@@ -116,7 +116,7 @@ __device__ inline double wave_sum(double v) {
 template <int EPLP, int DT>   // EPLP: elements of the d x d block per lane: 1 (d <= 8), 4 (d <= 16), 16 (d <= 32)
 // kin: index of the factor inside the (mu, Sigma) INPUT arrays (== k, or 0 when the caller staged this factor's
 // marginal in LDS); outputs always go to slot k
-__device__ inline void prep_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
+__device__ __forceinline__ void prep_body(const FactorDev& f, const double* mu, const double* Sigma, int k, double* sm, int kin) {
   const int d = DT ? DT : f.d, dd = d * d, lane = threadIdx.x & 63;      // one wave per factor (the fused kernel runs several per block)
   const int dp = d + (d & 1);
   double* A0 = sm;
@@ -1129,15 +1129,19 @@ template <int D> using PsiHingeSdf2D = PsiHingeSdf<D, KIND_HINGE_SDF_2D>;
 
 // (bx, by): the block's position in the (ceil(K / 4), nchunk) grid of the set -- the launch's own blockIdx, or a virtual one
 // when several sets share a launch (moments_planar3_kernel).  hs_: [4][Psi::LDS], red_: [4][16][65] doubles of LDS.
+// kfix >= 0 (factor_block3_kernel): the calling wave takes chunk byfix of factor kfix (idle when kfix >= K or byfix >= nchunk);
+// (bx, by) are then unused.  Same points per (factor, chunk), same sums.
 template <int D, typename Psi, bool FULL>
-__device__ __forceinline__ void reg_body(const MomArgs& a, const int bx, const int by, double* hs_, double* red_) {
+__device__ __forceinline__ void reg_body(const MomArgs& a, const int bx, const int by_, double* hs_, double* red_, const int kfix = -1,
+                                         const int byfix = 0) {
   constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
   constexpr int NB = (NP + 15) / 16;
   double (*hs)[Psi::LDS] = (double (*)[Psi::LDS])hs_;
   double (*red)[16][65] = (double (*)[16][65])red_;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int k = bx * 4 + wave;
-  const bool active = k < a.f.K;
+  const int k = kfix >= 0 ? kfix : bx * 4 + wave;
+  const int by = kfix >= 0 ? byfix : by_;
+  const bool active = k < a.f.K && by < a.nchunk;
   if (active) Psi::load(a, k, hs[wave], lane);
   __syncthreads();
   double acc[NP];
@@ -1486,14 +1490,16 @@ __global__ __launch_bounds__(256, 2) void moments_split_kernel(MomArgs a) {
 // consecutive factors over the same range of points.
 // ---------------------------------------------------------------------------------------------
 template <int D, int M, bool FULL>
-__device__ __forceinline__ void sreg_body(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
+__device__ __forceinline__ void sreg_body(const MomArgs& a, const int bx, const int by_, double* usb, double* redb, const int kfix = -1,
+                                          const int byfix = 0) {
   constexpr int NP = FULL ? (D + 1) * (D + 2) / 2 : 1;
   constexpr int NB = (NP + 15) / 16;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double* us_w = usb + wave * 2 * M;               // [2 M] u0 | sgn of this wave's factor
   double (*red_w)[65] = (double (*)[65])(redb + wave * 16 * 65);
-  const int kq = bx * 4 + wave;
-  const bool active = kq < a.f.K;
+  const int kq = kfix >= 0 ? kfix : bx * 4 + wave;            // (kfix: see reg_body)
+  const int by = kfix >= 0 ? byfix : by_;
+  const bool active = kq < a.f.K && by < a.nchunk;
   const int k = __builtin_amdgcn_readfirstlane(active ? kq : a.f.K - 1);   // inactive waves redo the last factor
   if (lane < M) {
     us_w[lane] = a.f.u0[(size_t)k * M + lane];
@@ -1641,7 +1647,8 @@ __device__ __forceinline__ void pipe_acc_rows(double (&acc)[(D + 1) * (D + 2) / 
 }
 
 template <int D, int M, bool SIGNED, bool MIRROR>
-__device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
+__device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, const int by_, double* usb, double* redb, const int kfix = -1,
+                                               const int byfix = 0) {
   constexpr int NP = (D + 1) * (D + 2) / 2;
   constexpr int NB = (NP + 15) / 16;
   // columns per SGPR operand group: the grouping of split_psi_rows (same operand traffic, same SGPR budget)
@@ -1654,8 +1661,9 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   double* us_w = usb + wave * 2 * M;               // [2 M] u0 | sgn of this wave's factor
   double (*red_w)[65] = (double (*)[65])(redb + wave * 16 * 65);
-  const int kq = bx * 4 + wave;
-  const bool active = kq < a.f.K;
+  const int kq = kfix >= 0 ? kfix : bx * 4 + wave;            // (kfix: see reg_body)
+  const int by = kfix >= 0 ? byfix : by_;
+  const bool active = kq < a.f.K && by < a.nchunk;
   const int k = __builtin_amdgcn_readfirstlane(active ? kq : a.f.K - 1);   // inactive waves redo the last factor
   if (lane < M) {
     us_w[lane] = a.f.u0[(size_t)k * M + lane];
@@ -1680,7 +1688,11 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
   const int64_t i0 = (int64_t)by * ck;
   const int64_t i1 = (i0 + ck < Np) ? i0 + ck : Np;
   const int ntiles = i1 > i0 ? (int)((i1 - i0) >> 6) : 0;   // chunks are whole 64-point tiles
-  const char* const Zq = (const char*)(MIRROR ? a.f.Zm : a.f.Zq);
+  // (through readfirstlane, as hq: the loads below take the base as an SGPR operand of their asm, and inside a larger kernel
+  // -- factor_block3_kernel with the symmetric-root products inlined beside it -- the compiler no longer proved it uniform)
+  const uint64_t zbase = (uint64_t)(MIRROR ? a.f.Zm : a.f.Zq);
+  const char* const Zq = (const char*)(((uint64_t)__builtin_amdgcn_readfirstlane((int)(zbase >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)zbase));
   unsigned voff = (unsigned)(i0 >> 6) * (unsigned)TB + (unsigned)lane * 8u + (unsigned)BIAS;
   unsigned idx = (unsigned)(i0 + lane);
   const unsigned nvalid = (unsigned)(MIRROR ? a.f.Nm : a.f.N);
@@ -1771,13 +1783,14 @@ __device__ __forceinline__ void sreg_pipe_body(const MomArgs& a, const int bx, c
 
 // every residual row of the set has positive weight (sgn = +1): the sign multiply of psi is dropped
 template <int D, int M>
-__device__ __forceinline__ void sreg_pipe_dispatch(const MomArgs& a, const int bx, const int by, double* usb, double* redb) {
+__device__ __forceinline__ void sreg_pipe_dispatch(const MomArgs& a, const int bx, const int by, double* usb, double* redb, const int kfix = -1,
+                                                   const int byfix = 0) {
   if (a.f.Zm) {
-    if (a.f.all_pos) sreg_pipe_body<D, M, false, true>(a, bx, by, usb, redb);
-    else sreg_pipe_body<D, M, true, true>(a, bx, by, usb, redb);
+    if (a.f.all_pos) sreg_pipe_body<D, M, false, true>(a, bx, by, usb, redb, kfix, byfix);
+    else sreg_pipe_body<D, M, true, true>(a, bx, by, usb, redb, kfix, byfix);
   } else {
-    if (a.f.all_pos) sreg_pipe_body<D, M, false, false>(a, bx, by, usb, redb);
-    else sreg_pipe_body<D, M, true, false>(a, bx, by, usb, redb);
+    if (a.f.all_pos) sreg_pipe_body<D, M, false, false>(a, bx, by, usb, redb, kfix, byfix);
+    else sreg_pipe_body<D, M, true, false>(a, bx, by, usb, redb, kfix, byfix);
   }
 }
 

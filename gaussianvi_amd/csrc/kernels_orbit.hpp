@@ -118,6 +118,15 @@ __host__ __device__ constexpr int orbit_hstride(int M) { return M == 12 ? 14 : M
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+#ifndef GVI_EXP_FLATATOM
+#define GVI_EXP_FLATATOM 0     // timing experiment (WRONG results): every accumulator add of a lane goes to the lane's own address
+#endif                         // (64 consecutive doubles per instruction: what the adds cost without bank / address conflicts)
+#if GVI_EXP_FLATATOM
+#define ORBIT_ADD_TARGET(expr, n, sh) ((double*)((char*)accb_flat(base, sh) + ((((n) & 1) * 64 + (int)(threadIdx.x & 63)) << 3)))
+__device__ __forceinline__ char* accb_flat(char* base, int sh) { return base - (((int)(threadIdx.x & 63) & ((1 << (sh - 3)) - 1)) << 3); }
+#else
+#define ORBIT_ADD_TARGET(expr, n, sh) ((double*)(expr))
+#endif
 // The accumulator adds of one orbit.  Values and LDS addresses are formed FIRST (the record's registers die there), then
 // pre() requests the next tile's records into those registers, then the adds go out.  accb: byte address of this lane's
 // copy of entry 0; entry e lives at accb + (e << sh), sh = log2(copies) + 3.
@@ -159,10 +168,10 @@ __device__ __forceinline__ void orbit_accumulate(const int sh, const int (&c)[S]
   int n = 0;
 #pragma unroll
   for (int i = 0; i < S; ++i) {
-    lds_add_f64((double*)(base1 + B[i]), val[n++]);
-    lds_add_f64((double*)(base + (A[i] + B[i])), val[n++]);
+    lds_add_f64(ORBIT_ADD_TARGET(base1 + B[i], n, sh), val[n]); ++n;
+    lds_add_f64(ORBIT_ADD_TARGET(base + (A[i] + B[i]), n, sh), val[n]); ++n;
 #pragma unroll
-    for (int j = i + 1; j < S; ++j) lds_add_f64((double*)(base + (A[i] + B[j])), val[n++]);
+    for (int j = i + 1; j < S; ++j) { lds_add_f64(ORBIT_ADD_TARGET(base + (A[i] + B[j]), n, sh), val[n]); ++n; }
   }
 }
 
@@ -178,6 +187,7 @@ __device__ __forceinline__ void orbit_accumulate(const int sh, const int (&c)[S]
 #ifndef GVI_EXP_NOATOM
 #define GVI_EXP_NOATOM 0       // timing experiment (WRONG results): the accumulator adds of supports <= this size are skipped
 #endif
+
 
 // one orbit per lane, support size S (all lanes of the wave: tiles are uniform in S)
 // pre(): called between the Gray walk and the accumulator adds -- where the walk's registers are dead -- to request the
@@ -627,10 +637,10 @@ __device__ __forceinline__ void orbit_class_grouped(const OrbitDev& ob, const in
       int n = 0;
 #pragma unroll
       for (int i = 0; i < S; ++i) {
-        lds_add_f64((double*)(base1 + B[i]), acc[n++]);
-        lds_add_f64((double*)(base + (A[i] + B[i])), acc[n++]);
+        lds_add_f64(ORBIT_ADD_TARGET(base1 + B[i], n, sh), acc[n]); ++n;
+        lds_add_f64(ORBIT_ADD_TARGET(base + (A[i] + B[i]), n, sh), acc[n]); ++n;
 #pragma unroll
-        for (int j = i + 1; j < S; ++j) lds_add_f64((double*)(base + (A[i] + B[j])), acc[n++]);
+        for (int j = i + 1; j < S; ++j) { lds_add_f64(ORBIT_ADD_TARGET(base + (A[i] + B[j]), n, sh), acc[n]); ++n; }
       }
     } else if constexpr (FULL) {
       double tsum = 0.0;

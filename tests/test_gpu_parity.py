@@ -1566,6 +1566,34 @@ def test_handover_stress_published_costs_equal_the_device_log(safe, iterations):
     print(f"\nhand-over stress safe_publish={safe}: {done} iterations, {1e3 * t_run / done:.4f} ms per iteration inside gvi_ngd_run")
 
 
+@pytest.mark.parametrize("name", ["planar", "planar1k"])
+def test_planning_graph_one_launch_factor_stage_is_bit_identical_to_three_launches(name):
+    """factor_block3_kernel (one workgroup per factor: products -> psi moments on chunk = wave -> chunk sum, cost tail,
+    back-transform; kernels_block.hpp) against prep_all_kernel -> moments_planar3_kernel -> epilogue_all_kernel (option
+    fused = 0): the same bodies on the same points in the same order, so costs, accept decisions and state agree bit for bit
+    -- stepwise with backtracking (cost-only passes reuse the products the one launch left in memory), in both pass orders,
+    and through the pipelined run."""
+    ch = make_chain(name)
+    runs = []
+    for fused in (1, 0):
+        ctx, ids = api.context_for_chain(ch)
+        ctx.set_option("fused", fused)
+        for mode in ((1, 2), (1, 0)):
+            ctx.ngd_set_mode(*mode)
+            ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+            log = [ctx.ngd_step(s, 10) for s in (0.55, 0.55, 3.5, 0.55)]
+            st = ctx.ngd_get_state()
+            ctx.ngd_init(ch["mu0"], ch["D0"], ch["U0"])
+            log2 = ctx.ngd_run(6, 0.55, 10)
+            runs.append((mode, log, st, log2, ctx.ngd_get_state()))
+        ctx.close()
+    half = len(runs) // 2
+    for (mode, la, sa, ra, ta), (_, lb, sb, rb, tb) in zip(runs[:half], runs[half:]):
+        assert la == lb and ra == rb, mode
+        assert all(np.array_equal(sa[k], sb[k]) for k in sa), mode
+        assert all(np.array_equal(ta[k], tb[k]) for k in ta), mode
+
+
 def test_planning_graph_three_set_launch_is_bit_identical_to_one_launch_per_set(monkeypatch):
     """The planning graph (d = 8 priors, d = 4 hinge-on-SDF obstacle factors, two d = 4 anchors: the reference's own GPU
     workload, helpers/CudaOperation.cu:74-119) issues its three moments launches as ONE (moments_planar3_kernel, every block
