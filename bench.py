@@ -611,6 +611,8 @@ def main():
 
         fused_launch = os.environ.get("GVI_FUSED", "1") != "0" and chain_pattern and geo["variant"] == 6 and geo["nchunk"] == 4 and \
             ((m0 == 6 and d0 == 12) or (m0 == 2 and d0 == 4))
+        block3_launch = (os.environ.get("GVI_FUSED", "1") != "0" and os.environ.get("GVI_NO_PAIR", "0") == "0" and world == 1 and
+                         [(int(sp["kind"]), int(sp["d"])) for sp in local["specs"]] == [(1, 8), (4, 4), (2, 4)])
         executed_note = None
         if chain_pattern:
             sets_in_launch = [(K0, d0, m0, N0, weights_signed(local["specs"][0]))]
@@ -708,6 +710,9 @@ def main():
                                     f"more record (one all-gather per iteration), issued inside the library ({'gloo callback (rehearsal)' if rehearsal else transport})") if sharded else "none",
                        "kernel_variant": geo["variant"], "chunks_per_factor": geo["nchunk"],
                        "fused_pass": bool(fused_launch),
+                       # the planning graph's full pass as one launch (kernels_block.hpp: products -> psi moments -> epilogue in a
+                       # workgroup); roofline.kernel below is its psi body, sampled as the set's own launch after the timed region
+                       "one_launch_factor_stage": bool(block3_launch),
                        "mirror_pairs": bool(geo["variant"] == 5 and os.environ.get("GVI_MIRROR", "1") != "0"),
                        "fuse_trial": args.fuse_trial},
             "ngd_iters_per_s": args.steps / elapsed,
