@@ -170,6 +170,9 @@ __device__ __forceinline__ void asm_pair(const AsmList& L, const int n, const in
   }
 }
 
+#ifndef GVI_CHAIN_UBLATE
+#define GVI_CHAIN_UBLATE 1     // 0: the rows of Ub fetched row by row inside the Schur products (A/B build)
+#endif
 #ifndef GVI_CHAIN_THREADS_SMALL
 #define GVI_CHAIN_THREADS_SMALL 1024
 #endif
@@ -419,12 +422,26 @@ __device__ __forceinline__ void eliminate(double* sm, const int lane, const Elim
   }
   if (has_b) {
     double s[N];
+    // UBLATE (N <= 6 at 128 registers): the rows of Ub are all requested HERE -- the prefetched rows of Ua are dead once t is
+    // formed, so their registers hold Ub -- with one wait in front of the products.  Left to the scheduler the eighteen
+    // ds_read_b128 went out in six groups with a wait each: six dependent LDS round trips per elimination (ISA of N = 6).
+    // chain_bench T = 1025, n = 6: 47.36 -> 46.83 us.  (The same for the operand rows of the backward step: no gain, 47.4.)
+    constexpr bool UBLATE = !UBPRE && GVI_CHAIN_UBLATE != 0 && N * N * 2 <= (RB == 128 ? 72 : 0);
+    double ubl[UBLATE ? N : 1][N];
+    if constexpr (UBLATE) {
+#pragma unroll
+      for (int r = 0; r < N; ++r) ld_row<N>(sm + io.oUb + r * N, ubl[r]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = 0; r < N; ++r) {
       double ubr[N];
       if (UBPRE) {
 #pragma unroll
         for (int k = 0; k < N; ++k) ubr[k] = ub[UBPRE ? r : 0][k];
+      } else if constexpr (UBLATE) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) ubr[k] = ubl[UBLATE ? r : 0][k];
       } else ld_row<N>(sm + io.oUb + r * N, ubr);          // UbT[r][:] = Ub[:, r]
       double acc = 0.0;
 #pragma unroll
