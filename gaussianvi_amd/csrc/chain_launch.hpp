@@ -68,7 +68,7 @@ inline hipError_t chain_allow_lds() {
 
 // The hand-over words of a merged top + backward launch (kernels_chain.hpp::chain_top_back_kernel): two device words (one per
 // operation) and a sequence number the caller advances with every chain_launch.  words == nullptr: separate launches.
-struct ChainSync { unsigned* words = nullptr; unsigned seq = 0; };
+struct ChainSync { unsigned* words = nullptr; unsigned seq = 0; unsigned fault = 0; };   // fault: test hook (ChainArgs::sync_fault)
 
 // on0: factorisation a0 (log-det; + selected inverse when a0.need_back); on1: pivoted solve a1.  Both: side by side in the
 // same launches.  Returns hipErrorInvalidValue when a pass does not fit LDS.
@@ -80,7 +80,7 @@ inline hipError_t chain_launch_t(const ChainPlan& pl, ChainArgs a0, ChainArgs a1
   auto set = [](ChainArgs& a, const ChainPass& ps) {
     a.level0 = ps.level0; a.m = ps.m; a.S = ps.S; a.first = ps.first; a.par = ps.par; a.lp_off = ps.lp_off;
   };
-  a0.sync = a1.sync = nullptr; a0.sync_seq = a1.sync_seq = 0;
+  a0.sync = a1.sync = nullptr; a0.sync_seq = a1.sync_seq = 0; a0.sync_fault = a1.sync_fault = sync.fault;
   const bool back0 = on0 && a0.need_back;
   const int npass = (int)pl.passes.size();
   // the top pass carries the backward workgroups of the last segmented pass when there is one and its LDS fits

@@ -235,6 +235,7 @@ struct gvi_ctx {
   DevMem chain_sync;
   unsigned chain_seq = 0;
   bool chain_merge = true;
+  bool chain_merge_fault = false;     // option chain_merge = 2: the hand-over word is stored wrong (test of the bounded wait)
   DevMem tail_counter;                // arrival counter of cost_tail_kernel (last block reduces)
   DevMem epi_counter;                 // two-level arrival counters of epilogue_all_kernel's tail
   // trial precision formed inside the first pass of the next factorisation (see ChainArgs::mix*)
@@ -1031,6 +1032,7 @@ gvi_status run_chain(gvi_ctx* c, const ChainArgs& a0, const ChainArgs& a1, bool 
     if (++c->chain_seq == 0) ++c->chain_seq;       // 0 is the cleared state of a word
     sy.seq = c->chain_seq;
     sy.words = (unsigned*)c->chain_sync.p + 2 * (sy.seq % RING);
+    sy.fault = c->chain_merge_fault ? 0x40000000u : 0u;
   }
   const hipError_t e = chain_launch(c->n, chain_plan(c->T, c->n), a0, a1, on0, on1, st, AL, sy);
   if (e == hipErrorInvalidValue) return fail(c, GVI_ERR_UNSUPPORTED, "chain kernels: block size / LDS budget");
@@ -3451,7 +3453,7 @@ gvi_status gvi_set_option(gvi_ctx* ctx, const char* name, int value) {
   else if (n == "assemble_on_load") ctx->asm_on_load = value != 0;
   else if (n == "pipeline") ctx->pipeline = value != 0;
   else if (n == "chain_wave") chain_wave_enabled() = value != 0;
-  else if (n == "chain_merge") ctx->chain_merge = value != 0;
+  else if (n == "chain_merge") { ctx->chain_merge = value != 0; ctx->chain_merge_fault = value == 2; }
   else if (n == "trust_table_degree") ctx->trust_table_degree = value != 0;
   else if (n == "safe_publish") {
     GVICK(sync(ctx));

@@ -100,6 +100,7 @@ struct ChainArgs {
   // the top pass wrote (chain_wait).  null: separate launches
   unsigned* sync;
   unsigned sync_seq;
+  unsigned sync_fault;   // test hook: added to the word the producer stores (the consumers then time out)
 };
 // what changes from pass to pass (chain_launch.hpp::ChainPass), for the second pass of a merged launch
 struct ChainPassDev { int level0, m, S, first, par, lp_off; };
@@ -562,17 +563,20 @@ __device__ __forceinline__ void chain_signal(unsigned* sync, const unsigned seq)
   if (threadIdx.x == 0) __hip_atomic_store(sync, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Consumer: thread 0 polls (the producer's workgroups have the launch's lowest indices: they are resident before any waiting
-// one, and a waiting workgroup holds nothing the producer needs).  The wait is bounded (~0.5 s of polls), after which the
-// caller poisons what it would have read -- NaN results, a rejected step, never a hung device.  Returns false on the
-// time-out (block-uniform).
+// one, and a waiting workgroup holds nothing the producer needs).  The wait is bounded (0.2 s on the 100 MHz counter), after
+// which the caller poisons what it would have read -- NaN results, a rejected step, never a hung device.  Returns false on
+// the time-out (block-uniform).  (ChainArgs::sync_fault, option chain_merge = 2: the producer stores a wrong word -- the
+// test of this path.)
+constexpr unsigned long long CHAIN_WAIT_TICKS = 20000000ull;
 __device__ __forceinline__ bool chain_wait(const unsigned* sync, const unsigned seq, int* lds_word) {
   if (!sync) return true;
   if (threadIdx.x == 0) {
     int ok = 0;
-    for (int i = 0; i < (1 << 22); ++i) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
+    do {
       if (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) { ok = 1; break; }
       __builtin_amdgcn_s_sleep(1);
-    }
+    } while (__builtin_amdgcn_s_memrealtime() - t0 < CHAIN_WAIT_TICKS);
     *lds_word = ok;
   }
   __syncthreads();                                     // (no load of a consumer is issued before thread 0 has seen the word)
@@ -852,7 +856,7 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
         }
         lds_barrier();
       }
-      chain_signal(a.sync, a.sync_seq);
+      chain_signal(a.sync, a.sync_seq + a.sync_fault);
     } else if (HAS_E) {
       if (!a.need_back) return;
       const int oSg = oDl, oSL = oRl, oSLt = oCt, oSR = oNU;   // the forward arrays are dead
@@ -887,7 +891,7 @@ __device__ __forceinline__ void forward_body(const ChainArgs& a, const AsmList& 
         lds_barrier();
         CHAIN_STAMP(true);
       }
-      chain_signal(a.sync, a.sync_seq);
+      chain_signal(a.sync, a.sync_seq + a.sync_fault);
     }
   }
 }

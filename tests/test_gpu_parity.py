@@ -1267,6 +1267,36 @@ def test_merged_chain_launch_operators_on_multi_pass_plans(T, n):
     assert np.abs(Ax - rhs).max() < 1e-9 * max(1.0, np.abs(D).max()) * max(1.0, np.abs(x).max())
 
 
+def test_merged_chain_launch_wait_is_bounded_and_poisons_instead_of_hanging():
+    """The backward workgroups of the merged launch wait for a device word of the top pass's workgroup.  With the word stored
+    wrong on purpose (option chain_merge = 2) every one of them must leave its wait after the bound (0.2 s on the device's
+    100 MHz counter), the call must return, and what it could not read must be NaN -- the marginals of the segments'
+    interior nodes and the solution there -- while the top pass's own nodes (every 32nd) are untouched.  Afterwards the same
+    context works normally again."""
+    import time
+    T, n = 1025, 6
+    rng = np.random.default_rng(5)
+    D, U = _spd_chain(T, n, rng)
+    rhs = rng.normal(size=(T, n))
+    ctx = api.Context(0)
+    ctx.chain_set(T, n)
+    good = tuple(ctx.bt_marginals(D, U)) + (ctx.bt_solve(D, U, rhs),)
+    ctx.set_option("chain_merge", 2)
+    t0 = time.time()
+    SD, SU = ctx.bt_marginals(D, U)
+    x = ctx.bt_solve(D, U, rhs)
+    dt = time.time() - t0
+    ctx.set_option("chain_merge", 1)
+    again = tuple(ctx.bt_marginals(D, U)) + (ctx.bt_solve(D, U, rhs),)
+    ctx.close()
+    assert dt < 5.0
+    interior = np.arange(T) % 32 != 0
+    assert np.isnan(SD[interior]).all() and np.isnan(x[interior]).all()
+    assert np.array_equal(SD[~interior], good[0][~interior]) and np.array_equal(x[~interior], good[2][~interior])
+    for a, b in zip(good, again):
+        assert np.array_equal(a, b)
+
+
 def test_asymmetric_user_table_keeps_the_unpaired_kernel():
     """gvi_factors_set_table with a table that is NOT mirror-symmetric (one weight perturbed): the +-pairing must not be
     used; results follow the oracle on that very table."""
