@@ -339,6 +339,13 @@ def main():
     # one-time costs (buffer growth on the first cost pass, side stream / event creation, kernel attribute calls, the
     # cold Jacobi start) are primed outside the contract's W warm-up steps as well, so a small W does not time them
     # (and a fixed ~25 ms of untimed iterations first: a fresh process on a fresh box starts at low clocks)
+    # No cyclic-GC pass of the interpreter inside the timed region (what timeit does): with torch imported a full collection
+    # walks ~10^6 objects and takes ~40 ms -- observed as ONE restart block of 6.35 ms per step among 84 blocks of 0.11 ms in a
+    # planar1k run (0.205 instead of 0.13 ms per step), and as the occasional 0.17 ms c3 line.  Collected HERE, in front of the
+    # priming and warm-up steps, not between the warm-up and the timed steps: 40 ms of an idle GPU right in front of the timed
+    # region dropped its clocks, and the first block of a 20-step region ran 8 % slower than the blocks behind it.
+    gc.collect()
+    gc.disable()
     if not big:
         for j in range(200):
             if j % args.restart_every == 0:
@@ -354,11 +361,6 @@ def main():
         step_fn(); pos += 1
     barrier()
     ctx.ngd_counters(reset=True)
-    # No cyclic-GC pass of the interpreter inside the timed region (what timeit does): with torch imported a full collection
-    # walks ~10^6 objects and takes ~40 ms -- observed as ONE restart block of 6.35 ms per step among 84 blocks of 0.11 ms in a
-    # planar1k run (0.205 instead of 0.13 ms per step), and as the occasional 0.17 ms c3 line.
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     kern_ms, log, block_ms = [], [], []
     if single and not args.per_step_calls:
@@ -383,6 +385,8 @@ def main():
                     kern_ms.append(ctx.profile_last(ids[0], 0))      # last bracketed launch (sampled: every 8th)
                 except api.GviError:
                     pass
+    t_blocks = time.perf_counter() - t0
+    ctx.sync()                                          # the library's stream, polled: the contract's barrier + synchronize below then finds the device idle
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -718,6 +722,7 @@ def main():
             "ngd_iters_per_s": args.steps / elapsed,
             # diagnosis only (`value` / `ms_per_step` are the whole timed region): per-step time of the gvi_ngd_run blocks without
             # the restarts between them; a max far above the median is a host / box stall (tens of ms have been seen), not the path
+            "timed_region_ms": {"total": 1e3 * elapsed, "step_calls": 1e3 * t_blocks, "closing_barrier_and_synchronize": 1e3 * (elapsed - t_blocks)},
             "block_ms_per_step": ({"median": float(np.median(block_ms)), "max": float(np.max(block_ms)), "blocks": len(block_ms)}
                                   if block_ms else None),
             # `value` split by pass kind (SURVEY 8(d) defines an evaluation "in one moments pass")

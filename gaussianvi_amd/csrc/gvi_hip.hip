@@ -353,8 +353,16 @@ gvi_status d2h(gvi_ctx* c, void* dst, const void* src, size_t bytes) {
   return GVI_OK;
 }
 gvi_status sync(gvi_ctx* c) {
-  HIPCK(c, hipStreamSynchronize(c->stream));
-  if (c->side) HIPCK(c, hipStreamSynchronize(c->side));
+  // polled for a while before the blocking wait: a blocked hipStreamSynchronize wakes up 50-70 us after the stream has drained
+  // (bench.py, closing synchronisation of a 2 ms timed region), a poll within a few
+  const auto t0 = std::chrono::steady_clock::now();
+  for (hipStream_t st : {c->stream, c->side}) {
+    if (!st) continue;
+    hipError_t e = hipStreamQuery(st);
+    while (e == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2)) e = hipStreamQuery(st);
+    if (e != hipSuccess && e != hipErrorNotReady) HIPCK(c, e);
+    HIPCK(c, hipStreamSynchronize(st));
+  }
   return GVI_OK;
 }
 
