@@ -122,8 +122,15 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 #define GVI_EXP_FLATATOM 0     // timing experiment (WRONG results): every accumulator add of a lane goes to the lane's own address
 #endif                         // (64 consecutive doubles per instruction: what the adds cost without bank / address conflicts)
 #if GVI_EXP_FLATATOM
-#define ORBIT_ADD_TARGET(expr, n, sh) ((double*)((char*)accb_flat(base, sh) + ((((n) & 1) * 64 + (int)(threadIdx.x & 63)) << 3)))
 __device__ __forceinline__ char* accb_flat(char* base, int sh) { return base - (((int)(threadIdx.x & 63) & ((1 << (sh - 3)) - 1)) << 3); }
+// (= 2: the real address is still computed -- kept alive by an empty asm -- so that only the conflicts are taken out)
+__device__ __forceinline__ double* orbit_flat_target(char* real, char* base, int n, int sh) {
+#if GVI_EXP_FLATATOM == 2
+  asm volatile("" :: "v"(real));
+#endif
+  return (double*)(accb_flat(base, sh) + ((((n) & 1) * 64 + (int)(threadIdx.x & 63)) << 3));
+}
+#define ORBIT_ADD_TARGET(expr, n, sh) orbit_flat_target((char*)(expr), base, n, sh)
 #else
 #define ORBIT_ADD_TARGET(expr, n, sh) ((double*)(expr))
 #endif
