@@ -123,7 +123,8 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 #endif                         // (64 consecutive doubles per instruction: what the adds cost without bank / address conflicts)
 #if GVI_EXP_FLATATOM
 __device__ __forceinline__ char* accb_flat(char* base, int sh) { return base - (((int)(threadIdx.x & 63) & ((1 << (sh - 3)) - 1)) << 3); }
-// (= 2: the real address is still computed -- kept alive by an empty asm -- so that only the conflicts are taken out)
+// (= 2: the real address is still computed -- kept alive by an empty asm -- so that only the conflicts are taken out;
+//  = 3: flat targets, and the record's coordinates / row bases kept live up to the adds without being used)
 __device__ __forceinline__ double* orbit_flat_target(char* real, char* base, int n, int sh) {
 #if GVI_EXP_FLATATOM == 2
   asm volatile("" :: "v"(real));
@@ -161,6 +162,11 @@ __device__ __forceinline__ void orbit_accumulate(const int sh, const int (&c)[S]
       for (int j = i + 1; j < S; ++j) val[n++] = wm * mgl[j] * Eij[e++];
     }
   }
+#if GVI_EXP_FLATATOM == 3      // (the record's coordinates and row bases stay live up to here, but no address is formed from them)
+#pragma unroll
+  for (int i = 0; i < S; ++i) asm volatile("" :: "v"(c[i]));
+  asm volatile("" :: "v"(rpk));
+#endif
   pre();
   char* const base = (char*)accb;
   char* const base1 = base + (1u << sh);                         // m1[0]
