@@ -18,6 +18,8 @@
 // workgroup barriers.  Results are bit-identical to the three launches (tests: test_planning_graph_one_launch_*).
 // (First version: one workgroup per factor, phases 1 and 3 on wave 0 -- a quarter of the resident waves active in the two
 // latency-bound phases: 54.6 us against the three launches' 46.1.)
+// (The tail protocol on a factor's idle second wave, as factor_fused_kernel runs it: every form tried made the compiler merge
+// call sites over a pointer into the argument block and copy the block to scratch -- see block_products_of; not kept.)
 #pragma once
 #include "kernels_factor.hpp"
 
