@@ -563,11 +563,11 @@ __device__ __forceinline__ void chain_signal(unsigned* sync, const unsigned seq)
   if (threadIdx.x == 0) __hip_atomic_store(sync, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Consumer: thread 0 polls (the producer's workgroups have the launch's lowest indices: they are resident before any waiting
-// one, and a waiting workgroup holds nothing the producer needs).  The wait is bounded (0.2 s on the 100 MHz counter), after
+// one, and a waiting workgroup holds nothing the producer needs).  The wait is bounded (1 s on the 100 MHz counter), after
 // which the caller poisons what it would have read -- NaN results, a rejected step, never a hung device.  Returns false on
 // the time-out (block-uniform).  (ChainArgs::sync_fault, option chain_merge = 2: the producer stores a wrong word -- the
 // test of this path.)
-constexpr unsigned long long CHAIN_WAIT_TICKS = 20000000ull;
+constexpr unsigned long long CHAIN_WAIT_TICKS = 100000000ull;   // 1 s: far above a time slice of a GPU shared between processes
 __device__ __forceinline__ bool chain_wait(const unsigned* sync, const unsigned seq, int* lds_word) {
   if (!sync) return true;
   if (threadIdx.x == 0) {

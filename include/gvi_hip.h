@@ -382,7 +382,7 @@ gvi_status gvi_set_variant(gvi_ctx* ctx, int variant);
  * lane-per-node kernel (one wave per chain operation) instead of the generic block-cyclic-reduction kernels.
  * chain_merge (default 1; environment GVI_CHAIN_MERGE): a chain of more than one pass runs its top pass and the backward
  * recursion of the last segmented pass in ONE launch (the backward workgroups wait for a device word the top pass's workgroup
- * releases); 0: one launch per pass.  The wait is bounded (0.2 s); on a time-out the waiting workgroups take NaN for what they
+ * releases); 0: one launch per pass.  The wait is bounded (1 s); on a time-out the waiting workgroups take NaN for what they
  * would have read, so the affected marginals / solution are NaN and the step is rejected -- value 2 is the test of that path
  * (the word is stored wrong on purpose).
  * Names: split_flush, sreg_pipe, mirror, pair_fuse, fuse_gather, side_solve, dual_chain, warm_start, no_scost, target_waves,

@@ -1269,7 +1269,7 @@ def test_merged_chain_launch_operators_on_multi_pass_plans(T, n):
 
 def test_merged_chain_launch_wait_is_bounded_and_poisons_instead_of_hanging():
     """The backward workgroups of the merged launch wait for a device word of the top pass's workgroup.  With the word stored
-    wrong on purpose (option chain_merge = 2) every one of them must leave its wait after the bound (0.2 s on the device's
+    wrong on purpose (option chain_merge = 2) every one of them must leave its wait after the bound (1 s on the device's
     100 MHz counter), the call must return, and what it could not read must be NaN -- the marginals of the segments'
     interior nodes and the solution there -- while the top pass's own nodes (every 32nd) are untouched.  Afterwards the same
     context works normally again."""
@@ -1289,7 +1289,7 @@ def test_merged_chain_launch_wait_is_bounded_and_poisons_instead_of_hanging():
     ctx.set_option("chain_merge", 1)
     again = tuple(ctx.bt_marginals(D, U)) + (ctx.bt_solve(D, U, rhs),)
     ctx.close()
-    assert dt < 5.0
+    assert dt < 20.0
     interior = np.arange(T) % 32 != 0
     assert np.isnan(SD[interior]).all() and np.isnan(x[interior]).all()
     assert np.array_equal(SD[~interior], good[0][~interior]) and np.array_equal(x[~interior], good[2][~interior])
